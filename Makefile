@@ -1,0 +1,35 @@
+# Build recipe for the native pieces.  `make` builds the product library (HIP, gfx950).
+# `make hostcheck` builds the CPU debug harness of the per-ray core used by tests only.
+ROOT := $(dir $(abspath $(lastword $(MAKEFILE_LIST))))
+HIPCC ?= hipcc
+CXX ?= g++
+ARCH ?= gfx950
+
+LIB := $(ROOT)tracer_amd/lib/libtracer_amd.so
+SRC := $(ROOT)tracer_amd/csrc/trc_kernels.hip
+HDR := $(ROOT)tracer_amd/csrc/trc_core.h $(ROOT)include/tracer_amd.h
+
+HOSTCHECK := $(ROOT)tests/hostcheck/libtrc_hostcheck.so
+HOSTCHECK_SRC := $(ROOT)tests/hostcheck/hostcheck.cpp
+
+all: $(LIB)
+
+$(LIB): $(SRC) $(HDR)
+	mkdir -p $(dir $(LIB))
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -munsafe-fp-atomics -fPIC -shared \
+		-Wno-unused-result -o $@ $(SRC)
+
+hostcheck: $(HOSTCHECK)
+
+$(HOSTCHECK): $(HOSTCHECK_SRC) $(HDR)
+	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -o $@ $(HOSTCHECK_SRC)
+
+asm: $(SRC) $(HDR)
+	mkdir -p $(ROOT)build
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -munsafe-fp-atomics -S --cuda-device-only \
+		-Rpass-analysis=kernel-resource-usage -o $(ROOT)build/trc_kernels.s $(SRC)
+
+clean:
+	rm -f $(LIB) $(HOSTCHECK)
+
+.PHONY: all hostcheck asm clean

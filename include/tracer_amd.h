@@ -1,0 +1,306 @@
+/*
+ * tracer_amd.h -- C-ABI of the MI355X-native Monte-Carlo ray-tracing core.
+ *
+ * This is the drop-in boundary for ONE hot path of casselineau/Tracer:
+ * TracerEngine.ray_tracer() (reference: tracer/tracer_engine.py:124-295) and
+ * everything it calls per ray per bounce.  The reference has no FFI (it is pure
+ * NumPy); each entry point below cites the reference Python interface it
+ * replaces.  The Python host layer (the tracer_amd package) binds these through
+ * ctypes; INTEGRATION.md shows the binding a Tracer maintainer would add.
+ *
+ * Conventions
+ *   - every function returns TRC_OK (0) or a negative trc_status; the message
+ *     of the last failure on the calling thread is trc_last_error().
+ *   - the caller owns every host buffer; the library owns device memory.
+ *   - all real data is float64 (the reference computes in float64 throughout,
+ *     tracer/ray_bundle.py:25-33); indices are int64 / int32 as declared.
+ *   - vectors cross the boundary as structure-of-arrays (one pointer per
+ *     component) so that HBM loads are coalesced; the Python shim passes the
+ *     rows of the reference's (3,N) arrays without copying.
+ *   - no global state: a trc_ctx is bound to one GPU; scenes/results belong
+ *     to a context.  One context per (thread, GPU).
+ */
+#ifndef TRACER_AMD_H
+#define TRACER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRC_ABI_VERSION 1
+
+typedef enum trc_status {
+    TRC_OK = 0,
+    TRC_ERR_INVALID = -1,      /* bad argument (reference: ValueError / AttributeError) */
+    TRC_ERR_DEVICE = -2,       /* HIP runtime failure */
+    TRC_ERR_UNSUPPORTED = -3,  /* kind not in the native table */
+    TRC_ERR_CAPACITY = -4,     /* a fixed-capacity device buffer overflowed */
+    TRC_ERR_NOMEM = -5
+} trc_status;
+
+/* ---- geometry managers (reference classes in parentheses) ------------------ */
+typedef enum trc_gm_kind {
+    TRC_GM_FLAT_INF = 0,           /* FlatGeometryManager        flat_surface.py:11-113   */
+    TRC_GM_RECT = 1,               /* RectPlateGM                flat_surface.py:181-211  gm: w/2,h/2 */
+    TRC_GM_RECT_EXTRUDED = 2,      /* ExtrudedRectPlateGM        flat_surface.py:253-274  gm: w/2,h/2,cx,cy,ew/2,eh/2 */
+    TRC_GM_RECT_PERFORATED = 3,    /* PerforatedRectPlateGM      flat_surface.py:357-377  gm: w/2,h/2 ; extra: n*(cx,cy,r) */
+    TRC_GM_ROUND = 4,              /* RoundPlateGM               flat_surface.py:457-492  gm: Re,Ri(<0:none) */
+    TRC_GM_ROUND_CUT = 5,          /* StraightCutRoundPlateGM    flat_surface.py:548-560  gm: Re,Ri,x_cut */
+    TRC_GM_TRIANGLE = 6,           /* TriangularFace             triangular_face.py:35-74 gm: v0xyz,v1xyz */
+    TRC_GM_PARABOLOID = 7,         /* Paraboloid                 paraboloid.py:11-69      gm: a,b */
+    TRC_GM_PARAB_DISH = 8,         /* ParabolicDishGM            paraboloid.py:71-119     gm: a,b,h */
+    TRC_GM_PARAB_HEX = 9,          /* HexagonalParabolicDishGM   paraboloid.py:174-223    gm: a,b,R */
+    TRC_GM_PARAB_RECT = 10,        /* RectangularParabolicDishGM paraboloid.py:225-294    gm: a,b,w/2,h/2 */
+    TRC_GM_PARAB_RECT_OFFAXIS = 11,/* same, off_axis_normal set  paraboloid.py:279-281    gm: a,b,w/2,h/2,rot[9],centre[3] */
+    TRC_GM_PARAB_CYL = 12,         /* ParabolicCylinder          paraboloid.py:328-384    gm: a */
+    TRC_GM_PARAB_TROUGH = 13,      /* ParabolicTroughGM          paraboloid.py:386-443    gm: a,l/2,h */
+    TRC_GM_SPHERE = 14,            /* SphericalGM                sphere_surface.py:9-68   gm: r */
+    TRC_GM_HEMISPHERE = 15,        /* HemisphereGM               sphere_surface.py:117-139 gm: r */
+    TRC_GM_SPHERE_RECT = 16,       /* SphericalRectFacet         sphere_surface.py:206-228 gm: r,lx/2,ly/2 */
+    TRC_GM_CYL_INF = 17,           /* InfiniteCylinder           cylinder.py:12-57        gm: R */
+    TRC_GM_CYL_FINITE = 18,        /* FiniteCylinder             cylinder.py:59-110       gm: R,h/2,a0,a1 */
+    TRC_GM_CYL_RECTCUT = 19,       /* RectCutCylinder            cylinder.py:161-199      gm: R,h/2,w/2,hh/2 */
+    TRC_GM_CONE_INF = 20,          /* InfiniteCone               cone.py:7-72             gm: c,a */
+    TRC_GM_CONE_FINITE = 21,       /* FiniteCone (and RectCutCone, which the reference
+                                      silently runs as FiniteCone, cone.py:161)  cone.py:74-120  gm: c,a,h */
+    TRC_GM_FRUSTUM = 22,           /* ConicalFrustum             cone.py:261-320          gm: c,a,zmin,zmax */
+    TRC_GM_FRUSTUM_RECTCUT = 23,   /* RectCutConicalFrustum      cone.py:356-395          gm: c,a,zmin,zmax,w/2,h/2 */
+    TRC_GM_QUADRATIC = 24,         /* FlatQuadricSurfaceGM       quadratic_surface.py:4-61  gm: a,b,c,d,e,f */
+    TRC_GM_QUADRATIC_RECT = 25,    /* RectFlatQuadricSurfaceGM   quadratic_surface.py:64-105 gm: a..f,w/2,h/2 */
+    TRC_GM_ELLIPSOID = 26,         /* Ellipsoid                  ellipsoid.py:5-61        gm: a,b,c (1/semi-axis^2) */
+    TRC_GM_ELLIPSOID_CUT = 27,     /* EllipsoidGM                ellipsoid.py:63-118      gm: a,b,c,xlo,xhi,ylo,yhi,zlo,zhi */
+    TRC_GM_KIND_COUNT = 28
+} trc_gm_kind;
+
+/* ---- optics callables (reference: tracer/optics_callables.py) -------------- */
+typedef enum trc_optics_kind {
+    TRC_OPT_TRANSPARENT = 0,            /* Transparent             :93-113   */
+    TRC_OPT_REFLECTIVE = 1,             /* Reflective              :116-140   opt: absorptivity */
+    TRC_OPT_ONE_SIDED_REFLECTIVE = 2,   /* OneSidedReflective      :195-212   opt: absorptivity */
+    TRC_OPT_REAL_REFLECTIVE = 3,        /* RealReflective          :214-269   opt: absorptivity,sigma,bi_var */
+    TRC_OPT_ONE_SIDED_REAL_REFLECTIVE = 4, /* OneSidedRealReflective :492-504 opt: absorptivity,sigma,bi_var */
+    TRC_OPT_LAMBERTIAN = 5,             /* Lambertian              :143-176   opt: absorptivity,ang_range */
+    TRC_OPT_LAMBERTIAN_SPECULAR = 6,    /* LambertianSpecular      :553-585   opt: absorptivity,specularity */
+    TRC_OPT_REFRACTIVE_HOMOGENOUS = 7,  /* RefractiveHomogenous    :1186-1296 opt: n1,n2,single_ray,sigma(<0:none) */
+    TRC_OPT_REFLECTIVE_SPECTRAL = 8,    /* Reflective_spectral     :178-193   extra: n*(lambda,absorptance) */
+    TRC_OPT_KIND_COUNT = 9
+} trc_optics_kind;
+
+/* surface flags */
+#define TRC_SURF_CAPTURE_HITS 0x1  /* append every hit to the scene hit buffer (Location/Direction accountants) */
+
+/*
+ * One Surface of the flattened Assembly (reference: tracer/surface.py:6-112 +
+ * its GeometryManager + its optics callable).  frame is Surface._temp_frame
+ * (has_frame.py:70-75) rows 0..2, row-major: frame[4*r+k], k=0..2 rotation,
+ * k=3 translation.
+ */
+typedef struct trc_surface_desc {
+    int32_t gm_kind;
+    int32_t optics_kind;
+    int32_t flags;
+    int32_t extra_off;   /* first index into the scene's `extra` array, or -1 */
+    int32_t extra_len;   /* number of doubles */
+    int32_t reserved;
+    double frame[12];
+    double gm[16];
+    double opt[8];
+} trc_surface_desc;
+
+/*
+ * A ray bundle as structure-of-arrays (reference: RayBundle, ray_bundle.py:6-195).
+ * Required: x..e.  Optional (NULL when absent): parent, ref_index, wavelength, rid.
+ * `rid` is the 64-bit random-stream id of a ray (RNG); when NULL
+ * it is ray_offset + index.  on_device != 0 means the pointers are device
+ * pointers valid in this process (e.g. torch tensors on the context's GPU).
+ */
+typedef struct trc_rays {
+    int64_t n;
+    int32_t on_device;
+    int32_t reserved;
+    double *x, *y, *z;
+    double *dx, *dy, *dz;
+    double *e;
+    int64_t *parent;
+    double *ref_index;
+    double *wavelength;
+    uint64_t *rid;
+} trc_rays;
+
+/* ---- sources (reference: tracer/sources.py) -------------------------------- */
+typedef enum trc_source_kind {
+    TRC_SRC_PILLBOX_DISK = 0,  /* disk_bundle    sources.py:175-239  p: radius,radius_in,span0,span1,ang_range */
+    TRC_SRC_PILLBOX_RECT = 1,  /* rect_bundle    sources.py:241-264  p: x,y,ang_range,swap_xy */
+    TRC_SRC_BUIE_DISK = 2,     /* buie_sunshape  sources.py:412-464  p: radius ; tables */
+    TRC_SRC_BUIE_RECT = 3      /* rect_buie_sunshape sources.py:466-515 p: width,height ; tables */
+} trc_source_kind;
+
+#define TRC_BUIE_NELEM 210  /* sources.py:338 */
+
+/*
+ * Source descriptor: everything that does not depend on the random draws is
+ * evaluated once on the host (rotation_to_z frames spatial_geometry.py:24-48,
+ * per-ray energy, the Buie CDF table sources.py:333-361) and passed here.
+ * buie[] layout: theta[211] | g[211] (=phi*cos*sin) | cdf[211] |
+ *   I_dni, gamma, kappa, theta_dni, theta_tot, csr_positive.
+ */
+typedef struct trc_source_desc {
+    int32_t kind;
+    int32_t reserved;
+    double center[3];
+    double rot_pos[9];  /* row-major local->global for start points */
+    double rot_dir[9];  /* row-major local->global for directions   */
+    double p[8];
+    double energy;      /* energy carried by each ray */
+    double buie[3 * (TRC_BUIE_NELEM + 1) + 6];
+} trc_source_desc;
+
+/* ---- Kd-tree (reference: tracer/accel_tree.py) ------------------------------ */
+/*
+ * Flattened tree as built on the host with the reference's SAH rules
+ * (accel_tree.py:42-204).  flag: 0/1/2 = split axis, 3 = leaf.  Interior:
+ * split + child (children are child, child+1).  Leaf: leaf_off/leaf_cnt into
+ * leaf_surfs.  always_relevant: surfaces of objects without boundaries
+ * (accel_tree.py:59-73).  bounds: root box min xyz, max xyz.
+ */
+typedef struct trc_kdtree_desc {
+    int32_t n_nodes;
+    int32_t n_leaf_surfs;
+    int32_t n_always;
+    int32_t reserved;
+    const int32_t *flag;
+    const double *split;
+    const int32_t *child;
+    const int32_t *leaf_off;
+    const int32_t *leaf_cnt;
+    const int32_t *leaf_surfs;
+    const int32_t *always_relevant;
+    double bounds[6];
+} trc_kdtree_desc;
+
+typedef struct trc_ctx trc_ctx;
+typedef struct trc_scene trc_scene;
+typedef struct trc_result trc_result;
+
+/* trace flags */
+#define TRC_TRACE_ACCEL 0x1        /* use the Kd-tree set on the scene (ray_tracer(accel=...)) */
+#define TRC_TRACE_KEEP_LAST 0x2    /* fast engine: keep rays still alive after `reps` bounces */
+
+typedef struct trc_trace_stats {
+    int64_t segments;     /* sum over bounces of live rays (SURVEY 8(d) unit of work) */
+    int64_t hits;         /* segments that hit a surface */
+    int64_t rays_left;    /* rays still alive after the last bounce */
+    int64_t hits_dropped; /* hits not captured because the hit buffer was full */
+    double energy_left;
+    double kernel_ms;     /* device time of the trace kernels (HIP events on the launch stream) */
+    int32_t bounces;      /* iterations executed */
+    int32_t launches;     /* kernel launches issued */
+} trc_trace_stats;
+
+const char *trc_last_error(void);
+int trc_abi_version(void);
+
+/* context: one per GPU ------------------------------------------------------ */
+int trc_ctx_create(int device_id, trc_ctx **out);
+int trc_ctx_destroy(trc_ctx *ctx);
+int trc_ctx_synchronize(trc_ctx *ctx);
+int trc_ctx_device_name(trc_ctx *ctx, char *buf, int buflen);
+
+/* scene = Assembly.get_surfaces() flattened (assembly.py:60-77) --------------- */
+int trc_scene_create(trc_ctx *ctx, int32_t n_surf, const trc_surface_desc *surfs,
+                     int32_t n_extra, const double *extra, trc_scene **out);
+int trc_scene_destroy(trc_scene *scene);
+/* re-aim: Assembly.transform_children() (assembly.py:135-146) */
+int trc_scene_update_frames(trc_scene *scene, int32_t n_surf, const double *frames12);
+/* KdTree(...) result (accel_tree.py:20-40) */
+int trc_scene_set_kdtree(trc_scene *scene, const trc_kdtree_desc *kd);
+/* energy-weighted 2-D histogram of absorbed energy in the local x,y of one surface: the caller-side
+   numpy.histogram2d of examples/Sandia_NSTTF_field example.py:175-227 and RectPlateGM.get_fluxmap
+   (flat_surface.py:237-251), accumulated on the device.  u_edges[nu+1], v_edges[nv+1] are the numpy
+   bin edges (last bin closed on the right); proj12 = rows 0..2 of the global->local matrix, i.e.
+   round(inv(frame), 9) as in Surface.global_to_local (surface.py:114-126).  Resets the tallies. */
+int trc_scene_set_fluxmap(trc_scene *scene, int32_t surf, int32_t nu, int32_t nv,
+                          const double *u_edges, const double *v_edges, const double *proj12);
+/* capacity (in hits) of the hit buffer that backs the Location/Direction/
+   Absorption accountants (optics_callables.py:1597-1771) in the fast engine */
+int trc_scene_set_hit_capacity(trc_scene *scene, int64_t capacity);
+/* Assembly.reset_all_optics() (assembly.py:148-151) */
+int trc_scene_reset_tallies(trc_scene *scene);
+/* per-surface totals: absorbed = sum(E_in - sum E_out) (AbsorptionAccountant :1638-1643),
+   received = sum E_in (ReceptionAccountant :1699-1701), hits = count. Any pointer may be NULL. */
+int trc_scene_get_tallies(trc_scene *scene, double *absorbed, double *received, int64_t *hits);
+int trc_scene_get_fluxmap(trc_scene *scene, int32_t surf, double *out /* nu*nv, row-major u */);
+/* captured hits, in device arrival order. Query n first with all arrays NULL. */
+int trc_scene_get_hits(trc_scene *scene, int64_t *n, int32_t *surf, double *e_abs, double *e_in,
+                       double *px, double *py, double *pz, double *dx, double *dy, double *dz);
+/* the packed float64 tally buffer [absorbed S | received S | hits S | segments,hits | flux maps]
+   for the single end-of-run reduce across GPUs (reference merge: tracer_engine_mp.py:44-119).
+   export/import copy to/from a caller buffer (host, or device when on_device != 0) so the
+   caller can run ncclAllReduce / torch.distributed.all_reduce on it. */
+int trc_scene_tally_size(trc_scene *scene, int64_t *n_doubles);
+int trc_scene_export_tallies(trc_scene *scene, double *dst, int32_t on_device);
+int trc_scene_import_tallies(trc_scene *scene, const double *src, int32_t on_device);
+
+/*
+ * TracerEngine.ray_tracer(bundle, reps, min_energy, tree=False, accel) (tracer_engine.py:124-295):
+ * the persistent-wavefront engine.  Exactly one of `in` / `src` is non-NULL: `in` traces a given
+ * bundle; `src` fuses source generation (sources.py) into the kernel, ray i of the call has
+ * stream id ray_offset+i.  Tallies/flux maps/hit buffer accumulate on the scene.
+ * If TRC_TRACE_KEEP_LAST, rays still alive after `reps` bounces are written to `last`
+ * (capacity last->n on entry, count on exit).
+ */
+int trc_trace_fast(trc_scene *scene, const trc_rays *in, const trc_source_desc *src, int64_t n,
+                   int32_t reps, double min_energy, uint64_t seed, uint64_t ray_offset,
+                   int32_t flags, trc_rays *last, trc_trace_stats *stats);
+
+/*
+ * TracerEngine.ray_tracer(..., tree=True): the ordered engine.  Reproduces the reference's
+ * bundle ordering (surface-major, culled rays after live ones: tracer_engine.py:218-274) and
+ * parent indices, one RayTree level (trace_tree.py:6-55) per bounce, kept on the device until
+ * fetched.  Level 0 is the source bundle.
+ */
+int trc_trace_ordered(trc_scene *scene, const trc_rays *in, const trc_source_desc *src, int64_t n,
+                      int32_t reps, double min_energy, uint64_t seed, uint64_t ray_offset,
+                      int32_t flags, trc_result **out, trc_trace_stats *stats);
+int trc_result_num_levels(trc_result *res, int32_t *n_levels);
+/* n_total rays recorded at this level, the first n_live of which continued to the next bounce */
+int trc_result_level_size(trc_result *res, int32_t level, int64_t *n_total, int64_t *n_live);
+/* copy a level to host arrays (capacity out->n >= n_total); surf[i] = surface that produced ray i (-1 at level 0) */
+int trc_result_level_get(trc_result *res, int32_t level, trc_rays *out, int32_t *surf);
+int trc_result_destroy(trc_result *res);
+
+/* sources.*_bundle(...) materialised as a bundle (sources.py:175-515) */
+int trc_source_generate(trc_ctx *ctx, const trc_source_desc *src, int64_t n, uint64_t seed,
+                        uint64_t ray_offset, trc_rays *out);
+
+/*
+ * Per-surface trace protocol (user-doc/trace_protocol.rst:1-24), for callers that drive
+ * surfaces one at a time like the reference engine does:
+ *   GeometryManager.find_intersections(frame, bundle) -> t (+inf = miss)   geometry_manager.py:8-26
+ *   GeometryManager.get_normals() / get_intersection_points_global()       quadric.py:159-172
+ *   optics(geometry, rays, selector)                                       surface.py:84-94
+ */
+int trc_gm_find_intersections(trc_ctx *ctx, const trc_surface_desc *surf, int32_t n_extra,
+                              const double *extra, const trc_rays *rays, double *t_out,
+                              double *hx, double *hy, double *hz);
+int trc_gm_get_normals(trc_ctx *ctx, const trc_surface_desc *surf, int64_t n,
+                       const double *hx, const double *hy, const double *hz,
+                       const double *dx, const double *dy, const double *dz,
+                       double *nx, double *ny, double *nz);
+/*
+ * optics callable on n selected hits. in: incident rays (direction, energy, ref_index,
+ * wavelength, rid) + hit points + oriented normals.  out: capacity 2n rays; out->n is set to the
+ * number produced; out->parent[k] indexes the n inputs; block order as the reference's
+ * (reflected block, then refracted block: optics_callables.py:1284-1294).
+ */
+int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int32_t n_extra, const double *extra,
+                     const trc_rays *in, const double *hx, const double *hy, const double *hz,
+                     const double *nx, const double *ny, const double *nz,
+                     uint64_t seed, int32_t bounce, trc_rays *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRACER_AMD_H */

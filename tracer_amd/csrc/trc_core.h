@@ -1,0 +1,883 @@
+// trc_core.h -- per-ray math of the tracing core (one lane = one ray).
+//
+// Everything here is a pure function of its arguments, marked TRC_HD so that the SAME source
+// is compiled by hipcc for gfx950 (the product, trc_kernels.hip) and by g++ for the host-side
+// debug harness under tests/hostcheck (never shipped, never loaded by the package).
+//
+// The formulation is per ray, not per surface as in the reference: a lane walks the candidate
+// surfaces with the ray in registers.  Each function cites the reference lines whose results it
+// must reproduce (paths relative to the reference tree).
+#ifndef TRC_CORE_H
+#define TRC_CORE_H
+
+#include <stdint.h>
+#include <math.h>
+#include "../../include/tracer_amd.h"
+
+#if defined(__HIPCC__)
+#define TRC_HD __host__ __device__ __forceinline__
+#define TRC_HD_NOINLINE __host__ __device__
+#else
+#define TRC_HD static inline
+#define TRC_HD_NOINLINE static
+#endif
+
+#define TRC_INF (__builtin_inf())
+#define TRC_NAN (__builtin_nan(""))
+#define TRC_TWO_PI 6.283185307179586476925286766559
+
+// ---------------------------------------------------------------------------------------------
+// Compact per-surface record used by the kernels (LDS-staged).  Layout in doubles:
+//   [0..8]  R row-major (local->global rotation)     [9..11] c (origin)
+//   [12]    int32 gm_kind | int32 optics_kind        [13]    int32 extra_off | int32 extra_len
+//   [14..]  geometry parameters (trc_surface_desc.gm)
+// The record stride is chosen per scene (14 + max params used, made odd to spread LDS banks).
+// ---------------------------------------------------------------------------------------------
+#define TRC_REC_HDR 14
+
+TRC_HD int trc_rec_gm_kind(const double *rec) { return ((const int32_t *)(rec + 12))[0]; }
+TRC_HD int trc_rec_opt_kind(const double *rec) { return ((const int32_t *)(rec + 12))[1]; }
+TRC_HD int trc_rec_extra_off(const double *rec) { return ((const int32_t *)(rec + 13))[0]; }
+TRC_HD int trc_rec_extra_len(const double *rec) { return ((const int32_t *)(rec + 13))[1]; }
+
+// number of geometry parameters each kind reads (host side uses it to size the record)
+TRC_HD int trc_gm_nparams(int kind) {
+    switch (kind) {
+    case TRC_GM_FLAT_INF: return 0;
+    case TRC_GM_RECT: return 2;
+    case TRC_GM_RECT_EXTRUDED: return 6;
+    case TRC_GM_RECT_PERFORATED: return 2;
+    case TRC_GM_ROUND: return 2;
+    case TRC_GM_ROUND_CUT: return 3;
+    case TRC_GM_TRIANGLE: return 6;
+    case TRC_GM_PARABOLOID: return 2;
+    case TRC_GM_PARAB_DISH: return 3;
+    case TRC_GM_PARAB_HEX: return 3;
+    case TRC_GM_PARAB_RECT: return 4;
+    case TRC_GM_PARAB_RECT_OFFAXIS: return 16;
+    case TRC_GM_PARAB_CYL: return 1;
+    case TRC_GM_PARAB_TROUGH: return 3;
+    case TRC_GM_SPHERE: return 1;
+    case TRC_GM_HEMISPHERE: return 1;
+    case TRC_GM_SPHERE_RECT: return 3;
+    case TRC_GM_CYL_INF: return 1;
+    case TRC_GM_CYL_FINITE: return 4;
+    case TRC_GM_CYL_RECTCUT: return 4;
+    case TRC_GM_CONE_INF: return 2;
+    case TRC_GM_CONE_FINITE: return 3;
+    case TRC_GM_FRUSTUM: return 4;
+    case TRC_GM_FRUSTUM_RECTCUT: return 6;
+    case TRC_GM_QUADRATIC: return 6;
+    case TRC_GM_QUADRATIC_RECT: return 8;
+    case TRC_GM_ELLIPSOID: return 3;
+    case TRC_GM_ELLIPSOID_CUT: return 9;
+    default: return -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Random numbers: Philox4x32-10 (Salmon et al., SC'11), counter-based so that every draw is a
+// pure function of (seed, ray stream id, event index, block) -- results do not depend on how
+// rays are scheduled on waves, on the engine used, or on the number of GPUs.
+//   counter = (rid_lo, rid_hi, event, block)   key = (seed_lo, seed_hi)
+//   event 0 = source generation; event k>=1 = the k-th surface interaction of the ray.
+// ---------------------------------------------------------------------------------------------
+TRC_HD void trc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                              uint32_t k1, uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c0;
+        uint64_t p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// two 32-bit words -> double in [0,1) with 53 random bits
+TRC_HD double trc_u01_from_bits(uint32_t a, uint32_t b) {
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// uniforms (2k, 2k+1) of the event's stream live in Philox block k
+TRC_HD void trc_uniform_pair(uint64_t seed, uint64_t rid, uint32_t event, uint32_t block, double *u0,
+                             double *u1) {
+    uint32_t o[4];
+    trc_philox4x32_10((uint32_t)rid, (uint32_t)(rid >> 32), event, block, (uint32_t)seed,
+                      (uint32_t)(seed >> 32), o);
+    *u0 = trc_u01_from_bits(o[0], o[1]);
+    *u1 = trc_u01_from_bits(o[2], o[3]);
+}
+
+// Box-Muller: two independent N(0,1) from two uniforms (1-u0 keeps the log argument in (0,1])
+TRC_HD void trc_normal_pair(double u0, double u1, double *g0, double *g1) {
+    double r = sqrt(-2.0 * log(1.0 - u0));
+    double a = TRC_TWO_PI * u1;
+    *g0 = r * cos(a);
+    *g1 = r * sin(a);
+}
+
+// stream id of the second ray created when an interaction splits a ray in two
+// (RefractiveHomogenous, single_ray=False: optics_callables.py:1284-1294)
+TRC_HD uint64_t trc_child_rid(uint64_t rid, uint32_t event) {
+    return rid * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull * (uint64_t)(event + 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// small vector helpers
+// ---------------------------------------------------------------------------------------------
+TRC_HD double trc_dot3(double ax, double ay, double az, double bx, double by, double bz) {
+    return ax * bx + ay * by + az * bz;
+}
+
+// global -> local: R^T (p - c)   (the reference multiplies by linalg.inv(frame); frames are rigid)
+TRC_HD void trc_to_local_point(const double *rec, double px, double py, double pz, double *lx,
+                               double *ly, double *lz) {
+    double qx = px - rec[9], qy = py - rec[10], qz = pz - rec[11];
+    *lx = rec[0] * qx + rec[3] * qy + rec[6] * qz;
+    *ly = rec[1] * qx + rec[4] * qy + rec[7] * qz;
+    *lz = rec[2] * qx + rec[5] * qy + rec[8] * qz;
+}
+TRC_HD void trc_to_local_dir(const double *rec, double dx, double dy, double dz, double *lx, double *ly,
+                             double *lz) {
+    *lx = rec[0] * dx + rec[3] * dy + rec[6] * dz;
+    *ly = rec[1] * dx + rec[4] * dy + rec[7] * dz;
+    *lz = rec[2] * dx + rec[5] * dy + rec[8] * dz;
+}
+TRC_HD void trc_to_global_dir(const double *rec, double lx, double ly, double lz, double *gx, double *gy,
+                              double *gz) {
+    *gx = rec[0] * lx + rec[1] * ly + rec[2] * lz;
+    *gy = rec[3] * lx + rec[4] * ly + rec[5] * lz;
+    *gz = rec[6] * lx + rec[7] * ly + rec[8] * lz;
+}
+
+// ---------------------------------------------------------------------------------------------
+// G1/G2/G3 -- flat family.  flat_surface.py:33-60 (plane), :160-164 (local coords),
+// :209 rect, :271-272 extruded, :373-375 perforated, :488-490 round, :558 cut,
+// triangular_face.py:59-72 triangle.
+// ---------------------------------------------------------------------------------------------
+TRC_HD double trc_intersect_flat(int kind, const double *rec, const double *extra, double vx, double vy,
+                                 double vz, double dx, double dy, double dz) {
+    const double nx = rec[2], ny = rec[5], nz = rec[8];
+    double dt = dx * nx + dy * ny + dz * nz;
+    if (!(fabs(dt) > 1e-7)) return TRC_INF;                    // flat_surface.py:39
+    double vt = nx * (vx - rec[9]) + ny * (vy - rec[10]) + nz * (vz - rec[11]);
+    double t = -vt / dt;                                       // :47
+    if (!(t >= 1e-7)) return TRC_INF;                          // :50-51 (params < 1e-7 -> inf)
+    if (kind == TRC_GM_FLAT_INF) return t;
+    double hx = vx + t * dx, hy = vy + t * dy, hz = vz + t * dz;   // :156
+    const double *g = rec + TRC_REC_HDR;
+    if (kind == TRC_GM_TRIANGLE) {
+        // barycentric coordinates from Gram terms, triangular_face.py:59-72
+        double e0x, e0y, e0z, e1x, e1y, e1z;
+        trc_to_global_dir(rec, g[0], g[1], g[2], &e0x, &e0y, &e0z);
+        trc_to_global_dir(rec, g[3], g[4], g[5], &e1x, &e1y, &e1z);
+        double wx = hx - rec[9], wy = hy - rec[10], wz = hz - rec[11];
+        double uv = g[0] * g[3] + g[1] * g[4] + g[2] * g[5];
+        double n0 = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+        double n1 = g[3] * g[3] + g[4] * g[4] + g[5] * g[5];
+        double r0 = wx * e0x + wy * e0y + wz * e0z;
+        double r1 = wx * e1x + wy * e1y + wz * e1z;
+        double den = uv * uv - n0 * n1;
+        double bc0 = (uv * r1 - n1 * r0) / den;
+        double bc1 = (uv * r0 - n0 * r1) / den;
+        if (bc0 < 0.0 || bc1 < 0.0 || (bc0 + bc1) > 1.0) return TRC_INF;
+        return t;
+    }
+    double lx, ly, lz;
+    trc_to_local_point(rec, hx, hy, hz, &lx, &ly, &lz);
+    (void)lz;
+    switch (kind) {
+    case TRC_GM_RECT:
+        if (fabs(lx) > g[0] || fabs(ly) > g[1]) return TRC_INF;
+        return t;
+    case TRC_GM_RECT_EXTRUDED:
+        if (fabs(lx) > g[0] || fabs(ly) > g[1]) return TRC_INF;
+        if (fabs(lx - g[2]) < g[4] && fabs(ly - g[3]) < g[5]) return TRC_INF;
+        return t;
+    case TRC_GM_RECT_PERFORATED: {
+        if (fabs(lx) > g[0] || fabs(ly) > g[1]) return TRC_INF;
+        int off = trc_rec_extra_off(rec), len = trc_rec_extra_len(rec);
+        for (int k = 0; k + 2 < len; k += 3) {
+            double ex = lx - extra[off + k], ey = ly - extra[off + k + 1];
+            if (sqrt(ex * ex + ey * ey) < extra[off + k + 2]) return TRC_INF;
+        }
+        return t;
+    }
+    case TRC_GM_ROUND:
+    case TRC_GM_ROUND_CUT: {
+        double r2 = lx * lx + ly * ly;
+        if (r2 > g[0] * g[0]) return TRC_INF;
+        if (g[1] >= 0.0 && r2 < g[1] * g[1]) return TRC_INF;
+        if (kind == TRC_GM_ROUND_CUT && lx > g[2]) return TRC_INF;
+        return t;
+    }
+    default:
+        return TRC_INF;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// G4..G9 -- quadric family.  quadric.py:54-101 (solver), :133-142 (default root choice) and each
+// subclass' get_ABC / _select_coords.
+// ---------------------------------------------------------------------------------------------
+TRC_HD bool trc_quadric_aperture(int kind, const double *rec, const double *g, double lx, double ly,
+                                 double lz) {
+    switch (kind) {
+    case TRC_GM_PARAB_DISH: return (lz <= g[2]) && (lz >= 0.0);                         // paraboloid.py:112
+    case TRC_GM_PARAB_HEX: {                                                            // :213-216
+        double ax = fabs(lx), ay = fabs(ly);
+        bool outside = ax > sqrt(3.0) * g[2] / 2.0;
+        outside = outside || (ay > g[2] - tan(3.14159265358979323846 / 6.0) * ax);
+        return !outside;
+    }
+    case TRC_GM_PARAB_RECT: return !(fabs(lx) > g[2] || fabs(ly) > g[3]);               // :283-288
+    case TRC_GM_PARAB_RECT_OFFAXIS: {                                                   // :279-281
+        double qx = lx + g[13], qy = ly + g[14], qz = lz + g[15];
+        double rx = g[4] * qx + g[5] * qy + g[6] * qz;
+        double ry = g[7] * qx + g[8] * qy + g[9] * qz;
+        return !(fabs(rx) > g[2] || fabs(ry) > g[3]);
+    }
+    case TRC_GM_PARAB_TROUGH: return (fabs(ly) <= g[1]) && (lz <= g[2]) && (lz >= 0.0); // :433-438
+    case TRC_GM_HEMISPHERE: return lz <= 0.0;                                            // sphere_surface.py:133
+    case TRC_GM_SPHERE_RECT: return (lz <= 0.0) && (fabs(lx) <= g[1]) && (fabs(ly) <= g[2]); // :222-223
+    case TRC_GM_CYL_FINITE: {                                                           // cylinder.py:97-103
+        double ang = atan2(ly, lx);
+        if (ang < 0.0) ang = TRC_TWO_PI + ang;
+        return (fabs(lz) <= g[1]) && (ang >= g[2]) && (ang <= g[3]);
+    }
+    case TRC_GM_CYL_RECTCUT:                                                            // :185-190
+        return (-g[1] <= lz) && (lz <= g[1]) && (fabs(lx) <= g[2]) && (fabs(ly) <= g[3]);
+    case TRC_GM_CONE_FINITE: return (lz >= 0.0) && (lz <= g[2]);                          // cone.py:111
+    case TRC_GM_FRUSTUM: return (g[2] <= lz) && (lz <= g[3]);                            // :311
+    case TRC_GM_FRUSTUM_RECTCUT:                                                        // :381-386
+        return (g[2] <= lz) && (lz <= g[3]) && (fabs(lx) <= g[4]) && (fabs(ly) <= g[5]);
+    case TRC_GM_QUADRATIC_RECT: return !(fabs(lx) > g[6] || fabs(ly) > g[7]);            // quadratic_surface.py:95-98
+    case TRC_GM_ELLIPSOID_CUT:                                                          // ellipsoid.py:102-110
+        return (lx >= g[3]) && (lx <= g[4]) && (ly >= g[5]) && (ly <= g[6]) && (lz >= g[7]) && (lz <= g[8]);
+    default: return true;
+    }
+    (void)rec;
+}
+
+// how a kind picks between the two roots
+//   0: base class rule only (valid_k = t_k >= 1e-6)                      quadric.py:133-142
+//   1: own rule: valid_k = aperture_k && t_k > eps                       e.g. paraboloid.py:104-117
+//   2: base rule first, then restricted by inside_k = aperture_k && t_k > eps (xor -> that one,
+//      neither -> miss, both -> keep the base choice)                    e.g. sphere_surface.py:128-137
+TRC_HD int trc_quadric_select_mode(int kind, double *eps) {
+    switch (kind) {
+    case TRC_GM_PARAB_DISH: case TRC_GM_PARAB_TROUGH: case TRC_GM_CYL_FINITE: case TRC_GM_CYL_RECTCUT:
+    case TRC_GM_FRUSTUM: case TRC_GM_FRUSTUM_RECTCUT:
+        *eps = 1e-6; return 1;
+    case TRC_GM_CONE_FINITE: *eps = 1e-9; return 1;            // cone.py:112
+    case TRC_GM_ELLIPSOID_CUT: *eps = 1e-7; return 1;          // ellipsoid.py:96
+    case TRC_GM_PARAB_HEX: *eps = 0.0; return 2;               // paraboloid.py:217
+    case TRC_GM_PARAB_RECT: case TRC_GM_PARAB_RECT_OFFAXIS: case TRC_GM_HEMISPHERE: case TRC_GM_SPHERE_RECT:
+    case TRC_GM_QUADRATIC_RECT:
+        *eps = 1e-6; return 2;
+    default: *eps = 1e-6; return 0;
+    }
+}
+
+TRC_HD double trc_intersect_quadric(int kind, const double *rec, double vx, double vy, double vz, double dx,
+                                    double dy, double dz) {
+    const double *g = rec + TRC_REC_HDR;
+    double A, B, C;
+    if (kind == TRC_GM_SPHERE || kind == TRC_GM_HEMISPHERE || kind == TRC_GM_SPHERE_RECT) {
+        // global frame, sphere_surface.py:58-66
+        double qx = vx - rec[9], qy = vy - rec[10], qz = vz - rec[11];
+        A = dx * dx + dy * dy + dz * dz;
+        B = 2.0 * (dx * qx + dy * qy + dz * qz);
+        C = (qx * qx + qy * qy + qz * qz) - g[0] * g[0];
+    } else {
+        double lx, ly, lz, ex, ey, ez;
+        trc_to_local_point(rec, vx, vy, vz, &lx, &ly, &lz);
+        trc_to_local_dir(rec, dx, dy, dz, &ex, &ey, &ez);
+        switch (kind) {
+        case TRC_GM_PARABOLOID: case TRC_GM_PARAB_DISH: case TRC_GM_PARAB_HEX: case TRC_GM_PARAB_RECT:
+        case TRC_GM_PARAB_RECT_OFFAXIS:                           // paraboloid.py:39-41
+            A = g[0] * ex * ex + g[1] * ey * ey;
+            B = 2.0 * g[0] * ex * lx + 2.0 * g[1] * ey * ly - ez;
+            C = g[0] * lx * lx + g[1] * ly * ly - lz;
+            break;
+        case TRC_GM_PARAB_CYL: case TRC_GM_PARAB_TROUGH:           // paraboloid.py:354-356
+            A = g[0] * ex * ex;
+            B = 2.0 * g[0] * ex * lx - ez;
+            C = g[0] * lx * lx - lz;
+            break;
+        case TRC_GM_CYL_INF: case TRC_GM_CYL_FINITE: case TRC_GM_CYL_RECTCUT:   // cylinder.py:53-55
+            A = ex * ex + ey * ey;
+            B = 2.0 * (ex * lx + ey * ly);
+            C = (lx * lx + ly * ly) - g[0] * g[0];
+            break;
+        case TRC_GM_CONE_INF: case TRC_GM_CONE_FINITE: case TRC_GM_FRUSTUM: case TRC_GM_FRUSTUM_RECTCUT: {
+            double c = g[0], a = g[1];                            // cone.py:68-70
+            A = ex * ex + ey * ey - (c * ez) * (c * ez);
+            B = 2.0 * (lx * ex + ly * ey - c * c * (lz - a) * ez);
+            C = lx * lx + ly * ly - (c * (lz - a)) * (c * (lz - a));
+            break;
+        }
+        case TRC_GM_QUADRATIC: case TRC_GM_QUADRATIC_RECT:        // quadratic_surface.py:57-59
+            A = g[0] * ex * ex + g[1] * ey * ey + g[2] * ex * ey;
+            B = 2.0 * g[0] * ex * lx + 2.0 * g[1] * ey * ly + g[2] * (lx * ey + ly * ex) + g[3] * ex +
+                g[4] * ey - ez;
+            C = g[0] * lx * lx + g[1] * ly * ly + g[2] * lx * ly + g[3] * lx + g[4] * ly + g[5] - lz;
+            break;
+        case TRC_GM_ELLIPSOID: case TRC_GM_ELLIPSOID_CUT:         // ellipsoid.py:31-33
+            A = g[0] * ex * ex + g[1] * ey * ey + g[2] * ez * ez;
+            B = 2.0 * g[0] * ex * lx + 2.0 * g[1] * ey * ly + 2.0 * g[2] * ez * lz;
+            C = g[0] * lx * lx + g[1] * ly * ly + g[2] * lz * lz - 1.0;
+            break;
+        default:
+            return TRC_INF;
+        }
+    }
+    double delta = B * B - 4.0 * A * C;
+    if (!(delta >= 1e-6)) return TRC_INF;                         // quadric.py:57-58
+    double t0, t1;
+    if (A == 0.0) {                                               // :77-82
+        if (B == 0.0) return TRC_INF;
+        t0 = t1 = -C / B;
+    } else if (B == 0.0) {                                        // :84-85
+        t1 = sqrt(-C / A);
+        t0 = -t1;
+    } else {                                                      // :87-89
+        double q = -0.5 * (B + (B > 0.0 ? 1.0 : -1.0) * sqrt(delta));
+        t0 = q / A;
+        t1 = C / q;
+    }
+    double eps;
+    int mode = trc_quadric_select_mode(kind, &eps);
+    bool b0 = t0 >= 1e-6, b1 = t1 >= 1e-6;                         // base rule
+    int base_sel = (b0 && b1) ? 1 : (b0 ? 0 : (b1 ? 1 : -1));
+    int sel;
+    if (mode == 0) {
+        sel = base_sel;
+    } else {
+        bool in0 = t0 > eps, in1 = t1 > eps;
+        if (in0) {
+            double lx, ly, lz;
+            trc_to_local_point(rec, vx + dx * t0, vy + dy * t0, vz + dz * t0, &lx, &ly, &lz);
+            in0 = trc_quadric_aperture(kind, rec, g, lx, ly, lz);
+        }
+        if (in1) {
+            double lx, ly, lz;
+            trc_to_local_point(rec, vx + dx * t1, vy + dy * t1, vz + dz * t1, &lx, &ly, &lz);
+            in1 = trc_quadric_aperture(kind, rec, g, lx, ly, lz);
+        }
+        if (mode == 1) {
+            sel = (in0 && in1) ? 1 : (in0 ? 0 : (in1 ? 1 : -1));
+        } else {
+            if (!(in0 || in1)) sel = -1;
+            else if (in0 != in1) sel = in0 ? 0 : 1;
+            else sel = base_sel;
+        }
+    }
+    if (sel < 0) return TRC_INF;
+    return sel ? t1 : t0;
+}
+
+TRC_HD bool trc_gm_is_flat(int kind) { return kind <= TRC_GM_TRIANGLE; }
+
+// GeometryManager.find_intersections for one ray: parametric distance, +inf = miss
+TRC_HD double trc_intersect(const double *rec, const double *extra, double vx, double vy, double vz,
+                            double dx, double dy, double dz) {
+    int kind = trc_rec_gm_kind(rec);
+    if (trc_gm_is_flat(kind)) return trc_intersect_flat(kind, rec, extra, vx, vy, vz, dx, dy, dz);
+    return trc_intersect_quadric(kind, rec, vx, vy, vz, dx, dy, dz);
+}
+
+// GeometryManager.get_normals for one hit: unit normal opposing the incident direction.
+// flat_surface.py:84-91; paraboloid.py:57-67; sphere_surface.py:44-49; cylinder.py:26-30;
+// cone.py:42-54; quadratic_surface.py:32-40; ellipsoid.py:49-57.
+TRC_HD void trc_normal(const double *rec, double hx, double hy, double hz, double dx, double dy, double dz,
+                       double *nx, double *ny, double *nz) {
+    int kind = trc_rec_gm_kind(rec);
+    const double *g = rec + TRC_REC_HDR;
+    if (trc_gm_is_flat(kind)) {
+        double ux = rec[2], uy = rec[5], uz = rec[8];
+        double dt = dx * ux + dy * uy + dz * uz;
+        if (dt > 0.0) { ux = -ux; uy = -uy; uz = -uz; }          // backside, flat_surface.py:57-60
+        *nx = ux; *ny = uy; *nz = uz;
+        return;
+    }
+    if (kind == TRC_GM_SPHERE || kind == TRC_GM_HEMISPHERE || kind == TRC_GM_SPHERE_RECT) {
+        double ux = hx - rec[9], uy = hy - rec[10], uz = hz - rec[11];
+        double sides = (-ux) * dx + (-uy) * dy + (-uz) * dz;
+        if (sides < 0.0) { ux = -ux; uy = -uy; uz = -uz; }
+        double inv = 1.0 / sqrt(ux * ux + uy * uy + uz * uz);
+        *nx = ux * inv; *ny = uy * inv; *nz = uz * inv;
+        return;
+    }
+    double lx, ly, lz, ex, ey, ez;
+    trc_to_local_point(rec, hx, hy, hz, &lx, &ly, &lz);
+    trc_to_local_dir(rec, dx, dy, dz, &ex, &ey, &ez);
+    double ux, uy, uz;
+    bool flip;
+    switch (kind) {
+    case TRC_GM_CYL_INF: case TRC_GM_CYL_FINITE: case TRC_GM_CYL_RECTCUT:
+        ux = lx / g[0]; uy = ly / g[0]; uz = 0.0;
+        flip = (ux * ex + uy * ey) > 0.0;
+        break;
+    case TRC_GM_CONE_INF: case TRC_GM_CONE_FINITE: case TRC_GM_FRUSTUM: case TRC_GM_FRUSTUM_RECTCUT: {
+        ux = 2.0 * lx; uy = 2.0 * ly; uz = -2.0 * (lz - g[1]) * (g[0] * g[0]);
+        double inv = 1.0 / sqrt(ux * ux + uy * uy + uz * uz);
+        ux *= inv; uy *= inv; uz *= inv;
+        flip = (ex * ux + ey * uy + ez * uz) > 1e-9;
+        if (flip) { ux = -ux; uy = -uy; uz = -uz; }
+        if (lz == g[1]) { ux = 0.0; uy = 0.0; uz = -1.0; }       // apex, cone.py:52-54
+        trc_to_global_dir(rec, ux, uy, uz, nx, ny, nz);
+        return;
+    }
+    default: {
+        switch (kind) {
+        case TRC_GM_PARAB_CYL: case TRC_GM_PARAB_TROUGH:
+            ux = 2.0 * lx * g[0]; uy = 0.0; uz = -1.0; break;
+        case TRC_GM_QUADRATIC: case TRC_GM_QUADRATIC_RECT:
+            ux = 2.0 * lx * g[0] + g[2] * ly + g[3]; uy = 2.0 * ly * g[1] + g[2] * lx + g[4]; uz = -1.0; break;
+        case TRC_GM_ELLIPSOID: case TRC_GM_ELLIPSOID_CUT:
+            ux = 2.0 * lx * g[0]; uy = 2.0 * ly * g[1]; uz = 2.0 * lz * g[2]; break;
+        default:  // paraboloid family
+            ux = 2.0 * lx * g[0]; uy = 2.0 * ly * g[1]; uz = -1.0; break;
+        }
+        double inv = 1.0 / sqrt(ux * ux + uy * uy + uz * uz);
+        ux *= inv; uy *= inv; uz *= inv;
+        flip = (ex * ux + ey * uy + ez * uz) > 0.0;
+        break;
+    }
+    }
+    if (flip) { ux = -ux; uy = -uy; uz = -uz; }
+    trc_to_global_dir(rec, ux, uy, uz, nx, ny, nz);
+}
+
+// ---------------------------------------------------------------------------------------------
+// E2 -- nearest hit over all surfaces, brute force.  tracer_engine.py:45-63: surfaces in index
+// order, t == 0 is not a hit, a later surface replaces only on strictly smaller t.
+// ---------------------------------------------------------------------------------------------
+TRC_HD void trc_nearest_brute(const double *recs, int stride, int n_surf, const double *extra, double vx,
+                              double vy, double vz, double dx, double dy, double dz, double *t_best,
+                              int *s_best) {
+    double tb = TRC_INF;
+    int sb = -1;
+    for (int s = 0; s < n_surf; ++s) {
+        double t = trc_intersect(recs + (size_t)s * stride, extra, vx, vy, vz, dx, dy, dz);
+        if (t != 0.0 && t < tb) { tb = t; sb = s; }
+    }
+    *t_best = tb;
+    *s_best = sb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 -- Kd-tree traversal.  accel_tree.py:213-330.  The reference marks every leaf a ray crosses
+// and lets intersect_ray pick the nearest hit among the marked surfaces; here the candidates of a
+// leaf are tested as soon as the leaf is reached and the walk stops once the best hit is in front
+// of everything still on the stack.  The surviving (t, surface) pair is the same: lowest surface
+// index among the minimal t.
+// ---------------------------------------------------------------------------------------------
+struct trc_kd_view {
+    const int32_t *node_a;   // per node: flag (2 low bits) | child or leaf_off << 2
+    const int32_t *node_b;   // per node: leaf_cnt (leaf)
+    const double *split;     // per node
+    const int32_t *leaf_surfs;
+    const int32_t *always;
+    int32_t n_always;
+    double bmin[3], bmax[3];
+};
+
+#ifndef TRC_KD_STACK
+#define TRC_KD_STACK 32
+#endif
+
+template <class Stack>
+TRC_HD void trc_nearest_kd(const trc_kd_view &kd, Stack &stk, const double *recs, int stride,
+                           const double *extra, double vx, double vy, double vz, double dx, double dy,
+                           double dz, double *t_best, int *s_best) {
+    double tb = TRC_INF;
+    int sb = -1;
+    // surfaces of objects without boundaries are always candidates (accel_tree.py:59-73, :235)
+    for (int k = 0; k < kd.n_always; ++k) {
+        int s = kd.always[k];
+        double t = trc_intersect(recs + (size_t)s * stride, extra, vx, vy, vz, dx, dy, dz);
+        if (t != 0.0 && (t < tb || (t == tb && s < sb))) { tb = t; sb = s; }
+    }
+    // root slab test, accel_tree.py:314-330
+    const double v[3] = {vx, vy, vz}, d[3] = {dx, dy, dz};
+    double inv[3];
+    double tmin = 0.0, tmax = TRC_INF;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        inv[i] = 1.0 / d[i];
+        double lo = ((d[i] < 0.0 ? kd.bmax[i] : kd.bmin[i]) - v[i]) * inv[i];
+        double hi = ((d[i] < 0.0 ? kd.bmin[i] : kd.bmax[i]) - v[i]) * inv[i];
+        if (lo > hi) { double tmp = lo; lo = hi; hi = tmp; }
+        tmin = fmax(tmin, lo);   // NaN (0*inf) is ignored: conservative
+        tmax = fmin(tmax, hi);
+    }
+    if (tmax > 0.0 && !(tmin > tmax)) {
+        int node = 0;
+        int sp = 0;
+        for (;;) {
+            int a = kd.node_a[node];
+            int flag = a & 3;
+            if (flag != 3) {
+                double split = kd.split[node];
+                double pv = (flag == 0) ? v[0] : (flag == 1 ? v[1] : v[2]);
+                double dv = (flag == 0) ? d[0] : (flag == 1 ? d[1] : d[2]);
+                double iv = (flag == 0) ? inv[0] : (flag == 1 ? inv[1] : inv[2]);
+                double tp = (split - pv) * iv;                      // accel_tree.py:255
+                int c1 = a >> 2, c2 = c1 + 1;
+                bool below = (pv < split) || (pv == split && dv <= 0.0);   // :259
+                if (!below) { int tmp = c1; c1 = c2; c2 = tmp; }
+                if (tp > tmax || tp <= 0.0) node = c1;              // :264
+                else if (tp < tmin) node = c2;                      // :266
+                else {                                               // :268-274
+                    if (sp < TRC_KD_STACK) { stk.push(sp, c2, tmax); ++sp; }
+                    node = c1;
+                    tmax = tp;
+                }
+            } else {
+                int off = a >> 2, cnt = kd.node_b[node];
+                for (int k = 0; k < cnt; ++k) {
+                    int s = kd.leaf_surfs[off + k];
+                    double t = trc_intersect(recs + (size_t)s * stride, extra, vx, vy, vz, dx, dy, dz);
+                    if (t != 0.0 && (t < tb || (t == tb && s < sb))) { tb = t; sb = s; }
+                }
+                if (sp == 0) break;
+                --sp;
+                // the far child was pushed with t_min = t_plane, which is exactly where the near
+                // subtree just ended (the last leaf of a subtree inherits its interval's end)
+                tmin = tmax;
+                stk.pop(sp, &node, &tmax);
+                if (tb < tmin) break;   // everything left starts behind the best hit
+            }
+        }
+    }
+    *t_best = tb;
+    *s_best = sb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// O1..O6 -- optics.  One interaction of one ray; at most two outgoing rays.
+// ---------------------------------------------------------------------------------------------
+struct trc_ray_out {
+    double dx, dy, dz;
+    double e;
+    double ref;
+    int blk;   // 0: reflected block, 1: refracted block (ordering inside a surface's output bundle)
+};
+
+TRC_HD void trc_reflect(double dx, double dy, double dz, double nx, double ny, double nz, double *ox,
+                        double *oy, double *oz) {
+    double dn = dx * nx + dy * ny + dz * nz;                        // optics.py:156-157
+    *ox = dx - 2.0 * (dn * nx);
+    *oy = dy - 2.0 * (dn * ny);
+    *oz = dz - 2.0 * (dn * nz);
+}
+
+TRC_HD double trc_round14(double x) { return rint(x * 1e14) / 1e14; }  // N.round(x, 14), spatial_geometry.py:18
+
+// minimal rotation taking z to n, applied to e (ray_trace_utils/vector_manipulations.py:56-90,
+// spatial_geometry.py:8-22).  Used for the mirror slope error.
+TRC_HD void trc_rotate_z_to_normal(double ex, double ey, double ez, double nx, double ny, double nz,
+                                   double *ox, double *oy, double *oz) {
+    double ang = acos(nz);
+    if (ang == 0.0) { *ox = ex; *oy = ey; *oz = ez; return; }
+    // axis = unit(z x n); undefined -> x axis
+    double kx = -ny, ky = nx, kz = 0.0;
+    double kn = sqrt(kx * kx + ky * ky);
+    kx /= kn; ky /= kn;
+    if (kx != kx) { kx = 1.0; ky = 0.0; kz = 0.0; }
+    double s = trc_round14(sin(ang)), c = trc_round14(cos(ang)), vv = 1.0 - c;
+    // M = outer(k,k)*v + I*c + [k]x*s
+    double m00 = kx * kx * vv + c, m01 = kx * ky * vv - kz * s, m02 = kx * kz * vv + ky * s;
+    double m10 = ky * kx * vv + kz * s, m11 = ky * ky * vv + c, m12 = ky * kz * vv - kx * s;
+    double m20 = kz * kx * vv - ky * s, m21 = kz * ky * vv + kx * s, m22 = kz * kz * vv + c;
+    *ox = m00 * ex + m01 * ey + m02 * ez;
+    *oy = m10 * ex + m11 * ey + m12 * ez;
+    *oz = m20 * ex + m21 * ey + m22 * ez;
+}
+
+// frame whose columns are (perp, n x perp, n), applied to a (spatial_geometry.py:41-48)
+TRC_HD void trc_rotation_to_z_apply(double nx, double ny, double nz, double ax, double ay, double az,
+                                    double *ox, double *oy, double *oz) {
+    double px = ny, py = -nx, pz = 0.0;
+    if (px == 0.0 && py == 0.0) { px = 1.0; py = 0.0; }
+    double pn = sqrt(px * px + py * py + pz * pz);
+    px /= pn; py /= pn;
+    double cx = ny * pz - nz * py, cy = nz * px - nx * pz, cz = nx * py - ny * px;
+    *ox = px * ax + cx * ay + nx * az;
+    *oy = py * ax + cy * ay + ny * az;
+    *oz = pz * ax + cz * ay + nz * az;
+}
+
+// cone-limited cosine-weighted direction about +z (sources.py:91-98)
+TRC_HD void trc_pillbox_dir(double xi1, double xi2, double ang_range, double *ax, double *ay, double *az) {
+    if (ang_range == 0.0) { *ax = 0.0; *ay = 0.0; *az = 1.0; return; }
+    double s = sin(ang_range) * sqrt(xi2);
+    *ax = cos(xi1) * s;
+    *ay = sin(xi1) * s;
+    *az = sqrt(1.0 - s * s);
+}
+
+// slope-error normal in the frame of the ideal normal (optics_callables.py:234-251)
+TRC_HD void trc_slope_error_local(double sigma, bool bi_var, double g0, double g1, double u2, double *ex,
+                                  double *ey, double *ez) {
+    if (bi_var) {
+        double tx = tan(sigma * g0), ty = tan(sigma * g1);
+        double z = sqrt(1.0 / (1.0 + tx * tx + ty * ty));
+        *ex = tx * z; *ey = ty * z; *ez = z;
+    } else {
+        double th = sigma * g0, phi = TRC_TWO_PI * u2;
+        *ez = cos(th);
+        *ex = sin(th) * cos(phi);
+        *ey = sin(th) * sin(phi);
+    }
+}
+
+// unpolarised Fresnel reflectance, optics.py:28-38 (formula kept as written, through arccos/sin)
+TRC_HD double trc_fresnel(double cos_abs, double n1, double n2) {
+    double th = acos(cos_abs);
+    double foo = cos(th);
+    double sn = n1 / n2 * sin(th);
+    double bar = sqrt(1.0 - sn * sn);
+    double rs = (n1 * foo - n2 * bar) / (n1 * foo + n2 * bar);
+    double rp = (n1 * bar - n2 * foo) / (n1 * bar + n2 * foo);
+    return (rs * rs + rp * rp) / 2.0;
+}
+
+// N.interp: piecewise linear with clamped ends; table = n x then n y
+TRC_HD double trc_interp(const double *tab, int n, double x) {
+    const double *xs = tab, *ys = tab + n;
+    if (!(x > xs[0])) return ys[0];
+    if (x >= xs[n - 1]) return ys[n - 1];
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (xs[mid] <= x) lo = mid; else hi = mid;
+    }
+    double slope = (ys[lo + 1] - ys[lo]) / (xs[lo + 1] - xs[lo]);
+    return slope * (x - xs[lo]) + ys[lo];
+}
+
+// optics(geometry, rays, selector) for one hit.
+//   opt_kind / opt[8]: trc_surface_desc;  (ux,uy,uz): GeometryManager.up() = frame z axis;
+//   (dx..), e, ref, wl: incident ray;  (nx..): oriented normal from trc_normal.
+// Returns the number of outgoing rays (1 or 2) in out[].
+TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int extra_off, int extra_len,
+                     double ux, double uy, double uz, double dx, double dy, double dz, double e, double ref,
+                     double wl, double nx, double ny, double nz, uint64_t seed, uint64_t rid,
+                     uint32_t event, trc_ray_out out[2]) {
+    out[0].ref = ref;
+    out[0].blk = 0;
+    out[1].blk = 1;
+    switch (opt_kind) {
+    case TRC_OPT_TRANSPARENT:                                       // :106-113
+        out[0].dx = dx; out[0].dy = dy; out[0].dz = dz; out[0].e = e;
+        return 1;
+    case TRC_OPT_REFLECTIVE:
+    case TRC_OPT_ONE_SIDED_REFLECTIVE: {                            // :130-140, :201-212
+        trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);
+        double eo = e * (1.0 - opt[0]);
+        if (opt_kind == TRC_OPT_ONE_SIDED_REFLECTIVE && (dx * ux + dy * uy + dz * uz) > 0.0) eo = 0.0;
+        out[0].e = eo;
+        return 1;
+    }
+    case TRC_OPT_REFLECTIVE_SPECTRAL: {                             // :183-193
+        trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);
+        int n = extra_len / 2;
+        out[0].e = e * (1.0 - trc_interp(extra + extra_off, n, wl));
+        return 1;
+    }
+    case TRC_OPT_REAL_REFLECTIVE:
+    case TRC_OPT_ONE_SIDED_REAL_REFLECTIVE: {                       // :231-269, :498-504
+        double sigma = opt[1];
+        double rx = nx, ry = ny, rz = nz;
+        if (sigma > 0.0) {
+            double u0, u1, u2 = 0.0, u3, g0, g1;
+            trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
+            trc_normal_pair(u0, u1, &g0, &g1);
+            bool bi = opt[2] != 0.0;
+            if (!bi) trc_uniform_pair(seed, rid, event, 1, &u2, &u3);
+            double ex, ey, ez;
+            trc_slope_error_local(sigma, bi, g0, g1, u2, &ex, &ey, &ez);
+            trc_rotate_z_to_normal(ex, ey, ez, nx, ny, nz, &rx, &ry, &rz);
+            double inv = 1.0 / sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= inv; ry *= inv; rz *= inv;
+        }
+        trc_reflect(dx, dy, dz, rx, ry, rz, &out[0].dx, &out[0].dy, &out[0].dz);
+        double eo = e * (1.0 - opt[0]);
+        if (opt_kind == TRC_OPT_ONE_SIDED_REAL_REFLECTIVE && (dx * ux + dy * uy + dz * uz) > 0.0) eo = 0.0;
+        out[0].e = eo;
+        return 1;
+    }
+    case TRC_OPT_LAMBERTIAN: {                                      // :154-176
+        double u0, u1, ax, ay, az;
+        trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
+        trc_pillbox_dir(TRC_TWO_PI * u0, u1, opt[1], &ax, &ay, &az);
+        trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
+        out[0].e = e * (1.0 - opt[0]);
+        return 1;
+    }
+    case TRC_OPT_LAMBERTIAN_SPECULAR: {                             // :561-585
+        double u0, u1, u2, u3;
+        trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
+        if (u0 < opt[1]) {
+            trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);
+        } else {
+            double ax, ay, az;
+            trc_uniform_pair(seed, rid, event, 1, &u2, &u3);
+            trc_pillbox_dir(TRC_TWO_PI * u1, u2, 1.57079632679489661923, &ax, &ay, &az);
+            trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
+        }
+        out[0].e = e * (1.0 - opt[0]);
+        return 1;
+    }
+    case TRC_OPT_REFRACTIVE_HOMOGENOUS: {                           // :1226-1296 on :836-858
+        double na = opt[0], nb = opt[1];
+        bool single = opt[2] != 0.0;
+        double sigma = opt[3];
+        double u0, u1, u2, u3;
+        trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
+        trc_uniform_pair(seed, rid, event, 1, &u2, &u3);
+        if (sigma >= 0.0) {                                         // normal perturbation :1227-1239
+            double g0, g1;
+            trc_normal_pair(u0, u1, &g0, &g1);
+            double th = sigma * g0, phi = TRC_TWO_PI * u2;
+            double ex = sin(th) * cos(phi), ey = sin(th) * sin(phi), ez = cos(th);
+            double rx, ry, rz;
+            trc_rotation_to_z_apply(nx, ny, nz, ex, ey, ez, &rx, &ry, &rz);
+            nx = rx; ny = ry; nz = rz;
+        }
+        double n1 = ref;
+        double n2 = (n1 == na) ? nb : na;                           // :1217-1218
+        double eta = n2 / n1;
+        double cos1 = nx * dx + ny * dy + nz * dz;
+        bool refracted = (cos1 * cos1) >= (1.0 - eta * eta);        // optics.py:180
+        double R = 1.0;
+        double tx = 0.0, ty = 0.0, tz = 0.0;
+        if (refracted) {
+            tx = (dx - cos1 * nx) / eta; ty = (dy - cos1 * ny) / eta; tz = (dz - cos1 * nz) / eta;   // :188
+            double cos2 = sqrt(1.0 - 1.0 / (eta * eta) * (1.0 - cos1 * cos1));                        // :189
+            double sg = (cos1 < 0.0) ? -1.0 : 1.0;
+            tx += nx * cos2 * sg; ty += ny * cos2 * sg; tz += nz * cos2 * sg;                         // :190
+            R = trc_fresnel(fabs(cos1), n1, n2);
+        }
+        if (single) {                                               // :1254-1280
+            if (u3 <= R) {
+                trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);
+                out[0].e = e; out[0].ref = ref;
+            } else {
+                out[0].dx = tx; out[0].dy = ty; out[0].dz = tz;
+                out[0].e = e; out[0].ref = n2; out[0].blk = 1;
+            }
+            return 1;
+        }
+        trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);     // :1284-1294
+        out[0].e = e * R; out[0].ref = ref;
+        if (!refracted) return 1;
+        out[1].dx = tx; out[1].dy = ty; out[1].dz = tz;
+        out[1].e = e * (1.0 - R); out[1].ref = n2;
+        return 2;
+    }
+    default:
+        out[0].dx = dx; out[0].dy = dy; out[0].dz = dz; out[0].e = 0.0;
+        return 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S1..S3 -- sources.  One ray from its four uniforms.
+// ---------------------------------------------------------------------------------------------
+// Buie sunshape polar angle from its uniform (sources.py:364-377).  tab: trc_source_desc.buie
+TRC_HD double trc_buie_theta(const double *tab, double Rv) {
+    const int NE = TRC_BUIE_NELEM;
+    const double *theta = tab, *g = tab + (NE + 1), *cdf = tab + 2 * (NE + 1);
+    const double *sc = tab + 3 * (NE + 1);
+    double I_dni = sc[0], gamma = sc[1], kappa = sc[2], theta_dni = sc[3], theta_tot = sc[4];
+    bool csr_pos = sc[5] != 0.0;
+    if (Rv < cdf[NE]) {
+        int lo = 0, hi = NE;                       // largest i with cdf[i] <= R
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= Rv) lo = mid; else hi = mid;
+        }
+        int i = lo;
+        double A = g[i], B = g[i + 1];
+        double Cq = 2.0 * I_dni * (Rv - cdf[i]) * (theta[i + 1] - theta[i]);                   // :370
+        double w = (theta[i] - theta[i + 1]) * A;
+        return -(-A * theta[i + 1] + B * theta[i] + sqrt(w * w + Cq * (B - A))) / (A - B);     // :371
+    }
+    if (!csr_pos) return 0.0;                      // thetas stay 0 (sources.py:364, :376)
+    double gp2 = gamma + 2.0;                      // aureole, :377
+    double base = (Rv - 1.0) * (gp2 / (pow(10.0, 3.0 * gamma) * exp(kappa)) * I_dni - pow(theta_dni, gp2)) +
+                  Rv * pow(theta_tot, gp2);
+    return pow(base, 1.0 / gp2);
+}
+
+TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint64_t seed, uint64_t rid,
+                           double *px, double *py, double *pz, double *dx, double *dy, double *dz) {
+    double u0, u1, u2, u3;
+    trc_uniform_pair(seed, rid, 0, 0, &u0, &u1);
+    trc_uniform_pair(seed, rid, 0, 1, &u2, &u3);
+    double lx, ly, ax, ay, az;
+    const double *p = src->p;
+    switch (src->kind) {
+    case TRC_SRC_PILLBOX_DISK: {        // draws: dir phi, dir R, pos xi, pos theta (sources.py:200-213)
+        trc_pillbox_dir(TRC_TWO_PI * u0, u1, p[4], &ax, &ay, &az);
+        double r = sqrt(p[1] * p[1] + u2 * (p[0] * p[0] - p[1] * p[1]));
+        double th = p[2] + (p[3] - p[2]) * u3;
+        lx = r * cos(th); ly = r * sin(th);
+        break;
+    }
+    case TRC_SRC_PILLBOX_RECT: {        // draws: dir phi, dir R, xs, ys (sources.py:243-256)
+        trc_pillbox_dir(TRC_TWO_PI * u0, u1, p[2], &ax, &ay, &az);
+        double xs = -p[0] / 2.0 + p[0] * u2, ys = -p[1] / 2.0 + p[1] * u3;
+        if (p[3] != 0.0) { double tmp = xs; xs = ys; ys = tmp; }
+        lx = ys; ly = xs;               // vertices_local = (ys, xs, 0)
+        break;
+    }
+    case TRC_SRC_BUIE_DISK: {           // draws: xv1, phiv, R_theta, xi (sources.py:431-434, :365, :380)
+        double r = p[0] * sqrt(u0), ph = TRC_TWO_PI * u1;
+        lx = r * cos(ph); ly = r * sin(ph);
+        double th = trc_buie_theta(buie, u2), xi = TRC_TWO_PI * u3;
+        double st = sin(th);
+        ax = cos(xi) * st; ay = sin(xi) * st; az = cos(th);
+        break;
+    }
+    default: {                          // TRC_SRC_BUIE_RECT (sources.py:485-486)
+        lx = p[0] * (u0 - 0.5); ly = p[1] * (u1 - 0.5);
+        double th = trc_buie_theta(buie, u2), xi = TRC_TWO_PI * u3;
+        double st = sin(th);
+        ax = cos(xi) * st; ay = sin(xi) * st; az = cos(th);
+        break;
+    }
+    }
+    const double *rp = src->rot_pos, *rd = src->rot_dir;
+    *px = rp[0] * lx + rp[1] * ly + src->center[0];
+    *py = rp[3] * lx + rp[4] * ly + src->center[1];
+    *pz = rp[6] * lx + rp[7] * ly + src->center[2];
+    *dx = rd[0] * ax + rd[1] * ay + rd[2] * az;
+    *dy = rd[3] * ax + rd[4] * ay + rd[5] * az;
+    *dz = rd[6] * ax + rd[7] * ay + rd[8] * az;
+}
+
+// ---------------------------------------------------------------------------------------------
+// O8 -- flux-map bin of a coordinate for numpy.histogram edges (right edge of the last bin closed)
+// ---------------------------------------------------------------------------------------------
+TRC_HD int trc_bin_index(const double *edges, int nbins, double x) {
+    if (!(x >= edges[0]) || !(x <= edges[nbins])) return -1;
+    int lo = 0, hi = nbins;      // largest i with edges[i] <= x
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (edges[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+#endif  // TRC_CORE_H

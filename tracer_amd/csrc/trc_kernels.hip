@@ -1,0 +1,1684 @@
+// trc_kernels.hip -- CDNA4 (gfx950) kernels and the C-ABI of include/tracer_amd.h.
+//
+// Two engines over the same per-ray core (trc_core.h):
+//   * fast engine  (k_trace_fast): persistent wavefronts.  A lane carries one ray through all of its
+//     bounces in registers; when a lane's ray dies (miss, absorbed, culled) the wave refills its dead
+//     lanes from its slice of the ray-id range (ballot + prefix rank), so every iteration of the wave
+//     loop traces 64 live segments.  Surface frames, Kd nodes and the Buie table are staged in LDS;
+//     per-surface tallies are privatised in LDS and flushed once per workgroup.
+//   * ordered engine (k_ord_*): one launch per bounce, reproducing the reference's bundle order and
+//     parent indices for RayTree (tracer_engine.py:218-274); dead-ray compaction by wavefront ballot +
+//     prefix sum, surface-major ordering by a stable radix sort of (culled, surface, block) keys.
+//
+// No CPU fallback lives here: without a GPU every entry point fails with TRC_ERR_DEVICE.
+
+#include <cstring>
+#include <cstdlib>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <new>
+
+#include "trc_core.h"
+
+// ================================================================================================
+// error handling
+// ================================================================================================
+static thread_local std::string g_last_error;
+
+static int trc_fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return trc_fail(TRC_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                            __FILE__, __LINE__);                                                        \
+    } while (0)
+
+#define TRC_TRY(expr)                   \
+    do {                                \
+        int _s = (expr);                \
+        if (_s != TRC_OK) return _s;    \
+    } while (0)
+
+extern "C" const char *trc_last_error(void) { return g_last_error.c_str(); }
+extern "C" int trc_abi_version(void) { return TRC_ABI_VERSION; }
+
+// ================================================================================================
+// host-side objects
+// ================================================================================================
+struct trc_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    int n_cu;
+};
+
+struct FluxMapDev {
+    int32_t surf, nu, nv, pad;
+    int64_t edges_u, edges_v;  // offsets into fm_edges
+    int64_t bins;              // offset into the tally buffer
+    double proj[12];           // global -> local (rows 0..2 of round(inv(frame), 9), surface.py:125)
+};
+
+// device view of a scene, passed by value to kernels
+struct DScene {
+    const double *recs;
+    const double *opt;       // n_surf * 8
+    const int32_t *sflags;   // n_surf
+    const double *extra;
+    int32_t stride, n_surf, n_extra, has_kd;
+    // Kd-tree
+    const int32_t *kd_a, *kd_b, *kd_leaf, *kd_always;
+    const double *kd_split;
+    int32_t kd_nodes, kd_nleaf, kd_nalways, kd_pad;
+    double kd_bmin[3], kd_bmax[3];
+    // tallies: [absorbed S | received S | count S | segments, hits | flux bins ...]
+    double *tally;
+    // flux maps
+    const int32_t *fm_of_surf;  // n_surf, -1 = none
+    const FluxMapDev *fms;
+    const double *fm_edges;
+    // hit capture
+    unsigned long long *counters;  // [0] hit cursor, [1] hits dropped, [2] last cursor, [3] rays left
+    double *energy_left;
+    long long hit_cap;
+    int32_t *h_surf;
+    double *h_eabs, *h_ein, *h_px, *h_py, *h_pz, *h_dx, *h_dy, *h_dz;
+};
+
+struct trc_scene {
+    trc_ctx *ctx;
+    int32_t n_surf, stride, n_extra;
+    std::vector<trc_surface_desc> surfs;
+    std::vector<double> extra_h;
+    bool splits;  // some optics can emit two rays per hit
+    // device buffers
+    double *d_recs, *d_opt, *d_extra;
+    int32_t *d_sflags;
+    int32_t *d_kd_a, *d_kd_b, *d_kd_leaf, *d_kd_always;
+    double *d_kd_split;
+    int32_t kd_nodes, kd_nleaf, kd_nalways;
+    double kd_bounds[6];
+    bool has_kd;
+    double *d_tally;
+    int64_t tally_n;
+    std::vector<FluxMapDev> fms_h;
+    std::vector<double> fm_edges_h;
+    std::vector<int32_t> fm_of_surf_h;
+    int32_t *d_fm_of_surf;
+    FluxMapDev *d_fms;
+    double *d_fm_edges;
+    unsigned long long *d_counters;
+    double *d_energy_left;
+    int64_t hit_cap;
+    int32_t *d_h_surf;
+    double *d_h[8];
+};
+
+struct Level {
+    int64_t n_total, n_live;
+    double *x, *y, *z, *dx, *dy, *dz, *e, *ref, *wl;
+    uint64_t *rid;
+    int64_t *parent;
+    int32_t *surf;
+};
+
+struct trc_result {
+    trc_ctx *ctx;
+    std::vector<Level> levels;
+};
+
+template <class T>
+static int dev_alloc(T **p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess)
+        return trc_fail(TRC_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+    return TRC_OK;
+}
+template <class T>
+static void dev_free(T *&p) {
+    if (p) (void)hipFree((void *)p);
+    p = nullptr;
+}
+
+// ================================================================================================
+// device helpers
+// ================================================================================================
+struct LocalKdStack {
+    int node[TRC_KD_STACK];
+    float tmax[TRC_KD_STACK];
+    __device__ __forceinline__ void push(int sp, int n, double t) {
+        node[sp] = n;
+        tmax[sp] = __double2float_ru(t);  // rounded up: the interval only ever grows (conservative)
+    }
+    __device__ __forceinline__ void pop(int sp, int *n, double *t) {
+        *n = node[sp];
+        *t = (double)tmax[sp];
+    }
+};
+
+__device__ __forceinline__ trc_kd_view make_kd_view(const DScene &sc, const int32_t *a, const int32_t *b,
+                                                    const double *split, const int32_t *leaf,
+                                                    const int32_t *always) {
+    trc_kd_view kd;
+    kd.node_a = a; kd.node_b = b; kd.split = split; kd.leaf_surfs = leaf; kd.always = always;
+    kd.n_always = sc.kd_nalways;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { kd.bmin[i] = sc.kd_bmin[i]; kd.bmax[i] = sc.kd_bmax[i]; }
+    return kd;
+}
+
+__device__ __forceinline__ unsigned lane_id() { return __lane_id(); }
+
+// wave-level sum of a double (64 lanes)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// per-hit bookkeeping shared by both engines: tallies, flux map, hit capture
+template <bool LDS_TALLY>
+__device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, int s, double e_in,
+                                           double e_abs, double hx, double hy, double hz, double dx,
+                                           double dy, double dz, bool capture_enabled) {
+    const int S = sc.n_surf;
+    if (LDS_TALLY) {
+        atomicAdd(&lds_tally[s], e_abs);
+        atomicAdd(&lds_tally[S + s], e_in);
+        atomicAdd(&lds_tally[2 * S + s], 1.0);
+    } else {
+        atomicAdd(&sc.tally[s], e_abs);
+        atomicAdd(&sc.tally[S + s], e_in);
+        atomicAdd(&sc.tally[2 * S + s], 1.0);
+    }
+    int fm = sc.fm_of_surf ? sc.fm_of_surf[s] : -1;
+    if (fm >= 0) {
+        const FluxMapDev &m = sc.fms[fm];
+        double u = m.proj[0] * hx + m.proj[1] * hy + m.proj[2] * hz + m.proj[3];
+        double v = m.proj[4] * hx + m.proj[5] * hy + m.proj[6] * hz + m.proj[7];
+        int iu = trc_bin_index(sc.fm_edges + m.edges_u, m.nu, u);
+        int iv = trc_bin_index(sc.fm_edges + m.edges_v, m.nv, v);
+        if (iu >= 0 && iv >= 0) atomicAdd(&sc.tally[m.bins + (int64_t)iu * m.nv + iv], e_abs);
+    }
+    if (capture_enabled) {
+        // wave-aggregated append: one atomic per wave per iteration
+        bool want = (sc.sflags[s] & TRC_SURF_CAPTURE_HITS) != 0;
+        unsigned long long mask = __ballot(want);
+        if (mask) {
+            int leader = __ffsll((long long)mask) - 1;
+            unsigned long long base = 0;
+            if ((int)lane_id() == leader) base = atomicAdd(&sc.counters[0], (unsigned long long)__popcll(mask));
+            base = __shfl(base, leader, 64);
+            if (want) {
+                unsigned long long slot = base + __popcll(mask & ((1ull << lane_id()) - 1ull));
+                if ((long long)slot < sc.hit_cap) {
+                    sc.h_surf[slot] = s;
+                    sc.h_eabs[slot] = e_abs; sc.h_ein[slot] = e_in;
+                    sc.h_px[slot] = hx; sc.h_py[slot] = hy; sc.h_pz[slot] = hz;
+                    sc.h_dx[slot] = dx; sc.h_dy[slot] = dy; sc.h_dz[slot] = dz;
+                } else {
+                    atomicAdd(&sc.counters[1], 1ull);
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// fast engine
+// ================================================================================================
+struct FastParams {
+    DScene sc;
+    // given bundle (NULL when a source descriptor is used)
+    const double *x, *y, *z, *dx, *dy, *dz, *e, *ref, *wl;
+    const uint64_t *rid;
+    const trc_source_desc *src;  // device copy
+    long long n;
+    int reps;
+    int flags;
+    double min_energy;
+    unsigned long long seed, ray_offset;
+    // rays left after `reps` bounces
+    double *lx, *ly, *lz, *ldx, *ldy, *ldz, *le;
+    long long last_cap;
+    // LDS carve-up (in doubles / flags)
+    int lds_scene;    // surfaces (+ Kd arrays) staged in LDS
+    int lds_tally;    // tallies privatised in LDS
+    int capture;      // some surface captures hits
+};
+
+// LDS layout (doubles): [recs S*stride][kd_split nodes][buie 639][tally 3S+2] then int32: [kd_a][kd_b][leaf][always]
+__global__ __launch_bounds__(256) void k_trace_fast(FastParams P) {
+    extern __shared__ double lds[];
+    const DScene &sc = P.sc;
+    const int S = sc.n_surf;
+    const int tid = threadIdx.x;
+
+    const double *recs = sc.recs;
+    const double *kd_split = sc.kd_split;
+    const int32_t *kd_a = sc.kd_a, *kd_b = sc.kd_b, *kd_leaf = sc.kd_leaf, *kd_always = sc.kd_always;
+    double *cursor = lds;
+    if (P.lds_scene) {
+        double *l_recs = cursor; cursor += (size_t)S * sc.stride;
+        for (int i = tid; i < S * sc.stride; i += blockDim.x) l_recs[i] = sc.recs[i];
+        recs = l_recs;
+        if (sc.has_kd) {
+            double *l_split = cursor; cursor += sc.kd_nodes;
+            for (int i = tid; i < sc.kd_nodes; i += blockDim.x) l_split[i] = sc.kd_split[i];
+            kd_split = l_split;
+        }
+    }
+    const double *buie = nullptr;
+    if (P.src) {
+        const int NB = 3 * (TRC_BUIE_NELEM + 1) + 6;
+        double *l_buie = cursor; cursor += NB;
+        if (P.src->kind == TRC_SRC_BUIE_DISK || P.src->kind == TRC_SRC_BUIE_RECT)
+            for (int i = tid; i < NB; i += blockDim.x) l_buie[i] = P.src->buie[i];
+        buie = l_buie;
+    }
+    double *l_tally = cursor;
+    if (P.lds_tally) {
+        cursor += 3 * S + 2;
+        for (int i = tid; i < 3 * S + 2; i += blockDim.x) l_tally[i] = 0.0;
+    }
+    if (P.lds_scene && sc.has_kd) {
+        int32_t *ic = (int32_t *)cursor;
+        int32_t *l_a = ic; ic += sc.kd_nodes;
+        int32_t *l_b = ic; ic += sc.kd_nodes;
+        int32_t *l_leaf = ic; ic += sc.kd_nleaf;
+        int32_t *l_alw = ic;
+        for (int i = tid; i < sc.kd_nodes; i += blockDim.x) { l_a[i] = sc.kd_a[i]; l_b[i] = sc.kd_b[i]; }
+        for (int i = tid; i < sc.kd_nleaf; i += blockDim.x) l_leaf[i] = sc.kd_leaf[i];
+        for (int i = tid; i < sc.kd_nalways; i += blockDim.x) l_alw[i] = sc.kd_always[i];
+        kd_a = l_a; kd_b = l_b; kd_leaf = l_leaf; kd_always = l_alw;
+    }
+    __syncthreads();
+
+    const bool accel = sc.has_kd && (P.flags & TRC_TRACE_ACCEL);
+    trc_kd_view kd = make_kd_view(sc, kd_a, kd_b, kd_split, kd_leaf, kd_always);
+
+    // this wave's slice of the ray-id range
+    const unsigned lane = lane_id();
+    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (tid >> 6);
+    const long long chunk = (P.n + n_waves - 1) / n_waves;
+    long long next = wave * chunk;
+    long long end = next + chunk;
+    if (end > P.n) end = P.n;
+    if (next > end) next = end;
+
+    bool alive = false;
+    double px = 0, py = 0, pz = 0, dx = 0, dy = 0, dz = 0, e = 0, ref = 1.0, wl = 0.0;
+    unsigned long long rid = 0;
+    int bounce = 0;
+    double nseg = 0.0, nhit = 0.0;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    for (;;) {
+        // ---- refill dead lanes with fresh rays (ballot + prefix rank) ----
+        unsigned long long need = __ballot(!alive);
+        if (next < end && need) {
+            long long id = next + __popcll(need & lt_mask);
+            if (!alive && id < end) {
+                rid = P.rid ? P.rid[id] : (P.ray_offset + (unsigned long long)id);
+                if (P.src) {
+                    trc_source_ray(P.src, buie, P.seed, rid, &px, &py, &pz, &dx, &dy, &dz);
+                    e = P.src->energy; ref = 1.0; wl = 0.0;
+                } else {
+                    px = P.x[id]; py = P.y[id]; pz = P.z[id];
+                    dx = P.dx[id]; dy = P.dy[id]; dz = P.dz[id];
+                    e = P.e[id];
+                    ref = P.ref ? P.ref[id] : 1.0;
+                    wl = P.wl ? P.wl[id] : 0.0;
+                }
+                bounce = 0;
+                alive = true;
+            }
+            next += __popcll(need);
+        }
+        if (!__ballot(alive)) break;
+        if (!alive) continue;
+
+        // ---- one segment ----
+        nseg += 1.0;
+        double t;
+        int s;
+        if (accel) {
+            LocalKdStack stk;
+            trc_nearest_kd(kd, stk, recs, sc.stride, sc.extra, px, py, pz, dx, dy, dz, &t, &s);
+        } else {
+            trc_nearest_brute(recs, sc.stride, S, sc.extra, px, py, pz, dx, dy, dz, &t, &s);
+        }
+        if (s < 0) { alive = false; continue; }
+        nhit += 1.0;
+        bounce += 1;
+        const double *rec = recs + (size_t)s * sc.stride;
+        double hx = px + t * dx, hy = py + t * dy, hz = pz + t * dz;
+        double nx, ny, nz;
+        trc_normal(rec, hx, hy, hz, dx, dy, dz, &nx, &ny, &nz);
+        trc_ray_out out[2];
+        int n_out = trc_shade(trc_rec_opt_kind(rec), sc.opt + (size_t)s * 8, sc.extra, trc_rec_extra_off(rec),
+                              trc_rec_extra_len(rec), rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, nx, ny,
+                              nz, P.seed, rid, (uint32_t)bounce, out);
+        (void)n_out;  // scenes whose optics split rays are routed to the ordered engine by the host
+        double e_abs = e - out[0].e;
+        if (P.lds_tally) record_hit<true>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0);
+        else record_hit<false>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0);
+        px = hx; py = hy; pz = hz;
+        dx = out[0].dx; dy = out[0].dy; dz = out[0].dz;
+        e = out[0].e; ref = out[0].ref;
+        if (e <= P.min_energy) { alive = false; continue; }      // tracer_engine.py:242
+        if (bounce >= P.reps) {                                   // still alive after the last iteration
+            alive = false;
+            atomicAdd(&sc.counters[3], 1ull);
+            atomicAdd(sc.energy_left, e);
+            if (P.flags & TRC_TRACE_KEEP_LAST) {
+                unsigned long long slot = atomicAdd(&sc.counters[2], 1ull);
+                if ((long long)slot < P.last_cap) {
+                    P.lx[slot] = px; P.ly[slot] = py; P.lz[slot] = pz;
+                    P.ldx[slot] = dx; P.ldy[slot] = dy; P.ldz[slot] = dz; P.le[slot] = e;
+                }
+            }
+        }
+    }
+
+    // ---- flush ----
+    nseg = wave_sum(nseg);
+    nhit = wave_sum(nhit);
+    if (P.lds_tally) {
+        if (lane == 0) { atomicAdd(&l_tally[3 * S], nseg); atomicAdd(&l_tally[3 * S + 1], nhit); }
+        __syncthreads();
+        for (int i = tid; i < 3 * S + 2; i += blockDim.x) {
+            double v = l_tally[i];
+            if (v != 0.0) atomicAdd(&sc.tally[i], v);
+        }
+    } else if (lane == 0) {
+        atomicAdd(&sc.tally[3 * S], nseg);
+        atomicAdd(&sc.tally[3 * S + 1], nhit);
+    }
+}
+
+// ================================================================================================
+// source generation as a bundle (sources.*_bundle)
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_source_generate(const trc_source_desc *src, long long n,
+                                                         unsigned long long seed, unsigned long long offset,
+                                                         double *x, double *y, double *z, double *dx, double *dy,
+                                                         double *dz, double *e, uint64_t *rid) {
+    __shared__ double l_buie[3 * (TRC_BUIE_NELEM + 1) + 6];
+    for (int i = threadIdx.x; i < 3 * (TRC_BUIE_NELEM + 1) + 6; i += blockDim.x) l_buie[i] = src->buie[i];
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        unsigned long long r = offset + (unsigned long long)i;
+        double px, py, pz, qx, qy, qz;
+        trc_source_ray(src, l_buie, seed, r, &px, &py, &pz, &qx, &qy, &qz);
+        x[i] = px; y[i] = py; z[i] = pz;
+        dx[i] = qx; dy[i] = qy; dz[i] = qz;
+        e[i] = src->energy;
+        if (rid) rid[i] = r;
+    }
+}
+
+// ================================================================================================
+// ordered engine
+// ================================================================================================
+struct OrdParams {
+    DScene sc;
+    // current bundle (live rays of the previous level)
+    const double *x, *y, *z, *dx, *dy, *dz, *e, *ref, *wl;
+    const uint64_t *rid;
+    long long n;
+    int event;  // index of this interaction (1-based), same for the whole bundle
+    int flags;
+    double min_energy;
+    unsigned long long seed;
+    // outputs, 2n slots: child 0 of ray i at slot i, child 1 at slot n+i
+    double *ox, *oy, *oz, *odx, *ody, *odz, *oe, *oref, *owl;
+    uint64_t *orid;
+    uint32_t *key;  // (culled << 30) | (surface << 1) | block, 0xFFFFFFFF = empty slot
+};
+
+#define ORD_EMPTY 0xFFFFFFFFu
+#define ORD_CULLED_BIT (1u << 30)
+
+__global__ __launch_bounds__(256) void k_ord_bounce(OrdParams P) {
+    const DScene &sc = P.sc;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // global atomics for tallies here: this engine favours order over speed
+    if (i >= P.n) return;
+    double px = P.x[i], py = P.y[i], pz = P.z[i], dx = P.dx[i], dy = P.dy[i], dz = P.dz[i], e = P.e[i];
+    double ref = P.ref[i], wl = P.wl[i];
+    unsigned long long rid = P.rid[i];
+    double t;
+    int s;
+    if (sc.has_kd && (P.flags & TRC_TRACE_ACCEL)) {
+        trc_kd_view kd = make_kd_view(sc, sc.kd_a, sc.kd_b, sc.kd_split, sc.kd_leaf, sc.kd_always);
+        LocalKdStack stk;
+        trc_nearest_kd(kd, stk, sc.recs, sc.stride, sc.extra, px, py, pz, dx, dy, dz, &t, &s);
+    } else {
+        trc_nearest_brute(sc.recs, sc.stride, sc.n_surf, sc.extra, px, py, pz, dx, dy, dz, &t, &s);
+    }
+    uint32_t k0 = ORD_EMPTY, k1 = ORD_EMPTY;
+    if (s >= 0) {
+        const double *rec = sc.recs + (size_t)s * sc.stride;
+        double hx = px + t * dx, hy = py + t * dy, hz = pz + t * dz;
+        double nx, ny, nz;
+        trc_normal(rec, hx, hy, hz, dx, dy, dz, &nx, &ny, &nz);
+        trc_ray_out out[2];
+        int n_out = trc_shade(trc_rec_opt_kind(rec), sc.opt + (size_t)s * 8, sc.extra, trc_rec_extra_off(rec),
+                              trc_rec_extra_len(rec), rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, nx, ny,
+                              nz, P.seed, rid, (uint32_t)P.event, out);
+        double e_out = out[0].e + (n_out > 1 ? out[1].e : 0.0);
+        // tallies (no wave-aggregated capture here: lanes may have exited)
+        const int S = sc.n_surf;
+        atomicAdd(&sc.tally[s], e - e_out);
+        atomicAdd(&sc.tally[S + s], e);
+        atomicAdd(&sc.tally[2 * S + s], 1.0);
+        int fm = sc.fm_of_surf ? sc.fm_of_surf[s] : -1;
+        if (fm >= 0) {
+            const FluxMapDev &m = sc.fms[fm];
+            double u = m.proj[0] * hx + m.proj[1] * hy + m.proj[2] * hz + m.proj[3];
+            double v = m.proj[4] * hx + m.proj[5] * hy + m.proj[6] * hz + m.proj[7];
+            int iu = trc_bin_index(sc.fm_edges + m.edges_u, m.nu, u);
+            int iv = trc_bin_index(sc.fm_edges + m.edges_v, m.nv, v);
+            if (iu >= 0 && iv >= 0) atomicAdd(&sc.tally[m.bins + (int64_t)iu * m.nv + iv], e - e_out);
+        }
+        for (int c = 0; c < n_out; ++c) {
+            long long slot = (c == 0) ? i : (P.n + i);
+            P.ox[slot] = hx; P.oy[slot] = hy; P.oz[slot] = hz;
+            P.odx[slot] = out[c].dx; P.ody[slot] = out[c].dy; P.odz[slot] = out[c].dz;
+            P.oe[slot] = out[c].e; P.oref[slot] = out[c].ref; P.owl[slot] = wl;
+            P.orid[slot] = (c == 0) ? rid : trc_child_rid(rid, (uint32_t)P.event);
+            uint32_t k = ((uint32_t)s << 1) | (uint32_t)out[c].blk;
+            if (out[c].e <= P.min_energy) k |= ORD_CULLED_BIT;   // tracer_engine.py:242, :270-274
+            if (c == 0) k0 = k; else k1 = k;
+        }
+    }
+    P.key[i] = k0;
+    P.key[P.n + i] = k1;
+}
+
+// ---- order-preserving compaction of the occupied slots: ballot + prefix sum ----
+// pass 1: per-block counts of occupied and of culled slots
+__global__ __launch_bounds__(256) void k_compact_count(const uint32_t *key, long long n, unsigned *blk_cnt,
+                                                       unsigned *blk_culled) {
+    __shared__ unsigned s_cnt[4], s_cul[4];
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t k = (i < n) ? key[i] : ORD_EMPTY;
+    bool occ = k != ORD_EMPTY;
+    bool cul = occ && (k & ORD_CULLED_BIT);
+    unsigned long long m = __ballot(occ), mc = __ballot(cul);
+    int w = threadIdx.x >> 6;
+    if (lane_id() == 0) { s_cnt[w] = __popcll(m); s_cul[w] = __popcll(mc); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blk_cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        blk_culled[blockIdx.x] = s_cul[0] + s_cul[1] + s_cul[2] + s_cul[3];
+    }
+}
+
+// pass 2: exclusive scan of the block counts (one workgroup, wave-level scan over 256-wide chunks)
+__global__ __launch_bounds__(256) void k_scan_blocks(const unsigned *blk_cnt, const unsigned *blk_culled,
+                                                     long long n_blocks, unsigned long long *blk_off,
+                                                     unsigned long long *totals) {
+    __shared__ unsigned long long s_wave[4];
+    __shared__ unsigned long long s_carry;
+    unsigned long long culled = 0;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (long long base = 0; base < n_blocks; base += blockDim.x) {
+        long long i = base + threadIdx.x;
+        unsigned long long v = (i < n_blocks) ? blk_cnt[i] : 0;
+        culled += (i < n_blocks) ? blk_culled[i] : 0;
+        // inclusive scan inside the wave
+        unsigned long long incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned long long o = __shfl_up(incl, off, 64);
+            if ((int)lane_id() >= off) incl += o;
+        }
+        int w = threadIdx.x >> 6;
+        if (lane_id() == 63) s_wave[w] = incl;
+        __syncthreads();
+        unsigned long long wave_off = 0;
+        for (int k = 0; k < w; ++k) wave_off += s_wave[k];
+        unsigned long long carry = s_carry;
+        if (i < n_blocks) blk_off[i] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) s_carry = carry + wave_off + incl;
+        __syncthreads();
+    }
+    // total culled: block reduction
+    __shared__ unsigned long long s_cul[4];
+    unsigned long long c = culled;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if (lane_id() == 0) s_cul[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        totals[0] = s_carry;
+        totals[1] = s_cul[0] + s_cul[1] + s_cul[2] + s_cul[3];
+    }
+}
+
+// pass 3: scatter (key, slot) of the occupied slots, in slot order
+__global__ __launch_bounds__(256) void k_compact_scatter(const uint32_t *key, long long n,
+                                                         const unsigned long long *blk_off, uint32_t *ckey,
+                                                         uint32_t *cslot) {
+    __shared__ unsigned s_cnt[4];
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t k = (i < n) ? key[i] : ORD_EMPTY;
+    bool occ = k != ORD_EMPTY;
+    unsigned long long m = __ballot(occ);
+    int w = threadIdx.x >> 6;
+    if (lane_id() == 0) s_cnt[w] = __popcll(m);
+    __syncthreads();
+    unsigned wave_off = 0;
+    for (int q = 0; q < w; ++q) wave_off += s_cnt[q];
+    if (occ) {
+        unsigned long long pos = blk_off[blockIdx.x] + wave_off + __popcll(m & ((1ull << lane_id()) - 1ull));
+        ckey[pos] = k;
+        cslot[pos] = (uint32_t)i;
+    }
+}
+
+struct GatherParams {
+    const double *ox, *oy, *oz, *odx, *ody, *odz, *oe, *oref, *owl;
+    const uint64_t *orid;
+    const uint32_t *skey, *sslot;
+    long long m, n_parent;
+    double *x, *y, *z, *dx, *dy, *dz, *e, *ref, *wl;
+    uint64_t *rid;
+    int64_t *parent;
+    int32_t *surf;
+};
+
+__global__ __launch_bounds__(256) void k_ord_gather(GatherParams G) {
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= G.m) return;
+    uint32_t slot = G.sslot[j], k = G.skey[j];
+    G.x[j] = G.ox[slot]; G.y[j] = G.oy[slot]; G.z[j] = G.oz[slot];
+    G.dx[j] = G.odx[slot]; G.dy[j] = G.ody[slot]; G.dz[j] = G.odz[slot];
+    G.e[j] = G.oe[slot]; G.ref[j] = G.oref[slot]; G.wl[j] = G.owl[slot];
+    G.rid[j] = G.orid[slot];
+    G.parent[j] = (int64_t)(slot >= G.n_parent ? slot - G.n_parent : slot);   // tracer_engine.py:235-236
+    G.surf[j] = (int32_t)((k & ~ORD_CULLED_BIT) >> 1);
+}
+
+__global__ void k_fill_f64(double *p, long long n, double v) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+__global__ void k_fill_rid(uint64_t *p, long long n, unsigned long long offset) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        p[i] = offset + (unsigned long long)i;
+}
+
+// ================================================================================================
+// per-surface protocol kernels
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_gm_intersect(const double *rec, const double *extra, long long n,
+                                                      const double *x, const double *y, const double *z,
+                                                      const double *dx, const double *dy, const double *dz,
+                                                      double *t_out, double *hx, double *hy, double *hz) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double t = trc_intersect(rec, extra, x[i], y[i], z[i], dx[i], dy[i], dz[i]);
+    t_out[i] = t;
+    if (hx) {
+        // FiniteFlatGM / QuadricGM keep v + t*d for every ray (flat_surface.py:156, quadric.py:101)
+        hx[i] = x[i] + t * dx[i]; hy[i] = y[i] + t * dy[i]; hz[i] = z[i] + t * dz[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gm_normals(const double *rec, long long n, const double *hx,
+                                                    const double *hy, const double *hz, const double *dx,
+                                                    const double *dy, const double *dz, double *nx, double *ny,
+                                                    double *nz) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a, b, c;
+    trc_normal(rec, hx[i], hy[i], hz[i], dx[i], dy[i], dz[i], &a, &b, &c);
+    nx[i] = a; ny[i] = b; nz[i] = c;
+}
+
+struct OpticsParams {
+    const double *rec, *opt, *extra;
+    long long n;
+    const double *dx, *dy, *dz, *e, *ref, *wl;
+    const uint64_t *rid;
+    unsigned long long ray_offset;
+    const double *nx, *ny, *nz;
+    unsigned long long seed;
+    int event;
+    double *odx, *ody, *odz, *oe, *oref;
+    int32_t *oblk;  // 2n: -1 empty, else block id
+};
+
+__global__ __launch_bounds__(256) void k_optics_apply(OpticsParams P) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    trc_ray_out out[2];
+    unsigned long long rid = P.rid ? P.rid[i] : (P.ray_offset + (unsigned long long)i);
+    int n_out = trc_shade(trc_rec_opt_kind(P.rec), P.opt, P.extra, trc_rec_extra_off(P.rec),
+                          trc_rec_extra_len(P.rec), P.rec[2], P.rec[5], P.rec[8], P.dx[i], P.dy[i], P.dz[i],
+                          P.e[i], P.ref ? P.ref[i] : 1.0, P.wl ? P.wl[i] : 0.0, P.nx[i], P.ny[i], P.nz[i], P.seed,
+                          rid, (uint32_t)P.event, out);
+    for (int c = 0; c < 2; ++c) {
+        long long slot = c == 0 ? i : P.n + i;
+        if (c < n_out) {
+            P.odx[slot] = out[c].dx; P.ody[slot] = out[c].dy; P.odz[slot] = out[c].dz;
+            P.oe[slot] = out[c].e; P.oref[slot] = out[c].ref; P.oblk[slot] = out[c].blk;
+        } else {
+            P.oblk[slot] = -1;
+        }
+    }
+}
+
+// ================================================================================================
+// C-ABI: context
+// ================================================================================================
+extern "C" int trc_ctx_create(int device_id, trc_ctx **out) {
+    if (!out) return trc_fail(TRC_ERR_INVALID, "trc_ctx_create: out is NULL");
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev == 0)
+        return trc_fail(TRC_ERR_DEVICE, "no HIP device available (%s): this library has no CPU path",
+                        e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n_dev)
+        return trc_fail(TRC_ERR_INVALID, "device %d out of range (%d devices)", device_id, n_dev);
+    HIP_TRY(hipSetDevice(device_id));
+    trc_ctx *c = new (std::nothrow) trc_ctx();
+    if (!c) return trc_fail(TRC_ERR_NOMEM, "out of host memory");
+    c->device = device_id;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    c->n_cu = prop.multiProcessorCount;
+    *out = c;
+    return TRC_OK;
+}
+
+extern "C" int trc_ctx_destroy(trc_ctx *ctx) {
+    if (!ctx) return TRC_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return TRC_OK;
+}
+
+extern "C" int trc_ctx_synchronize(trc_ctx *ctx) {
+    if (!ctx) return trc_fail(TRC_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return TRC_OK;
+}
+
+extern "C" int trc_ctx_device_name(trc_ctx *ctx, char *buf, int buflen) {
+    if (!ctx || !buf || buflen <= 0) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return TRC_OK;
+}
+
+// ================================================================================================
+// C-ABI: scene
+// ================================================================================================
+static int validate_surface(const trc_surface_desc &s, int idx, int n_extra) {
+    if (s.gm_kind < 0 || s.gm_kind >= TRC_GM_KIND_COUNT)
+        return trc_fail(TRC_ERR_UNSUPPORTED, "surface %d: geometry kind %d is not in the native table", idx, s.gm_kind);
+    if (s.optics_kind < 0 || s.optics_kind >= TRC_OPT_KIND_COUNT)
+        return trc_fail(TRC_ERR_UNSUPPORTED, "surface %d: optics kind %d is not in the native table", idx, s.optics_kind);
+    bool needs_extra = s.gm_kind == TRC_GM_RECT_PERFORATED || s.optics_kind == TRC_OPT_REFLECTIVE_SPECTRAL;
+    if (needs_extra && (s.extra_off < 0 || s.extra_len <= 0 || s.extra_off + s.extra_len > n_extra))
+        return trc_fail(TRC_ERR_INVALID, "surface %d: extra range [%d,+%d) outside the %d extra values", idx,
+                        s.extra_off, s.extra_len, n_extra);
+    if (s.gm_kind == TRC_GM_RECT_PERFORATED && s.optics_kind == TRC_OPT_REFLECTIVE_SPECTRAL)
+        return trc_fail(TRC_ERR_UNSUPPORTED, "surface %d: perforated plate with spectral optics shares one extra range", idx);
+    // reference argument checks (flat_surface.py:192-195, :470-480; sphere_surface.py:31-32; cone.py:82-83)
+    const double *g = s.gm;
+    switch (s.gm_kind) {
+    case TRC_GM_RECT: case TRC_GM_RECT_EXTRUDED: case TRC_GM_RECT_PERFORATED:
+        if (!(g[0] > 0) || !(g[1] > 0)) return trc_fail(TRC_ERR_INVALID, "surface %d: width and height must be positive", idx);
+        break;
+    case TRC_GM_ROUND: case TRC_GM_ROUND_CUT:
+        if (!(g[0] > 0)) return trc_fail(TRC_ERR_INVALID, "surface %d: radius must be positive", idx);
+        if (g[1] >= 0 && !(g[1] < g[0])) return trc_fail(TRC_ERR_INVALID, "surface %d: inner radius must be lower than the outer one", idx);
+        break;
+    case TRC_GM_SPHERE: case TRC_GM_HEMISPHERE: case TRC_GM_SPHERE_RECT:
+        if (!(g[0] > 0)) return trc_fail(TRC_ERR_INVALID, "surface %d: radius must be positive", idx);
+        break;
+    default: break;
+    }
+    return TRC_OK;
+}
+
+static void pack_record(const trc_surface_desc &s, double *rec, int stride) {
+    for (int i = 0; i < stride; ++i) rec[i] = 0.0;
+    for (int r = 0; r < 3; ++r) {
+        for (int k = 0; k < 3; ++k) rec[3 * r + k] = s.frame[4 * r + k];
+        rec[9 + r] = s.frame[4 * r + 3];
+    }
+    int32_t *h = (int32_t *)(rec + 12);
+    h[0] = s.gm_kind; h[1] = s.optics_kind; h[2] = s.extra_off; h[3] = s.extra_len;
+    int np = trc_gm_nparams(s.gm_kind);
+    for (int i = 0; i < np; ++i) rec[TRC_REC_HDR + i] = s.gm[i];
+}
+
+static int scene_upload_surfaces(trc_scene *sc) {
+    std::vector<double> recs((size_t)sc->n_surf * sc->stride), opt((size_t)sc->n_surf * 8);
+    std::vector<int32_t> flags(sc->n_surf);
+    for (int i = 0; i < sc->n_surf; ++i) {
+        pack_record(sc->surfs[i], recs.data() + (size_t)i * sc->stride, sc->stride);
+        for (int k = 0; k < 8; ++k) opt[(size_t)i * 8 + k] = sc->surfs[i].opt[k];
+        flags[i] = sc->surfs[i].flags;
+    }
+    HIP_TRY(hipMemcpy(sc->d_recs, recs.data(), recs.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sc->d_opt, opt.data(), opt.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sc->d_sflags, flags.data(), flags.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return TRC_OK;
+}
+
+static int scene_alloc_tally(trc_scene *sc) {
+    dev_free(sc->d_tally);
+    int64_t n = 3 * (int64_t)sc->n_surf + 2;
+    for (auto &m : sc->fms_h) { m.bins = n; n += (int64_t)m.nu * m.nv; }
+    sc->tally_n = n;
+    TRC_TRY(dev_alloc(&sc->d_tally, (size_t)n));
+    HIP_TRY(hipMemset(sc->d_tally, 0, (size_t)n * sizeof(double)));
+    return TRC_OK;
+}
+
+extern "C" int trc_scene_create(trc_ctx *ctx, int32_t n_surf, const trc_surface_desc *surfs, int32_t n_extra,
+                                const double *extra, trc_scene **out) {
+    if (!ctx || !out || n_surf <= 0 || !surfs) return trc_fail(TRC_ERR_INVALID, "trc_scene_create: bad arguments");
+    if (n_surf >= (1 << 28)) return trc_fail(TRC_ERR_INVALID, "too many surfaces");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int max_np = 0;
+    bool splits = false;
+    for (int i = 0; i < n_surf; ++i) {
+        TRC_TRY(validate_surface(surfs[i], i, n_extra));
+        int np = trc_gm_nparams(surfs[i].gm_kind);
+        if (np > max_np) max_np = np;
+        if (surfs[i].optics_kind == TRC_OPT_REFRACTIVE_HOMOGENOUS && surfs[i].opt[2] == 0.0) splits = true;
+    }
+    trc_scene *sc = new (std::nothrow) trc_scene();
+    if (!sc) return trc_fail(TRC_ERR_NOMEM, "out of host memory");
+    sc->ctx = ctx;
+    sc->n_surf = n_surf;
+    sc->stride = TRC_REC_HDR + max_np;
+    if ((sc->stride & 1) == 0) sc->stride += 1;  // odd number of doubles: spreads records over LDS banks
+    sc->n_extra = n_extra;
+    sc->surfs.assign(surfs, surfs + n_surf);
+    if (n_extra > 0 && extra) sc->extra_h.assign(extra, extra + n_extra);
+    sc->splits = splits;
+    sc->has_kd = false;
+    sc->hit_cap = 0;
+    sc->fm_of_surf_h.assign(n_surf, -1);
+    int st = TRC_OK;
+    do {
+        if ((st = dev_alloc(&sc->d_recs, (size_t)n_surf * sc->stride))) break;
+        if ((st = dev_alloc(&sc->d_opt, (size_t)n_surf * 8))) break;
+        if ((st = dev_alloc(&sc->d_sflags, (size_t)n_surf))) break;
+        if ((st = dev_alloc(&sc->d_extra, (size_t)n_extra))) break;
+        if ((st = dev_alloc(&sc->d_fm_of_surf, (size_t)n_surf))) break;
+        if ((st = dev_alloc(&sc->d_counters, 8))) break;
+        if ((st = dev_alloc(&sc->d_energy_left, 1))) break;
+        if ((st = scene_upload_surfaces(sc))) break;
+        if (n_extra > 0 && hipMemcpy(sc->d_extra, sc->extra_h.data(), (size_t)n_extra * sizeof(double),
+                                     hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "extra upload failed"); break; }
+        if (hipMemcpy(sc->d_fm_of_surf, sc->fm_of_surf_h.data(), (size_t)n_surf * sizeof(int32_t),
+                      hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "upload failed"); break; }
+        if (hipMemset(sc->d_counters, 0, 8 * sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(sc->d_energy_left, 0, sizeof(double)) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memset failed"); break; }
+        if ((st = scene_alloc_tally(sc))) break;
+    } while (0);
+    if (st != TRC_OK) { trc_scene_destroy(sc); return st; }
+    *out = sc;
+    return TRC_OK;
+}
+
+extern "C" int trc_scene_destroy(trc_scene *sc) {
+    if (!sc) return TRC_OK;
+    (void)hipSetDevice(sc->ctx->device);
+    (void)hipStreamSynchronize(sc->ctx->stream);
+    dev_free(sc->d_recs); dev_free(sc->d_opt); dev_free(sc->d_extra); dev_free(sc->d_sflags);
+    dev_free(sc->d_kd_a); dev_free(sc->d_kd_b); dev_free(sc->d_kd_leaf); dev_free(sc->d_kd_always);
+    dev_free(sc->d_kd_split); dev_free(sc->d_tally); dev_free(sc->d_fm_of_surf); dev_free(sc->d_fms);
+    dev_free(sc->d_fm_edges); dev_free(sc->d_counters); dev_free(sc->d_energy_left); dev_free(sc->d_h_surf);
+    for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
+    delete sc;
+    return TRC_OK;
+}
+
+extern "C" int trc_scene_update_frames(trc_scene *sc, int32_t n_surf, const double *frames12) {
+    if (!sc || !frames12 || n_surf != sc->n_surf) return trc_fail(TRC_ERR_INVALID, "trc_scene_update_frames: bad arguments");
+    HIP_TRY(hipSetDevice(sc->ctx->device));
+    HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+    for (int i = 0; i < n_surf; ++i) memcpy(sc->surfs[i].frame, frames12 + 12 * (size_t)i, 12 * sizeof(double));
+    return scene_upload_surfaces(sc);
+}
+
+extern "C" int trc_scene_set_kdtree(trc_scene *sc, const trc_kdtree_desc *kd) {
+    if (!sc) return trc_fail(TRC_ERR_INVALID, "scene is NULL");
+    HIP_TRY(hipSetDevice(sc->ctx->device));
+    HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+    dev_free(sc->d_kd_a); dev_free(sc->d_kd_b); dev_free(sc->d_kd_leaf); dev_free(sc->d_kd_always); dev_free(sc->d_kd_split);
+    sc->has_kd = false;
+    if (!kd) return TRC_OK;
+    if (kd->n_nodes <= 0 || !kd->flag || !kd->split || !kd->child || !kd->leaf_off || !kd->leaf_cnt)
+        return trc_fail(TRC_ERR_INVALID, "trc_scene_set_kdtree: incomplete tree");
+    if (kd->n_nodes >= (1 << 29) || kd->n_leaf_surfs >= (1 << 29)) return trc_fail(TRC_ERR_INVALID, "tree too large");
+    std::vector<int32_t> a(kd->n_nodes), b(kd->n_nodes);
+    // validate and measure depth (the traversal stack is TRC_KD_STACK deep)
+    std::vector<int32_t> depth(kd->n_nodes, 0);
+    int max_depth = 0;
+    for (int i = 0; i < kd->n_nodes; ++i) {
+        int f = kd->flag[i];
+        if (f < 0 || f > 3) return trc_fail(TRC_ERR_INVALID, "node %d: flag %d", i, f);
+        if (f == 3) {
+            int off = kd->leaf_off[i], cnt = kd->leaf_cnt[i];
+            if (off < 0 || cnt < 0 || off + cnt > kd->n_leaf_surfs) return trc_fail(TRC_ERR_INVALID, "node %d: leaf range", i);
+            for (int k = 0; k < cnt; ++k) {
+                int s = kd->leaf_surfs[off + k];
+                if (s < 0 || s >= sc->n_surf) return trc_fail(TRC_ERR_INVALID, "node %d: surface %d out of range", i, s);
+            }
+            a[i] = (off << 2) | 3; b[i] = cnt;
+        } else {
+            int c = kd->child[i];
+            if (c <= i || c + 1 >= kd->n_nodes) return trc_fail(TRC_ERR_INVALID, "node %d: child %d out of range", i, c);
+            a[i] = (c << 2) | f; b[i] = 0;
+            depth[c] = depth[c + 1] = depth[i] + 1;
+            if (depth[c] > max_depth) max_depth = depth[c];
+        }
+    }
+    if (max_depth > TRC_KD_STACK) return trc_fail(TRC_ERR_UNSUPPORTED, "Kd-tree depth %d exceeds the traversal stack (%d)", max_depth, TRC_KD_STACK);
+    for (int k = 0; k < kd->n_always; ++k)
+        if (kd->always_relevant[k] < 0 || kd->always_relevant[k] >= sc->n_surf) return trc_fail(TRC_ERR_INVALID, "always_relevant out of range");
+    TRC_TRY(dev_alloc(&sc->d_kd_a, (size_t)kd->n_nodes));
+    TRC_TRY(dev_alloc(&sc->d_kd_b, (size_t)kd->n_nodes));
+    TRC_TRY(dev_alloc(&sc->d_kd_split, (size_t)kd->n_nodes));
+    TRC_TRY(dev_alloc(&sc->d_kd_leaf, (size_t)kd->n_leaf_surfs));
+    TRC_TRY(dev_alloc(&sc->d_kd_always, (size_t)kd->n_always));
+    HIP_TRY(hipMemcpy(sc->d_kd_a, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sc->d_kd_b, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sc->d_kd_split, kd->split, (size_t)kd->n_nodes * 8, hipMemcpyHostToDevice));
+    if (kd->n_leaf_surfs) HIP_TRY(hipMemcpy(sc->d_kd_leaf, kd->leaf_surfs, (size_t)kd->n_leaf_surfs * 4, hipMemcpyHostToDevice));
+    if (kd->n_always) HIP_TRY(hipMemcpy(sc->d_kd_always, kd->always_relevant, (size_t)kd->n_always * 4, hipMemcpyHostToDevice));
+    sc->kd_nodes = kd->n_nodes; sc->kd_nleaf = kd->n_leaf_surfs; sc->kd_nalways = kd->n_always;
+    memcpy(sc->kd_bounds, kd->bounds, sizeof(sc->kd_bounds));
+    sc->has_kd = true;
+    return TRC_OK;
+}
+
+extern "C" int trc_scene_set_fluxmap(trc_scene *sc, int32_t surf, int32_t nu, int32_t nv, const double *u_edges,
+                                           const double *v_edges, const double *proj12) {
+    if (!sc || surf < 0 || surf >= sc->n_surf || nu <= 0 || nv <= 0 || !u_edges || !v_edges || !proj12)
+        return trc_fail(TRC_ERR_INVALID, "trc_scene_set_fluxmap: bad arguments");
+    HIP_TRY(hipSetDevice(sc->ctx->device));
+    HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+    for (int i = 0; i < nu; ++i) if (!(u_edges[i + 1] > u_edges[i])) return trc_fail(TRC_ERR_INVALID, "u edges must increase");
+    for (int i = 0; i < nv; ++i) if (!(v_edges[i + 1] > v_edges[i])) return trc_fail(TRC_ERR_INVALID, "v edges must increase");
+    if (sc->fm_of_surf_h[surf] >= 0) return trc_fail(TRC_ERR_INVALID, "surface %d already has a flux map", surf);
+    FluxMapDev m;
+    m.surf = surf; m.nu = nu; m.nv = nv; m.pad = 0;
+    m.edges_u = (int64_t)sc->fm_edges_h.size();
+    sc->fm_edges_h.insert(sc->fm_edges_h.end(), u_edges, u_edges + nu + 1);
+    m.edges_v = (int64_t)sc->fm_edges_h.size();
+    sc->fm_edges_h.insert(sc->fm_edges_h.end(), v_edges, v_edges + nv + 1);
+    memcpy(m.proj, proj12, sizeof(m.proj));
+    m.bins = 0;
+    sc->fm_of_surf_h[surf] = (int32_t)sc->fms_h.size();
+    sc->fms_h.push_back(m);
+    TRC_TRY(scene_alloc_tally(sc));  // resets the tallies
+    dev_free(sc->d_fms); dev_free(sc->d_fm_edges);
+    TRC_TRY(dev_alloc(&sc->d_fms, sc->fms_h.size()));
+    TRC_TRY(dev_alloc(&sc->d_fm_edges, sc->fm_edges_h.size()));
+    HIP_TRY(hipMemcpy(sc->d_fms, sc->fms_h.data(), sc->fms_h.size() * sizeof(FluxMapDev), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sc->d_fm_edges, sc->fm_edges_h.data(), sc->fm_edges_h.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sc->d_fm_of_surf, sc->fm_of_surf_h.data(), (size_t)sc->n_surf * sizeof(int32_t), hipMemcpyHostToDevice));
+    return TRC_OK;
+}
+
+extern "C" int trc_scene_set_hit_capacity(trc_scene *sc, int64_t capacity) {
+    if (!sc || capacity < 0) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(sc->ctx->device));
+    HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+    dev_free(sc->d_h_surf);
+    for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
+    sc->hit_cap = 0;
+    if (capacity == 0) return TRC_OK;
+    TRC_TRY(dev_alloc(&sc->d_h_surf, (size_t)capacity));
+    for (int i = 0; i < 8; ++i) TRC_TRY(dev_alloc(&sc->d_h[i], (size_t)capacity));
+    sc->hit_cap = capacity;
+    return TRC_OK;
+}
+
+extern "C" int trc_scene_reset_tallies(trc_scene *sc) {
+    if (!sc) return trc_fail(TRC_ERR_INVALID, "scene is NULL");
+    HIP_TRY(hipSetDevice(sc->ctx->device));
+    HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+    HIP_TRY(hipMemset(sc->d_tally, 0, (size_t)sc->tally_n * sizeof(double)));
+    HIP_TRY(hipMemset(sc->d_counters, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(sc->d_energy_left, 0, sizeof(double)));
+    return TRC_OK;
+}
+
+extern "C" int trc_scene_get_tallies(trc_scene *sc, double *absorbed, double *received, int64_t *hits) {
+    if (!sc) return trc_fail(TRC_ERR_INVALID, "scene is NULL");
+    HIP_TRY(hipSetDevice(sc->ctx->device));
+    HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+    const int S = sc->n_surf;
+    std::vector<double> t((size_t)3 * S);
+    HIP_TRY(hipMemcpy(t.data(), sc->d_tally, t.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < S; ++i) {
+        if (absorbed) absorbed[i] = t[i];
+        if (received) received[i] = t[S + i];
+        if (hits) hits[i] = (int64_t)(t[2 * S + i] + 0.5);
+    }
+    return TRC_OK;
+}
+
+extern "C" int trc_scene_get_fluxmap(trc_scene *sc, int32_t surf, double *out) {
+    if (!sc || surf < 0 || surf >= sc->n_surf || !out) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    int fm = sc->fm_of_surf_h[surf];
+    if (fm < 0) return trc_fail(TRC_ERR_INVALID, "surface %d has no flux map", surf);
+    HIP_TRY(hipSetDevice(sc->ctx->device));
+    HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+    const FluxMapDev &m = sc->fms_h[fm];
+    HIP_TRY(hipMemcpy(out, sc->d_tally + m.bins, (size_t)m.nu * m.nv * sizeof(double), hipMemcpyDeviceToHost));
+    return TRC_OK;
+}
+
+extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, double *e_abs, double *e_in, double *px,
+                                  double *py, double *pz, double *dx, double *dy, double *dz) {
+    if (!sc || !n) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(sc->ctx->device));
+    HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+    unsigned long long c[2];
+    HIP_TRY(hipMemcpy(c, sc->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    int64_t cnt = (int64_t)c[0];
+    if (cnt > sc->hit_cap) cnt = sc->hit_cap;
+    *n = cnt;
+    if (cnt == 0) return TRC_OK;
+    double *dst[8] = {e_abs, e_in, px, py, pz, dx, dy, dz};
+    if (surf) HIP_TRY(hipMemcpy(surf, sc->d_h_surf, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i)
+        if (dst[i]) HIP_TRY(hipMemcpy(dst[i], sc->d_h[i], (size_t)cnt * 8, hipMemcpyDeviceToHost));
+    return TRC_OK;
+}
+
+extern "C" int trc_scene_tally_size(trc_scene *sc, int64_t *n_doubles) {
+    if (!sc || !n_doubles) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    *n_doubles = sc->tally_n;
+    return TRC_OK;
+}
+
+extern "C" int trc_scene_export_tallies(trc_scene *sc, double *dst, int32_t on_device) {
+    if (!sc || !dst) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(sc->ctx->device));
+    HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+    HIP_TRY(hipMemcpy(dst, sc->d_tally, (size_t)sc->tally_n * sizeof(double),
+                      on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return TRC_OK;
+}
+
+extern "C" int trc_scene_import_tallies(trc_scene *sc, const double *src, int32_t on_device) {
+    if (!sc || !src) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(sc->ctx->device));
+    HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+    HIP_TRY(hipMemcpy(sc->d_tally, src, (size_t)sc->tally_n * sizeof(double),
+                      on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    return TRC_OK;
+}
+
+static DScene make_dscene(trc_scene *sc) {
+    DScene d;
+    memset(&d, 0, sizeof(d));
+    d.recs = sc->d_recs; d.opt = sc->d_opt; d.sflags = sc->d_sflags; d.extra = sc->d_extra;
+    d.stride = sc->stride; d.n_surf = sc->n_surf; d.n_extra = sc->n_extra; d.has_kd = sc->has_kd ? 1 : 0;
+    d.kd_a = sc->d_kd_a; d.kd_b = sc->d_kd_b; d.kd_leaf = sc->d_kd_leaf; d.kd_always = sc->d_kd_always;
+    d.kd_split = sc->d_kd_split;
+    d.kd_nodes = sc->kd_nodes; d.kd_nleaf = sc->kd_nleaf; d.kd_nalways = sc->kd_nalways;
+    for (int i = 0; i < 3; ++i) { d.kd_bmin[i] = sc->kd_bounds[i]; d.kd_bmax[i] = sc->kd_bounds[3 + i]; }
+    d.tally = sc->d_tally;
+    d.fm_of_surf = sc->d_fm_of_surf; d.fms = sc->d_fms; d.fm_edges = sc->d_fm_edges;
+    d.counters = sc->d_counters; d.energy_left = sc->d_energy_left;
+    d.hit_cap = sc->hit_cap; d.h_surf = sc->d_h_surf;
+    d.h_eabs = sc->d_h[0]; d.h_ein = sc->d_h[1]; d.h_px = sc->d_h[2]; d.h_py = sc->d_h[3]; d.h_pz = sc->d_h[4];
+    d.h_dx = sc->d_h[5]; d.h_dy = sc->d_h[6]; d.h_dz = sc->d_h[7];
+    return d;
+}
+
+// ================================================================================================
+// ray staging helpers
+// ================================================================================================
+struct DevRays {
+    double *x = nullptr, *y = nullptr, *z = nullptr, *dx = nullptr, *dy = nullptr, *dz = nullptr, *e = nullptr;
+    double *ref = nullptr, *wl = nullptr;
+    uint64_t *rid = nullptr;
+    bool owned[10] = {false, false, false, false, false, false, false, false, false, false};
+    void release() {
+        double **p[9] = {&x, &y, &z, &dx, &dy, &dz, &e, &ref, &wl};
+        for (int i = 0; i < 9; ++i) { if (owned[i] && *p[i]) (void)hipFree(*p[i]); *p[i] = nullptr; }
+        if (owned[9] && rid) (void)hipFree(rid);
+        rid = nullptr;
+    }
+};
+
+static int check_rays(const trc_rays *r, int64_t n, const char *who) {
+    if (!r) return trc_fail(TRC_ERR_INVALID, "%s: rays is NULL", who);
+    if (r->n < n) return trc_fail(TRC_ERR_INVALID, "%s: bundle holds %lld rays, %lld requested", who, (long long)r->n, (long long)n);
+    if (n > 0 && (!r->x || !r->y || !r->z || !r->dx || !r->dy || !r->dz))
+        return trc_fail(TRC_ERR_INVALID, "%s: vertices and directions are required", who);
+    return TRC_OK;
+}
+
+// bring the required columns of a bundle to the device (no copy when already there)
+static int stage_rays(const trc_rays *r, int64_t n, bool need_energy, DevRays *d) {
+    const double *src[9] = {r->x, r->y, r->z, r->dx, r->dy, r->dz, r->e, r->ref_index, r->wavelength};
+    double **dst[9] = {&d->x, &d->y, &d->z, &d->dx, &d->dy, &d->dz, &d->e, &d->ref, &d->wl};
+    if (need_energy && !r->e) return trc_fail(TRC_ERR_INVALID, "ray energies are required");
+    for (int i = 0; i < 9; ++i) {
+        if (!src[i]) continue;
+        if (r->on_device) { *dst[i] = (double *)src[i]; continue; }
+        TRC_TRY(dev_alloc(dst[i], (size_t)n));
+        d->owned[i] = true;
+        HIP_TRY(hipMemcpy(*dst[i], src[i], (size_t)n * 8, hipMemcpyHostToDevice));
+    }
+    if (r->rid) {
+        if (r->on_device) d->rid = r->rid;
+        else {
+            TRC_TRY(dev_alloc(&d->rid, (size_t)n));
+            d->owned[9] = true;
+            HIP_TRY(hipMemcpy(d->rid, r->rid, (size_t)n * 8, hipMemcpyHostToDevice));
+        }
+    }
+    return TRC_OK;
+}
+
+static int upload_source(const trc_source_desc *src, trc_source_desc **d_src) {
+    if (src->kind < TRC_SRC_PILLBOX_DISK || src->kind > TRC_SRC_BUIE_RECT)
+        return trc_fail(TRC_ERR_UNSUPPORTED, "source kind %d is not in the native table", src->kind);
+    TRC_TRY(dev_alloc(d_src, 1));
+    HIP_TRY(hipMemcpy(*d_src, src, sizeof(trc_source_desc), hipMemcpyHostToDevice));
+    return TRC_OK;
+}
+
+// ================================================================================================
+// C-ABI: fast engine
+// ================================================================================================
+extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_source_desc *src, int64_t n, int32_t reps,
+                              double min_energy, uint64_t seed, uint64_t ray_offset, int32_t flags, trc_rays *last,
+                              trc_trace_stats *stats) {
+    if (!sc) return trc_fail(TRC_ERR_INVALID, "scene is NULL");
+    if ((in == nullptr) == (src == nullptr)) return trc_fail(TRC_ERR_INVALID, "exactly one of `in` and `src` must be given");
+    if (n < 0 || reps < 0) return trc_fail(TRC_ERR_INVALID, "n and reps must be >= 0");
+    if (sc->splits) return trc_fail(TRC_ERR_UNSUPPORTED, "the scene has ray-splitting optics: use trc_trace_ordered");
+    if ((flags & TRC_TRACE_ACCEL) && !sc->has_kd) return trc_fail(TRC_ERR_INVALID, "TRC_TRACE_ACCEL without a Kd-tree on the scene");
+    trc_ctx *ctx = sc->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevRays dr;
+    trc_source_desc *d_src = nullptr;
+    double *d_last[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int st = TRC_OK;
+    trc_trace_stats s;
+    memset(&s, 0, sizeof(s));
+    double tally_before[2] = {0, 0};
+    unsigned long long cnt_before[4] = {0, 0, 0, 0};
+    double eleft_before = 0;
+    const int S = sc->n_surf;
+    do {
+        if (in) { if ((st = check_rays(in, n, "trc_trace_fast")) || (st = stage_rays(in, n, true, &dr))) break; }
+        else if ((st = upload_source(src, &d_src))) break;
+        int64_t last_cap = 0;
+        if (flags & TRC_TRACE_KEEP_LAST) {
+            if (!last || !last->x || !last->y || !last->z || !last->dx || !last->dy || !last->dz || !last->e || last->on_device) {
+                st = trc_fail(TRC_ERR_INVALID, "TRC_TRACE_KEEP_LAST needs a host `last` bundle with x..e"); break;
+            }
+            last_cap = last->n;
+            for (int i = 0; i < 7 && st == TRC_OK; ++i) st = dev_alloc(&d_last[i], (size_t)last_cap);
+            if (st) break;
+        }
+        if (hipMemcpy(tally_before, sc->d_tally + 3 * S, sizeof(tally_before), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(cnt_before, sc->d_counters, sizeof(cnt_before), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&eleft_before, sc->d_energy_left, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+            st = trc_fail(TRC_ERR_DEVICE, "counter readback failed"); break;
+        }
+        // the `last` cursor restarts for every call
+        unsigned long long zero = 0;
+        if (hipMemcpy(sc->d_counters + 2, &zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+
+        FastParams P;
+        memset(&P, 0, sizeof(P));
+        P.sc = make_dscene(sc);
+        P.x = dr.x; P.y = dr.y; P.z = dr.z; P.dx = dr.dx; P.dy = dr.dy; P.dz = dr.dz; P.e = dr.e;
+        P.ref = dr.ref; P.wl = dr.wl; P.rid = dr.rid;
+        P.src = d_src;
+        P.n = n; P.reps = reps; P.flags = flags; P.min_energy = min_energy; P.seed = seed; P.ray_offset = ray_offset;
+        P.lx = d_last[0]; P.ly = d_last[1]; P.lz = d_last[2]; P.ldx = d_last[3]; P.ldy = d_last[4]; P.ldz = d_last[5]; P.le = d_last[6];
+        P.last_cap = last_cap;
+        P.capture = 0;
+        if (sc->hit_cap > 0)
+            for (int i = 0; i < S; ++i) if (sc->surfs[i].flags & TRC_SURF_CAPTURE_HITS) P.capture = 1;
+
+        // LDS budget: stage the scene (and the Kd-tree) when it fits in 64 KiB together with the rest
+        const bool accel = sc->has_kd && (flags & TRC_TRACE_ACCEL);
+        size_t b_buie = src ? (size_t)(3 * (TRC_BUIE_NELEM + 1) + 6) * 8 : 0;
+        size_t b_tally = (size_t)(3 * S + 2) * 8;
+        size_t b_scene = (size_t)S * sc->stride * 8;
+        if (sc->has_kd) b_scene += (size_t)sc->kd_nodes * 8 + ((size_t)sc->kd_nodes * 2 + sc->kd_nleaf + sc->kd_nalways) * 4 + 8;
+        const size_t LDS_MAX = 64 * 1024;
+        size_t lds = b_buie;
+        P.lds_tally = (lds + b_tally <= LDS_MAX) ? 1 : 0;
+        if (P.lds_tally) lds += b_tally;
+        P.lds_scene = (lds + b_scene <= LDS_MAX) ? 1 : 0;
+        if (P.lds_scene) lds += b_scene;
+        (void)accel;
+
+        // persistent grid: as many workgroups as are resident at once, never more waves than rays/64
+        int blocks_per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_trace_fast, 256, lds) != hipSuccess || blocks_per_cu < 1)
+            blocks_per_cu = 1;
+        if (blocks_per_cu > 8) blocks_per_cu = 8;
+        long long grid = (long long)ctx->n_cu * blocks_per_cu;
+        long long max_grid = (n + 255) / 256;
+        if (grid > max_grid) grid = max_grid;
+        if (grid < 1) grid = 1;
+        if (n > 0) {
+            if (hipEventRecord(ctx->ev0, ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "event record failed"); break; }
+            hipLaunchKernelGGL(k_trace_fast, dim3((unsigned)grid), dim3(256), lds, ctx->stream, P);
+            hipError_t le = hipGetLastError();
+            if (le != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "k_trace_fast launch failed: %s", hipGetErrorString(le)); break; }
+            if (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "event record failed"); break; }
+            hipError_t se = hipStreamSynchronize(ctx->stream);
+            if (se != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "k_trace_fast failed: %s", hipGetErrorString(se)); break; }
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+            s.kernel_ms = ms;
+            s.launches = 1;
+        }
+        double tally_after[2];
+        unsigned long long cnt_after[4];
+        double eleft_after;
+        if (hipMemcpy(tally_after, sc->d_tally + 3 * S, sizeof(tally_after), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(cnt_after, sc->d_counters, sizeof(cnt_after), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&eleft_after, sc->d_energy_left, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+            st = trc_fail(TRC_ERR_DEVICE, "counter readback failed"); break;
+        }
+        s.segments = (int64_t)(tally_after[0] - tally_before[0] + 0.5);
+        s.hits = (int64_t)(tally_after[1] - tally_before[1] + 0.5);
+        s.rays_left = (int64_t)(cnt_after[3] - cnt_before[3]);
+        s.hits_dropped = (int64_t)(cnt_after[1] - cnt_before[1]);
+        s.energy_left = eleft_after - eleft_before;
+        s.bounces = reps;
+        if (flags & TRC_TRACE_KEEP_LAST) {
+            int64_t m = (int64_t)cnt_after[2];
+            if (m > last_cap) { st = trc_fail(TRC_ERR_CAPACITY, "%lld rays left but `last` holds %lld", (long long)m, (long long)last_cap); break; }
+            double *dst[7] = {last->x, last->y, last->z, last->dx, last->dy, last->dz, last->e};
+            for (int i = 0; i < 7 && m > 0; ++i)
+                if (hipMemcpy(dst[i], d_last[i], (size_t)m * 8, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+            last->n = m;
+        }
+    } while (0);
+    dr.release();
+    dev_free(d_src);
+    for (int i = 0; i < 7; ++i) dev_free(d_last[i]);
+    if (stats) *stats = s;
+    return st;
+}
+
+// ================================================================================================
+// C-ABI: source generation
+// ================================================================================================
+extern "C" int trc_source_generate(trc_ctx *ctx, const trc_source_desc *src, int64_t n, uint64_t seed,
+                                   uint64_t ray_offset, trc_rays *out) {
+    if (!ctx || !src || n < 0) return trc_fail(TRC_ERR_INVALID, "trc_source_generate: bad arguments");
+    TRC_TRY(check_rays(out, n, "trc_source_generate"));
+    if (!out->e) return trc_fail(TRC_ERR_INVALID, "trc_source_generate: energy column required");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) return TRC_OK;
+    trc_source_desc *d_src = nullptr;
+    double *d[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint64_t *d_rid = nullptr;
+    int st = TRC_OK;
+    do {
+        if ((st = upload_source(src, &d_src))) break;
+        double *host[7] = {out->x, out->y, out->z, out->dx, out->dy, out->dz, out->e};
+        if (out->on_device) { for (int i = 0; i < 7; ++i) d[i] = host[i]; d_rid = out->rid; }
+        else {
+            for (int i = 0; i < 7 && st == TRC_OK; ++i) st = dev_alloc(&d[i], (size_t)n);
+            if (st == TRC_OK && out->rid) st = dev_alloc(&d_rid, (size_t)n);
+            if (st) break;
+        }
+        long long grid = (n + 255) / 256;
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(k_source_generate, dim3((unsigned)grid), dim3(256), 0, ctx->stream, d_src, (long long)n,
+                           (unsigned long long)seed, (unsigned long long)ray_offset, d[0], d[1], d[2], d[3], d[4], d[5],
+                           d[6], d_rid);
+        hipError_t se = hipStreamSynchronize(ctx->stream);
+        if (se != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "k_source_generate failed: %s", hipGetErrorString(se)); break; }
+        if (!out->on_device) {
+            for (int i = 0; i < 7; ++i)
+                if (hipMemcpy(host[i], d[i], (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+            if (st == TRC_OK && out->rid && hipMemcpy(out->rid, d_rid, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                st = trc_fail(TRC_ERR_DEVICE, "memcpy failed");
+        }
+    } while (0);
+    dev_free(d_src);
+    if (!out->on_device) { for (int i = 0; i < 7; ++i) dev_free(d[i]); dev_free(d_rid); }
+    return st;
+}
+
+// ================================================================================================
+// C-ABI: ordered engine
+// ================================================================================================
+static void level_free(Level &L) {
+    dev_free(L.x); dev_free(L.y); dev_free(L.z); dev_free(L.dx); dev_free(L.dy); dev_free(L.dz); dev_free(L.e);
+    dev_free(L.ref); dev_free(L.wl); dev_free(L.rid); dev_free(L.parent); dev_free(L.surf);
+}
+
+static int level_alloc(Level &L, int64_t n) {
+    memset(&L, 0, sizeof(L));
+    L.n_total = n; L.n_live = n;
+    double **p[9] = {&L.x, &L.y, &L.z, &L.dx, &L.dy, &L.dz, &L.e, &L.ref, &L.wl};
+    for (int i = 0; i < 9; ++i) TRC_TRY(dev_alloc(p[i], (size_t)n));
+    TRC_TRY(dev_alloc(&L.rid, (size_t)n));
+    TRC_TRY(dev_alloc(&L.parent, (size_t)n));
+    TRC_TRY(dev_alloc(&L.surf, (size_t)n));
+    return TRC_OK;
+}
+
+struct OrdScratch {
+    double *o[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint64_t *orid = nullptr;
+    uint32_t *key = nullptr, *ckey = nullptr, *cslot = nullptr, *skey = nullptr, *sslot = nullptr;
+    unsigned *blk_cnt = nullptr, *blk_cul = nullptr;
+    unsigned long long *blk_off = nullptr, *totals = nullptr;
+    void *sort_tmp = nullptr;
+    void release() {
+        for (int i = 0; i < 9; ++i) dev_free(o[i]);
+        dev_free(orid); dev_free(key); dev_free(ckey); dev_free(cslot); dev_free(skey); dev_free(sslot);
+        dev_free(blk_cnt); dev_free(blk_cul); dev_free(blk_off); dev_free(totals);
+        if (sort_tmp) (void)hipFree(sort_tmp);
+        sort_tmp = nullptr;
+    }
+};
+
+extern "C" int trc_result_destroy(trc_result *res) {
+    if (!res) return TRC_OK;
+    (void)hipSetDevice(res->ctx->device);
+    for (auto &L : res->levels) level_free(L);
+    delete res;
+    return TRC_OK;
+}
+
+extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_source_desc *src, int64_t n, int32_t reps,
+                                 double min_energy, uint64_t seed, uint64_t ray_offset, int32_t flags, trc_result **out,
+                                 trc_trace_stats *stats) {
+    if (!sc || !out) return trc_fail(TRC_ERR_INVALID, "trc_trace_ordered: bad arguments");
+    *out = nullptr;
+    if ((in == nullptr) == (src == nullptr)) return trc_fail(TRC_ERR_INVALID, "exactly one of `in` and `src` must be given");
+    if (n < 0 || reps < 0) return trc_fail(TRC_ERR_INVALID, "n and reps must be >= 0");
+    if (2 * n >= (int64_t)0xFFFFFFFFll) return trc_fail(TRC_ERR_UNSUPPORTED, "ordered engine handles fewer than 2^31 rays per call");
+    if ((flags & TRC_TRACE_ACCEL) && !sc->has_kd) return trc_fail(TRC_ERR_INVALID, "TRC_TRACE_ACCEL without a Kd-tree on the scene");
+    if (sc->n_surf >= (1 << 28)) return trc_fail(TRC_ERR_UNSUPPORTED, "too many surfaces for the ordering key");
+    trc_ctx *ctx = sc->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    trc_result *res = new (std::nothrow) trc_result();
+    if (!res) return trc_fail(TRC_ERR_NOMEM, "out of host memory");
+    res->ctx = ctx;
+    trc_trace_stats s;
+    memset(&s, 0, sizeof(s));
+    OrdScratch sx;
+    trc_source_desc *d_src = nullptr;
+    int st = TRC_OK;
+    float total_ms = 0;
+    do {
+        // ---- level 0: the source bundle ----
+        Level L0;
+        if ((st = level_alloc(L0, n))) { level_free(L0); break; }
+        res->levels.push_back(L0);
+        Level &B0 = res->levels.back();
+        long long g0 = (n + 255) / 256; if (g0 > 8192) g0 = 8192; if (g0 < 1) g0 = 1;
+        if (src) {
+            if ((st = upload_source(src, &d_src))) break;
+            hipLaunchKernelGGL(k_source_generate, dim3((unsigned)g0), dim3(256), 0, ctx->stream, d_src, (long long)n,
+                               (unsigned long long)seed, (unsigned long long)ray_offset, B0.x, B0.y, B0.z, B0.dx, B0.dy,
+                               B0.dz, B0.e, B0.rid);
+            hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)g0), dim3(256), 0, ctx->stream, B0.ref, (long long)n, 1.0);
+            hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)g0), dim3(256), 0, ctx->stream, B0.wl, (long long)n, 0.0);
+        } else {
+            if ((st = check_rays(in, n, "trc_trace_ordered"))) break;
+            if (!in->e) { st = trc_fail(TRC_ERR_INVALID, "ray energies are required"); break; }
+            hipMemcpyKind kind = in->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+            const double *hs[7] = {in->x, in->y, in->z, in->dx, in->dy, in->dz, in->e};
+            double *ds[7] = {B0.x, B0.y, B0.z, B0.dx, B0.dy, B0.dz, B0.e};
+            bool bad = false;
+            for (int i = 0; i < 7 && n > 0; ++i) if (hipMemcpy(ds[i], hs[i], (size_t)n * 8, kind) != hipSuccess) bad = true;
+            if (in->ref_index) { if (n > 0 && hipMemcpy(B0.ref, in->ref_index, (size_t)n * 8, kind) != hipSuccess) bad = true; }
+            else hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)g0), dim3(256), 0, ctx->stream, B0.ref, (long long)n, 1.0);
+            if (in->wavelength) { if (n > 0 && hipMemcpy(B0.wl, in->wavelength, (size_t)n * 8, kind) != hipSuccess) bad = true; }
+            else hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)g0), dim3(256), 0, ctx->stream, B0.wl, (long long)n, 0.0);
+            if (in->rid) { if (n > 0 && hipMemcpy(B0.rid, in->rid, (size_t)n * 8, kind) != hipSuccess) bad = true; }
+            else hipLaunchKernelGGL(k_fill_rid, dim3((unsigned)g0), dim3(256), 0, ctx->stream, B0.rid, (long long)n, (unsigned long long)ray_offset);
+            if (bad) { st = trc_fail(TRC_ERR_DEVICE, "bundle upload failed"); break; }
+        }
+        if (n > 0) {
+            (void)hipMemsetAsync(B0.parent, 0, (size_t)n * 8, ctx->stream);
+            (void)hipMemsetAsync(B0.surf, 0xFF, (size_t)n * 4, ctx->stream);
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "level 0 setup failed"); break; }
+
+        // ---- bounce loop ----
+        int64_t n_cur = n;
+        for (int it = 0; it < reps && n_cur > 0; ++it) {
+            const Level cur = res->levels.back();
+            const int64_t slots = 2 * n_cur;
+            sx.release();
+            for (int i = 0; i < 9 && st == TRC_OK; ++i) st = dev_alloc(&sx.o[i], (size_t)slots);
+            if (st == TRC_OK) st = dev_alloc(&sx.orid, (size_t)slots);
+            if (st == TRC_OK) st = dev_alloc(&sx.key, (size_t)slots);
+            const long long nblk = (slots + 255) / 256;
+            if (st == TRC_OK) st = dev_alloc(&sx.blk_cnt, (size_t)nblk);
+            if (st == TRC_OK) st = dev_alloc(&sx.blk_cul, (size_t)nblk);
+            if (st == TRC_OK) st = dev_alloc(&sx.blk_off, (size_t)nblk);
+            if (st == TRC_OK) st = dev_alloc(&sx.totals, 2);
+            if (st) break;
+
+            OrdParams P;
+            memset(&P, 0, sizeof(P));
+            P.sc = make_dscene(sc);
+            P.x = cur.x; P.y = cur.y; P.z = cur.z; P.dx = cur.dx; P.dy = cur.dy; P.dz = cur.dz; P.e = cur.e;
+            P.ref = cur.ref; P.wl = cur.wl; P.rid = cur.rid;
+            P.n = n_cur; P.event = it + 1; P.flags = flags; P.min_energy = min_energy; P.seed = seed;
+            P.ox = sx.o[0]; P.oy = sx.o[1]; P.oz = sx.o[2]; P.odx = sx.o[3]; P.ody = sx.o[4]; P.odz = sx.o[5];
+            P.oe = sx.o[6]; P.oref = sx.o[7]; P.owl = sx.o[8]; P.orid = sx.orid; P.key = sx.key;
+
+            (void)hipEventRecord(ctx->ev0, ctx->stream);
+            hipLaunchKernelGGL(k_ord_bounce, dim3((unsigned)((n_cur + 255) / 256)), dim3(256), 0, ctx->stream, P);
+            hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, sx.key, (long long)slots,
+                               sx.blk_cnt, sx.blk_cul);
+            hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, sx.blk_cnt, sx.blk_cul, nblk, sx.blk_off,
+                               sx.totals);
+            (void)hipEventRecord(ctx->ev1, ctx->stream);
+            unsigned long long totals[2];
+            hipError_t ce = hipMemcpyAsync(totals, sx.totals, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream);
+            hipError_t se = hipStreamSynchronize(ctx->stream);
+            if (ce != hipSuccess || se != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "bounce %d failed: %s", it, hipGetErrorString(se != hipSuccess ? se : ce)); break; }
+            float ms = 0; (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1); total_ms += ms;
+            s.launches += 3;
+            s.segments += n_cur;
+            s.bounces = it + 1;
+            const int64_t m = (int64_t)totals[0], n_culled = (int64_t)totals[1];
+            // hits = rays that produced at least one child: count child-0 slots == slots < n_cur occupied; cheap bound: m minus second children
+            if (m == 0) { n_cur = 0; break; }   // "Ray bundle depleted": nothing recorded (tracer_engine.py:271, :277)
+            if ((st = dev_alloc(&sx.ckey, (size_t)m)) || (st = dev_alloc(&sx.cslot, (size_t)m)) ||
+                (st = dev_alloc(&sx.skey, (size_t)m)) || (st = dev_alloc(&sx.sslot, (size_t)m))) break;
+            hipLaunchKernelGGL(k_compact_scatter, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, sx.key, (long long)slots,
+                               sx.blk_off, sx.ckey, sx.cslot);
+            // stable sort by (culled, surface, block); slot order (= parent order) is kept inside a key
+            size_t tmp_bytes = 0;
+            hipError_t re = rocprim::radix_sort_pairs(nullptr, tmp_bytes, sx.ckey, sx.skey, sx.cslot, sx.sslot, (size_t)m, 0, 31, ctx->stream);
+            if (re != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "radix_sort_pairs(size query) failed: %s", hipGetErrorString(re)); break; }
+            if (hipMalloc(&sx.sort_tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { st = trc_fail(TRC_ERR_NOMEM, "sort scratch allocation failed"); break; }
+            re = rocprim::radix_sort_pairs(sx.sort_tmp, tmp_bytes, sx.ckey, sx.skey, sx.cslot, sx.sslot, (size_t)m, 0, 31, ctx->stream);
+            if (re != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "radix_sort_pairs failed: %s", hipGetErrorString(re)); break; }
+            Level Ln;
+            if ((st = level_alloc(Ln, m))) { level_free(Ln); break; }
+            Ln.n_live = m - n_culled;
+            res->levels.push_back(Ln);
+            GatherParams G;
+            G.ox = sx.o[0]; G.oy = sx.o[1]; G.oz = sx.o[2]; G.odx = sx.o[3]; G.ody = sx.o[4]; G.odz = sx.o[5];
+            G.oe = sx.o[6]; G.oref = sx.o[7]; G.owl = sx.o[8]; G.orid = sx.orid; G.skey = sx.skey; G.sslot = sx.sslot;
+            G.m = m; G.n_parent = n_cur;
+            G.x = Ln.x; G.y = Ln.y; G.z = Ln.z; G.dx = Ln.dx; G.dy = Ln.dy; G.dz = Ln.dz; G.e = Ln.e; G.ref = Ln.ref;
+            G.wl = Ln.wl; G.rid = Ln.rid; G.parent = Ln.parent; G.surf = Ln.surf;
+            hipLaunchKernelGGL(k_ord_gather, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, G);
+            se = hipStreamSynchronize(ctx->stream);
+            if (se != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "ordering of bounce %d failed: %s", it, hipGetErrorString(se)); break; }
+            s.launches += 3;
+            s.hits += m;
+            n_cur = Ln.n_live;
+        }
+        if (st) break;
+        s.rays_left = n_cur;
+        s.kernel_ms = total_ms;
+        if (n_cur > 0) {
+            // energy of the live part of the last level
+            const Level &LL = res->levels.back();
+            std::vector<double> eh((size_t)n_cur);
+            if (hipMemcpy(eh.data(), LL.e, (size_t)n_cur * 8, hipMemcpyDeviceToHost) == hipSuccess)
+                for (double v : eh) s.energy_left += v;
+        }
+    } while (0);
+    sx.release();
+    dev_free(d_src);
+    if (stats) *stats = s;
+    if (st != TRC_OK) { trc_result_destroy(res); return st; }
+    *out = res;
+    return TRC_OK;
+}
+
+extern "C" int trc_result_num_levels(trc_result *res, int32_t *n_levels) {
+    if (!res || !n_levels) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    *n_levels = (int32_t)res->levels.size();
+    return TRC_OK;
+}
+
+extern "C" int trc_result_level_size(trc_result *res, int32_t level, int64_t *n_total, int64_t *n_live) {
+    if (!res || level < 0 || level >= (int)res->levels.size()) return trc_fail(TRC_ERR_INVALID, "level out of range");
+    if (n_total) *n_total = res->levels[level].n_total;
+    if (n_live) *n_live = res->levels[level].n_live;
+    return TRC_OK;
+}
+
+extern "C" int trc_result_level_get(trc_result *res, int32_t level, trc_rays *out, int32_t *surf) {
+    if (!res || level < 0 || level >= (int)res->levels.size() || !out) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    const Level &L = res->levels[level];
+    if (out->n < L.n_total) return trc_fail(TRC_ERR_CAPACITY, "output bundle holds %lld rays, level has %lld", (long long)out->n, (long long)L.n_total);
+    if (out->on_device) return trc_fail(TRC_ERR_INVALID, "host output expected");
+    HIP_TRY(hipSetDevice(res->ctx->device));
+    const size_t n = (size_t)L.n_total;
+    out->n = L.n_total;
+    if (n == 0) return TRC_OK;
+    struct { void *dst; const void *src; size_t w; } cp[] = {
+        {out->x, L.x, 8}, {out->y, L.y, 8}, {out->z, L.z, 8}, {out->dx, L.dx, 8}, {out->dy, L.dy, 8}, {out->dz, L.dz, 8},
+        {out->e, L.e, 8}, {out->parent, L.parent, 8}, {out->ref_index, L.ref, 8}, {out->wavelength, L.wl, 8},
+        {out->rid, L.rid, 8}, {surf, L.surf, 4}};
+    for (auto &c : cp)
+        if (c.dst) HIP_TRY(hipMemcpy(c.dst, c.src, n * c.w, hipMemcpyDeviceToHost));
+    return TRC_OK;
+}
+
+// ================================================================================================
+// C-ABI: per-surface protocol
+// ================================================================================================
+static int upload_record(const trc_surface_desc *surf, int32_t n_extra, const double *extra, double **d_rec, double **d_opt,
+                         double **d_extra) {
+    TRC_TRY(validate_surface(*surf, 0, n_extra));
+    int stride = TRC_REC_HDR + 16;
+    std::vector<double> rec(stride);
+    pack_record(*surf, rec.data(), stride);
+    TRC_TRY(dev_alloc(d_rec, (size_t)stride));
+    HIP_TRY(hipMemcpy(*d_rec, rec.data(), stride * sizeof(double), hipMemcpyHostToDevice));
+    if (d_opt) {
+        TRC_TRY(dev_alloc(d_opt, 8));
+        HIP_TRY(hipMemcpy(*d_opt, surf->opt, 8 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    TRC_TRY(dev_alloc(d_extra, (size_t)(n_extra > 0 ? n_extra : 1)));
+    if (n_extra > 0 && extra) HIP_TRY(hipMemcpy(*d_extra, extra, (size_t)n_extra * sizeof(double), hipMemcpyHostToDevice));
+    return TRC_OK;
+}
+
+extern "C" int trc_gm_find_intersections(trc_ctx *ctx, const trc_surface_desc *surf, int32_t n_extra, const double *extra,
+                                         const trc_rays *rays, double *t_out, double *hx, double *hy, double *hz) {
+    if (!ctx || !surf || !rays || !t_out) return trc_fail(TRC_ERR_INVALID, "trc_gm_find_intersections: bad arguments");
+    if (rays->on_device) return trc_fail(TRC_ERR_INVALID, "host bundle expected");
+    const int64_t n = rays->n;
+    TRC_TRY(check_rays(rays, n, "trc_gm_find_intersections"));
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) return TRC_OK;
+    double *d_rec = nullptr, *d_extra = nullptr, *d_t = nullptr, *d_h[3] = {nullptr, nullptr, nullptr};
+    DevRays dr;
+    int st = TRC_OK;
+    do {
+        if ((st = upload_record(surf, n_extra, extra, &d_rec, nullptr, &d_extra))) break;
+        if ((st = stage_rays(rays, n, false, &dr))) break;
+        if ((st = dev_alloc(&d_t, (size_t)n))) break;
+        const bool want_h = hx && hy && hz;
+        if (want_h) for (int i = 0; i < 3 && st == TRC_OK; ++i) st = dev_alloc(&d_h[i], (size_t)n);
+        if (st) break;
+        hipLaunchKernelGGL(k_gm_intersect, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_rec, d_extra,
+                           (long long)n, dr.x, dr.y, dr.z, dr.dx, dr.dy, dr.dz, d_t, d_h[0], d_h[1], d_h[2]);
+        hipError_t se = hipStreamSynchronize(ctx->stream);
+        if (se != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "k_gm_intersect failed: %s", hipGetErrorString(se)); break; }
+        if (hipMemcpy(t_out, d_t, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        if (want_h) {
+            double *dst[3] = {hx, hy, hz};
+            for (int i = 0; i < 3; ++i)
+                if (hipMemcpy(dst[i], d_h[i], (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        }
+    } while (0);
+    dr.release();
+    dev_free(d_rec); dev_free(d_extra); dev_free(d_t);
+    for (int i = 0; i < 3; ++i) dev_free(d_h[i]);
+    return st;
+}
+
+extern "C" int trc_gm_get_normals(trc_ctx *ctx, const trc_surface_desc *surf, int64_t n, const double *hx, const double *hy,
+                                  const double *hz, const double *dx, const double *dy, const double *dz, double *nx,
+                                  double *ny, double *nz) {
+    if (!ctx || !surf || n < 0) return trc_fail(TRC_ERR_INVALID, "trc_gm_get_normals: bad arguments");
+    if (n == 0) return TRC_OK;
+    if (!hx || !hy || !hz || !dx || !dy || !dz || !nx || !ny || !nz) return trc_fail(TRC_ERR_INVALID, "trc_gm_get_normals: NULL array");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double *d_rec = nullptr, *d_extra = nullptr, *d[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const double *src[6] = {hx, hy, hz, dx, dy, dz};
+    int st = TRC_OK;
+    do {
+        trc_surface_desc tmp = *surf;
+        tmp.optics_kind = TRC_OPT_TRANSPARENT;   // normals do not depend on the optics
+        if (tmp.gm_kind == TRC_GM_RECT_PERFORATED) { tmp.gm_kind = TRC_GM_RECT; }
+        if ((st = upload_record(&tmp, 0, nullptr, &d_rec, nullptr, &d_extra))) break;
+        for (int i = 0; i < 9 && st == TRC_OK; ++i) st = dev_alloc(&d[i], (size_t)n);
+        if (st) break;
+        for (int i = 0; i < 6; ++i)
+            if (hipMemcpy(d[i], src[i], (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        if (st) break;
+        hipLaunchKernelGGL(k_gm_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_rec, (long long)n, d[0],
+                           d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8]);
+        hipError_t se = hipStreamSynchronize(ctx->stream);
+        if (se != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "k_gm_normals failed: %s", hipGetErrorString(se)); break; }
+        double *dst[3] = {nx, ny, nz};
+        for (int i = 0; i < 3; ++i)
+            if (hipMemcpy(dst[i], d[6 + i], (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+    } while (0);
+    dev_free(d_rec); dev_free(d_extra);
+    for (int i = 0; i < 9; ++i) dev_free(d[i]);
+    return st;
+}
+
+extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int32_t n_extra, const double *extra,
+                                const trc_rays *in, const double *hx, const double *hy, const double *hz, const double *nx,
+                                const double *ny, const double *nz, uint64_t seed, int32_t bounce, trc_rays *out) {
+    if (!ctx || !surf || !in || !out) return trc_fail(TRC_ERR_INVALID, "trc_optics_apply: bad arguments");
+    if (in->on_device || out->on_device) return trc_fail(TRC_ERR_INVALID, "host bundles expected");
+    const int64_t n = in->n;
+    if (out->n < 2 * n) return trc_fail(TRC_ERR_CAPACITY, "output bundle must hold 2n rays");
+    if (n == 0) { out->n = 0; return TRC_OK; }
+    if (!in->dx || !in->dy || !in->dz || !in->e || !hx || !hy || !hz || !nx || !ny || !nz)
+        return trc_fail(TRC_ERR_INVALID, "trc_optics_apply: directions, energies, hit points and normals are required");
+    if (!out->x || !out->y || !out->z || !out->dx || !out->dy || !out->dz || !out->e || !out->parent)
+        return trc_fail(TRC_ERR_INVALID, "trc_optics_apply: output needs x..e and parent");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double *d_rec = nullptr, *d_opt = nullptr, *d_extra = nullptr;
+    double *d_in[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // dx dy dz e ref wl nx ny nz
+    uint64_t *d_rid = nullptr;
+    double *d_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int32_t *d_blk = nullptr;
+    int st = TRC_OK;
+    do {
+        if ((st = upload_record(surf, n_extra, extra, &d_rec, &d_opt, &d_extra))) break;
+        const double *src[9] = {in->dx, in->dy, in->dz, in->e, in->ref_index, in->wavelength, nx, ny, nz};
+        for (int i = 0; i < 9; ++i) {
+            if (!src[i]) continue;
+            if ((st = dev_alloc(&d_in[i], (size_t)n))) break;
+            if (hipMemcpy(d_in[i], src[i], (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        }
+        if (st) break;
+        if (in->rid) {
+            if ((st = dev_alloc(&d_rid, (size_t)n))) break;
+            if (hipMemcpy(d_rid, in->rid, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        }
+        for (int i = 0; i < 5 && st == TRC_OK; ++i) st = dev_alloc(&d_out[i], (size_t)(2 * n));
+        if (st == TRC_OK) st = dev_alloc(&d_blk, (size_t)(2 * n));
+        if (st) break;
+        OpticsParams P;
+        memset(&P, 0, sizeof(P));
+        P.rec = d_rec; P.opt = d_opt; P.extra = d_extra; P.n = n;
+        P.dx = d_in[0]; P.dy = d_in[1]; P.dz = d_in[2]; P.e = d_in[3]; P.ref = d_in[4]; P.wl = d_in[5];
+        P.rid = d_rid; P.ray_offset = 0;
+        P.nx = d_in[6]; P.ny = d_in[7]; P.nz = d_in[8];
+        P.seed = seed; P.event = bounce;
+        P.odx = d_out[0]; P.ody = d_out[1]; P.odz = d_out[2]; P.oe = d_out[3]; P.oref = d_out[4]; P.oblk = d_blk;
+        hipLaunchKernelGGL(k_optics_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, P);
+        hipError_t se = hipStreamSynchronize(ctx->stream);
+        if (se != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "k_optics_apply failed: %s", hipGetErrorString(se)); break; }
+        std::vector<double> h[5];
+        std::vector<int32_t> blk((size_t)(2 * n));
+        for (int i = 0; i < 5; ++i) {
+            h[i].resize((size_t)(2 * n));
+            if (hipMemcpy(h[i].data(), d_out[i], (size_t)(2 * n) * 8, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        }
+        if (st) break;
+        if (hipMemcpy(blk.data(), d_blk, (size_t)(2 * n) * 4, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        // reflected block first, then refracted block, each in selector order (optics_callables.py:852-857)
+        int64_t m = 0;
+        for (int b = 0; b < 2; ++b)
+            for (int64_t slot = 0; slot < 2 * n; ++slot) {
+                if (blk[(size_t)slot] != b) continue;
+                int64_t i = slot < n ? slot : slot - n;
+                out->x[m] = hx[i]; out->y[m] = hy[i]; out->z[m] = hz[i];
+                out->dx[m] = h[0][(size_t)slot]; out->dy[m] = h[1][(size_t)slot]; out->dz[m] = h[2][(size_t)slot];
+                out->e[m] = h[3][(size_t)slot];
+                if (out->ref_index) out->ref_index[m] = h[4][(size_t)slot];
+                if (out->wavelength) out->wavelength[m] = in->wavelength ? in->wavelength[i] : 0.0;
+                out->parent[m] = i;
+                ++m;
+            }
+        out->n = m;
+    } while (0);
+    dev_free(d_rec); dev_free(d_opt); dev_free(d_extra); dev_free(d_rid); dev_free(d_blk);
+    for (int i = 0; i < 9; ++i) dev_free(d_in[i]);
+    for (int i = 0; i < 5; ++i) dev_free(d_out[i]);
+    return st;
+}
