@@ -226,6 +226,8 @@ int trc_scene_set_fluxmap(trc_scene *scene, int32_t surf, int32_t nu, int32_t nv
 /* capacity (in hits) of the hit buffer that backs the Location/Direction/
    Absorption accountants (optics_callables.py:1597-1771) in the fast engine */
 int trc_scene_set_hit_capacity(trc_scene *scene, int64_t capacity);
+/* empty the hit buffer (the accountants' per-trace lists live on the Python side) */
+int trc_scene_clear_hits(trc_scene *scene);
 /* Assembly.reset_all_optics() (assembly.py:148-151) */
 int trc_scene_reset_tallies(trc_scene *scene);
 /* per-surface totals: absorbed = sum(E_in - sum E_out) (AbsorptionAccountant :1638-1643),

@@ -1,0 +1,173 @@
+"""
+Kd-tree over the global AABBs of the objects' BoundaryBoxes.
+
+build: host side, once per scene.  It follows the reference's builder rule for rule
+(tracer/accel_tree.py:42-204) so that the node array is identical to the reference's for the same
+scene: breadth-first numbering, leaf when count <= min_leaf or level >= max_depth, split on the
+longest axis that has any candidate plane, surface-area cost with t_trav/t_isec/empty_bonus, `fast`
+limiting the candidates to 12 planes, and the candidate planes taken from
+`bounds[:, tile(in_node, 2)]` exactly as written there (:109).
+
+traversal: on the device, inside the trace kernels (csrc/trc_core.h, trc_nearest_kd).  `flat()`
+produces the arrays for trc_scene_set_kdtree.
+"""
+import logging
+import time
+
+import numpy as N
+
+from .object import AssembledObject
+from .vector_manipulations import AABB
+
+
+class Node(object):
+    """flag 0/1/2: interior split on that axis (split, child); flag 3: leaf (surfaces_idxs)."""
+    pass
+
+
+class KdTree(object):
+    def __init__(self, assembly, max_depth=N.inf, min_leaf=1, loglevel=logging.DEBUG, debug=False, fast=False,
+                 t_trav=1., t_isec=1000., empty_bonus=0.2, split_threshold=None):
+        self.loglevel = loglevel
+        self.nodes = []
+        self.t_trav = t_trav
+        self.t_isec = t_isec
+        self.empty_bonus = empty_bonus
+        self.split_threshold = split_threshold
+        self.fast = fast
+        self.min_leaf = min_leaf
+        self.max_depth = max_depth
+        self.objects = [assembly] if isinstance(assembly, AssembledObject) else assembly.get_objects()
+        self.n_surfs = len(assembly.get_surfaces())
+        self.debug = False
+        self.build_tree()
+
+    # ------------------------------------------------------------------------------------------
+    def build_tree(self):
+        logging.log(self.loglevel, 'Building tree')
+        t0 = time.time()
+        per_obj_bounds = [o.get_boundaries() for o in self.objects]
+        n_bounds_obj = N.array([len(b) for b in per_obj_bounds])
+        if (n_bounds_obj == 0).all():
+            raise Exception('No boundary defined in the assembly, please revert to non-accelerated ray-tracing')
+        total = int(N.sum(n_bounds_obj))
+
+        # surface indices of each object, in assembly order
+        n_surf_obj = [len(o.get_surfaces()) for o in self.objects]
+        first = N.concatenate(([0], N.cumsum(n_surf_obj)))
+        obj_surfs = [N.arange(first[i], first[i + 1]) for i in range(len(self.objects))]
+
+        minpoints = N.empty((3, total))
+        maxpoints = N.empty((3, total))
+        bounds = N.empty((3, 2 * total))
+        surfs_of_bound = []
+        always = []
+        k = 0
+        for oi, bnds in enumerate(per_obj_bounds):
+            if len(bnds) == 0:
+                always.append(obj_surfs[oi])
+                continue
+            for b in bnds:
+                minpoints[:, k] = b._minpoint
+                maxpoints[:, k] = b._maxpoint
+                bounds[:, 2 * k] = b._minpoint
+                bounds[:, 2 * k + 1] = b._maxpoint
+                surfs_of_bound.append(obj_surfs[oi])
+                k += 1
+        self.always_relevant = N.hstack(always).astype(int) if always else N.array([], dtype=int)
+        self.minpoint, self.maxpoint = AABB(bounds)
+
+        n_cand = 12 if self.fast == True else None
+        # breadth-first construction; boxes[i], levels[i] describe node i
+        boxes = [(self.minpoint[:, None], self.maxpoint[:, None])]
+        levels = [0]
+        self.nodes = [Node()]
+        idx = 0
+        level = 0
+        while idx < len(self.nodes):
+            lo, hi = boxes[idx]
+            level = levels[idx]
+            inside = N.logical_and((maxpoints >= lo).all(axis=0), (minpoints <= hi).all(axis=0))
+            count = N.count_nonzero(inside)
+            node = self.nodes[idx]
+            split = None
+            if not (count <= self.min_leaf or level >= self.max_depth):
+                split = self.determine_split(lo, hi, minpoints[:, inside], maxpoints[:, inside],
+                                             bounds[:, N.tile(inside, 2)], n_bounds=n_cand, t_trav=self.t_trav,
+                                             t_isec=self.t_isec, empty_bonus=self.empty_bonus)
+                if split[0] == 3:
+                    split = None
+            if split is None:
+                node.flag = 3
+                node.surfaces_idxs = [surfs_of_bound[i] for i in N.nonzero(inside)[0]]
+            else:
+                axis, pos = split
+                node.flag = int(axis)
+                node.split = pos
+                node.child = len(self.nodes)
+                hi_below = N.copy(hi)
+                hi_below[axis] = pos
+                lo_above = N.copy(lo)
+                lo_above[axis] = pos
+                boxes += [(lo, hi_below), (lo_above, hi)]
+                levels += [level + 1, level + 1]
+                self.nodes += [Node(), Node()]
+            idx += 1
+        self.build_time = time.time() - t0
+        logging.log(self.loglevel, 'build_time: %ss' % self.build_time)
+        logging.log(self.loglevel, 'maximum level%s' % level)
+        logging.log(self.loglevel, 'Kd-Tree built')
+
+    def determine_split(self, minpoint_parent, maxpoint_parent, minpoints, maxpoints, bounds, n_bounds=None,
+                        t_trav=1., t_isec=1000., empty_bonus=0.2):
+        """(axis, position) of the best plane on the longest axis that has candidates, or (3, Ns)."""
+        Ns = minpoints.shape[1]
+        diag = (maxpoint_parent - minpoint_parent).reshape(3)
+        lo = N.reshape(minpoint_parent, 3)
+        hi = N.reshape(maxpoint_parent, 3)
+        S_inv = 1. / (diag[0] * diag[1] + diag[1] * diag[2] + diag[2] * diag[0])
+        basecost = t_trav + Ns * t_isec
+        for a in N.argsort(diag)[::-1]:
+            cand = bounds[a]
+            cand = cand[N.logical_and(cand > lo[a], cand < hi[a])]
+            if len(cand) == 0:
+                continue
+            cand = N.unique(cand)
+            d0, d1 = diag[(a + 1) % 3], diag[(a + 2) % 3]
+            d0td1 = d0 * d1
+            d0pd1 = d0 + d1
+            if n_bounds is not None and n_bounds < len(cand):
+                cand = cand[N.round(N.linspace(0, len(cand) - 1, n_bounds)).astype(int)]
+            N_A = N.count_nonzero(maxpoints[a][None, :] >= cand[:, None], axis=1)
+            N_B = N.count_nonzero(minpoints[a][None, :] <= cand[:, None], axis=1)
+            p_A = S_inv * (d0td1 + (hi[a] - cand) * d0pd1)
+            p_B = S_inv * (d0td1 + (cand - lo[a]) * d0pd1)
+            b_e = N.logical_or(N_A == 0, N_B == 0) * empty_bonus
+            cost = basecost + t_isec * (1. - b_e) * (p_A * N_A + p_B * N_B)
+            return int(a), cand[int(N.argmin(cost))]
+        return 3, Ns
+
+    # ------------------------------------------------------------------------------------------
+    def flat(self):
+        """Arrays for trc_kdtree_desc."""
+        n = len(self.nodes)
+        flag = N.empty(n, dtype=N.int32)
+        split = N.zeros(n)
+        child = N.zeros(n, dtype=N.int32)
+        leaf_off = N.zeros(n, dtype=N.int32)
+        leaf_cnt = N.zeros(n, dtype=N.int32)
+        leaf_surfs = []
+        for i, nd in enumerate(self.nodes):
+            flag[i] = nd.flag
+            if nd.flag == 3:
+                s = N.unique(N.concatenate([N.ravel(x) for x in nd.surfaces_idxs])) if len(nd.surfaces_idxs) else []
+                leaf_off[i] = len(leaf_surfs)
+                leaf_cnt[i] = len(s)
+                leaf_surfs.extend(int(v) for v in s)
+            else:
+                split[i] = nd.split
+                child[i] = nd.child
+        return dict(flag=flag, split=split, child=child, leaf_off=leaf_off, leaf_cnt=leaf_cnt,
+                    leaf_surfs=N.array(leaf_surfs, dtype=N.int32),
+                    always_relevant=N.array(self.always_relevant, dtype=N.int32),
+                    bounds=N.concatenate((N.ravel(self.minpoint), N.ravel(self.maxpoint))).astype(float))

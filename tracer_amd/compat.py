@@ -1,0 +1,35 @@
+"""
+Drop-in aliasing: after `tracer_amd.compat.install()`, `import tracer.surface`, `from
+tracer.models.heliostat_field import HeliostatField`, ... resolve to the tracer_amd modules of the
+same name, so scene scripts written against casselineau/Tracer run unchanged on the GPU engine.
+"""
+import importlib
+import sys
+import types
+
+_MODULES = ['assembly', 'object', 'surface', 'has_frame', 'geometry_manager', 'flat_surface', 'triangular_face',
+            'quadric', 'paraboloid', 'sphere_surface', 'cylinder', 'cone', 'quadratic_surface', 'ellipsoid',
+            'optics', 'optics_callables', 'ray_bundle', 'trace_tree', 'tracer_engine', 'sources',
+            'spatial_geometry', 'boundary_shape', 'accel_tree', 'models', 'models.one_sided_mirror',
+            'models.heliostat_field']
+
+
+def install(force=False):
+    if 'tracer' in sys.modules and not force and not getattr(sys.modules['tracer'], '_tracer_amd_alias', False):
+        raise RuntimeError("a different `tracer` package is already imported")
+    root = importlib.import_module('tracer_amd')
+    alias = types.ModuleType('tracer')
+    alias.__path__ = []
+    alias._tracer_amd_alias = True
+    sys.modules['tracer'] = alias
+    for name in _MODULES:
+        mod = importlib.import_module('tracer_amd.' + name)
+        sys.modules['tracer.' + name] = mod
+        parent = alias if '.' not in name else sys.modules['tracer.' + name.rsplit('.', 1)[0]]
+        setattr(parent, name.rsplit('.', 1)[-1], mod)
+    rtu = types.ModuleType('ray_trace_utils')
+    rtu.__path__ = []
+    rtu.vector_manipulations = importlib.import_module('tracer_amd.vector_manipulations')
+    sys.modules.setdefault('ray_trace_utils', rtu)
+    sys.modules.setdefault('ray_trace_utils.vector_manipulations', rtu.vector_manipulations)
+    return root

@@ -982,6 +982,14 @@ extern "C" int trc_scene_set_hit_capacity(trc_scene *sc, int64_t capacity) {
     return TRC_OK;
 }
 
+extern "C" int trc_scene_clear_hits(trc_scene *sc) {
+    if (!sc) return trc_fail(TRC_ERR_INVALID, "scene is NULL");
+    HIP_TRY(hipSetDevice(sc->ctx->device));
+    HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+    HIP_TRY(hipMemset(sc->d_counters, 0, 2 * sizeof(unsigned long long)));
+    return TRC_OK;
+}
+
 extern "C" int trc_scene_reset_tallies(trc_scene *sc) {
     if (!sc) return trc_fail(TRC_ERR_INVALID, "scene is NULL");
     HIP_TRY(hipSetDevice(sc->ctx->device));

@@ -1,0 +1,405 @@
+"""
+Optics managers: callables `optics(geometry, rays, selector) -> RayBundle` plus accountants.
+
+Class names, constructor arguments and result conventions follow the reference's
+tracer/optics_callables.py (citations per class).  A native optics class only holds parameters:
+`_native()` gives its row in the device table (optics kind + up to 8 parameters + optional table),
+and `__call__` runs that kind's device code on the selected hits through trc_optics_apply, so the
+per-surface protocol and the fused engines share one implementation (csrc/trc_core.h, trc_shade).
+
+Accountant-wrapped classes (`ReflectiveReceiver`, `OneSidedRealReflectiveDetector`,
+`LambertianAbsorberLocationDirectional`, ...) are not generated eagerly like the reference does
+(~20.7k classes at import, optics_callables.py:2043-2092) but synthesised on first attribute access
+from the same naming algorithm (module __getattr__), giving the same name -> accountant-list map.
+"""
+import ctypes as C
+from itertools import combinations
+from copy import deepcopy
+
+import numpy as N
+
+from . import _cabi, rng
+from .geometry_manager import fill_desc
+from .ray_bundle import RayBundle
+
+
+def copy_optical_manager(opt):
+    """An optics instance must not be shared by two surfaces (optics_callables.py:82-91)."""
+    newopt = deepcopy(opt)
+    if hasattr(newopt, 'reset'):
+        newopt.reset()
+    return newopt
+
+
+# --------------------------------------------------------------------------------------------------
+# native optics
+# --------------------------------------------------------------------------------------------------
+class NativeOptics(object):
+    """Base of the optics whose behaviour is implemented on the device."""
+    _splits = False      # may emit two rays per hit
+
+    def _native(self):
+        """(optics_kind, params, extra)"""
+        raise NotImplementedError
+
+    def __call__(self, geometry, rays, selector):
+        selector = N.asarray(selector)
+        if len(selector) == 0:
+            return RayBundle.empty_bund()
+        ctx = _cabi.get_context()
+        kind, params, extra = self._native()
+        extra = _cabi.f64(extra)
+        desc = _cabi.SurfaceDesc()
+        fill_desc(desc, geometry._working_frame, _cabi.GM_FLAT_INF, [], kind, params,
+                  extra_off=0 if len(extra) else -1, extra_len=len(extra))
+        n = len(selector)
+        d = _cabi.f64(rays.get_directions(selector))
+        e = _cabi.f64(rays.get_energy(selector))
+        ri = _cabi.f64(rays.get_ref_index(selector)) if rays._has_column('ref_index') else None
+        wl = _cabi.f64(rays.get_wavelengths(selector)) if rays._has_column('wavelengths') else None
+        nrm = _cabi.f64(geometry.get_normals())
+        hit = _cabi.f64(geometry.get_intersection_points_global())
+        rid = N.arange(n, dtype=N.uint64)
+        rin = _cabi.make_rays(n, dx=d[0], dy=d[1], dz=d[2], e=e, ref_index=ri, wavelength=wl, rid=rid)
+        m = 2 * n
+        o = dict((k, N.empty(m)) for k in ('x', 'y', 'z', 'dx', 'dy', 'dz', 'e', 'ref', 'wl'))
+        par = N.empty(m, dtype=N.int64)
+        rout = _cabi.make_rays(m, o['x'], o['y'], o['z'], o['dx'], o['dy'], o['dz'], o['e'], parent=par,
+                               ref_index=o['ref'], wavelength=o['wl'])
+        _cabi.check(ctx.lib.trc_optics_apply(
+            ctx.handle, C.byref(desc), len(extra), _cabi.ptr(extra) if len(extra) else None, C.byref(rin),
+            _cabi.ptr(hit[0]), _cabi.ptr(hit[1]), _cabi.ptr(hit[2]), _cabi.ptr(nrm[0]), _cabi.ptr(nrm[1]),
+            _cabi.ptr(nrm[2]), rng.next_seed(), 1, C.byref(rout)))
+        k = rout.n
+        par = par[:k]
+        src = selector[par]
+        kw = {}
+        if ri is not None:
+            kw['ref_index'] = o['ref'][:k].copy()
+        return rays.inherit(src, vertices=N.vstack((o['x'][:k], o['y'][:k], o['z'][:k])),
+                            direction=N.vstack((o['dx'][:k], o['dy'][:k], o['dz'][:k])),
+                            energy=o['e'][:k].copy(), parents=src, **kw)
+
+
+class Transparent(NativeOptics):
+    """Rays go through unchanged (optics_callables.py:93-113)."""
+    def __init__(self):
+        pass
+
+    def _native(self):
+        return _cabi.OPT_TRANSPARENT, [], []
+
+
+class Reflective(NativeOptics):
+    """Specular mirror absorbing a fixed fraction (optics_callables.py:116-140)."""
+    def __init__(self, absorptivity):
+        self._abs = absorptivity
+
+    def _native(self):
+        return _cabi.OPT_REFLECTIVE, [self._abs], []
+
+
+perfect_mirror = Reflective(0)
+
+
+class OneSidedReflective(Reflective):
+    """Mirror whose back side (rays travelling along the surface's +z) absorbs everything (:195-212)."""
+    def _native(self):
+        return _cabi.OPT_ONE_SIDED_REFLECTIVE, [self._abs], []
+
+
+class RealReflective(NativeOptics):
+    """Mirror with Gaussian slope error, bi-variate or radial (optics_callables.py:214-269)."""
+    def __init__(self, absorptivity, sigma, bi_var=False):
+        self._abs = absorptivity
+        self._sig = sigma
+        self.bi_var = bi_var
+
+    def _native(self):
+        return _cabi.OPT_REAL_REFLECTIVE, [self._abs, self._sig, 1. if self.bi_var == True else 0.], []
+
+
+class OneSidedRealReflective(RealReflective):
+    """One-sided version of RealReflective (optics_callables.py:492-504)."""
+    def _native(self):
+        return _cabi.OPT_ONE_SIDED_REAL_REFLECTIVE, [self._abs, self._sig, 1. if self.bi_var == True else 0.], []
+
+
+class Lambertian(NativeOptics):
+    """Diffuse reflector, cosine-weighted within ang_range of the normal (optics_callables.py:143-176)."""
+    def __init__(self, absorptivity=0., ang_range=N.pi / 2.):
+        self._abs = absorptivity
+        self._ang_range = ang_range
+
+    def _native(self):
+        return _cabi.OPT_LAMBERTIAN, [self._abs, self._ang_range], []
+
+
+class LambertianSpecular(NativeOptics):
+    """Each ray is specular with probability `specularity`, else Lambertian (optics_callables.py:553-585)."""
+    def __init__(self, absorptivity=0., specularity=0.5):
+        self._abs = absorptivity
+        self.specularity = specularity
+
+    def _native(self):
+        return _cabi.OPT_LAMBERTIAN_SPECULAR, [self._abs, self.specularity], []
+
+
+class Reflective_spectral(NativeOptics):
+    """Mirror whose absorptance is interpolated on the ray wavelength (optics_callables.py:178-193)."""
+    def __init__(self, absorptances, wavelengths):
+        self._wavelengths = wavelengths
+        self._absorptances = absorptances
+
+    def _native(self):
+        lam = N.ravel(N.asarray(self._wavelengths, dtype=float))
+        ab = N.ravel(N.asarray(self._absorptances, dtype=float))
+        return _cabi.OPT_REFLECTIVE_SPECTRAL, [], N.concatenate((lam, ab)).tolist()
+
+
+class RefractiveHomogenous(NativeOptics):
+    """
+    Interface between two homogeneous media of real indices n1, n2 (optics_callables.py:1186-1296):
+    Snell + unpolarised Fresnel; single_ray=True picks reflection or refraction per ray, False emits
+    both (reflected block first); sigma perturbs the normal.
+    """
+    def __init__(self, n1, n2, single_ray=True, sigma=None):
+        self._ref_idxs = (n1, n2)
+        self._single_ray = single_ray
+        self._sigma = sigma
+
+    @property
+    def _splits(self):
+        return not self._single_ray
+
+    def toggle_ref_idx(self, current, wavelengths=None):
+        return N.where(current == self._ref_idxs[0], self._ref_idxs[1], self._ref_idxs[0])
+
+    def _native(self):
+        return _cabi.OPT_REFRACTIVE_HOMOGENOUS, [self._ref_idxs[0], self._ref_idxs[1],
+                                                 1. if self._single_ray else 0.,
+                                                 -1. if self._sigma is None else self._sigma], []
+
+
+# --------------------------------------------------------------------------------------------------
+# accountants (optics_callables.py:1577-1848)
+# --------------------------------------------------------------------------------------------------
+class Accountant(object):
+    shorthand = None
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self._data = []
+
+    def count(self, geometry, rays, selector, new_bundle):
+        raise NotImplementedError
+
+    def feed(self, hit):
+        """Fused engines: `hit` is a dict with e_in, e_out, points(3,H), directions(3,H), normals()."""
+        raise NotImplementedError
+
+    def _empty(self):
+        return N.array([])
+
+    def get_data(self):
+        chunks = [c for c in self._data if c.shape[-1]]
+        if not chunks:
+            return self._empty()
+        return N.hstack(chunks)
+
+
+class _Vector3Accountant(Accountant):
+    def _empty(self):
+        return N.array([]).reshape(3, 0)
+
+
+class LocationAccountant(_Vector3Accountant):
+    """Hit points in global coordinates."""
+    shorthand = 'Location'
+
+    def count(self, geometry, rays, selector, new_bundle):
+        self._data.append(N.asarray(geometry.get_intersection_points_global()))
+
+    def feed(self, hit):
+        self._data.append(hit['points'])
+
+
+class AbsorptionAccountant(Accountant):
+    """Energy absorbed by each hit: E_in - E_out."""
+    shorthand = 'Absorber'
+
+    def count(self, geometry, rays, selector, new_bundle):
+        self._data.append(rays.get_energy(selector) - new_bundle.get_energy())
+
+    def feed(self, hit):
+        self._data.append(hit['e_in'] - hit['e_out'])
+
+
+class AttenuationAccountant(Accountant):
+    shorthand = 'Attenuator'
+
+    def count(self, geometry, rays, selector, new_bundle, attenuations):
+        self._data.append(attenuations)
+
+    def feed(self, hit):
+        pass
+
+
+class ReceptionAccountant(Accountant):
+    """Incident energy of each hit."""
+    shorthand = 'Receptor'
+
+    def count(self, geometry, rays, selector, new_bundle):
+        self._data.append(rays.get_energy(selector))
+
+    def feed(self, hit):
+        self._data.append(hit['e_in'])
+
+
+class ScatteringAccountant(Accountant):
+    """Outgoing energy of each hit."""
+    shorthand = 'Scatterer'
+
+    def count(self, geometry, rays, selector, new_bundle):
+        self._data.append(new_bundle.get_energy())
+
+    def feed(self, hit):
+        self._data.append(hit['e_out'])
+
+
+class DirectionAccountant(_Vector3Accountant):
+    """Incident direction of each hit."""
+    shorthand = 'Directional'
+
+    def count(self, geometry, rays, selector, new_bundle):
+        self._data.append(rays.get_directions(selector))
+
+    def feed(self, hit):
+        self._data.append(hit['directions'])
+
+
+class NormalAccountant(_Vector3Accountant):
+    """Surface normal at each hit."""
+    shorthand = 'Normal'
+
+    def count(self, geometry, rays, selector, new_bundle):
+        self._data.append(geometry.get_normals())
+
+    def feed(self, hit):
+        self._data.append(hit['normals']())
+
+
+class SpectralAccountant(Accountant):
+    shorthand = 'Spectral'
+
+    def count(self, geometry, rays, selector, new_bundle):
+        self._data.append(rays.get_wavelengths()[selector])
+
+    def feed(self, hit):
+        self._data.append(hit['wavelengths'])
+
+
+class PolychromaticAccountant(Accountant):
+    shorthand = 'Polychromatic'
+
+    def count(self, geometry, rays, selector, new_bundle):
+        raise NotImplementedError("polychromatic bundles are outside the native path")
+
+    def feed(self, hit):
+        raise NotImplementedError("polychromatic bundles are outside the native path")
+
+
+# canonical accountant order: energy -> spectral -> location -> directions (optics_callables.py:2060-2071)
+_ACCOUNTANT_ORDER = [AbsorptionAccountant, AttenuationAccountant, ReceptionAccountant, ScatteringAccountant,
+                     PolychromaticAccountant, SpectralAccountant, LocationAccountant, DirectionAccountant,
+                     NormalAccountant]
+aliases = {'Receiver': ['Location', 'Absorber'], 'Detector': ['Directional', 'Location', 'Absorber'],
+           'Transmitter': ['Location', 'Scatterer']}
+
+
+def _accountant_suffix_table():
+    """
+    suffix -> tuple of accountant classes, produced by running the reference's naming loop
+    (optics_callables.py:2043-2054, :2075-2083) once on an empty class name: combination names in
+    canonical order, then the alias names, where the working name is rewritten cumulatively from one
+    alias to the next exactly as the reference does.
+    """
+    table = {}
+    for size in range(1, len(_ACCOUNTANT_ORDER)):
+        for accs in combinations(_ACCOUNTANT_ORDER, size):
+            if SpectralAccountant in accs and PolychromaticAccountant in accs:
+                continue
+            name = ''.join(a.shorthand for a in accs)
+            table[name] = accs
+            work = name
+            for alias, parts in aliases.items():
+                if all(p in name for p in parts):
+                    for p in parts:
+                        work = work.replace(p, '')
+                    table[work + alias] = accs
+    return table
+
+
+_SUFFIXES = None
+
+
+class OpticsCallable(object):
+    """An optics instance wrapped with accountants (optics_callables.py:1562-1575, :1942-1971)."""
+    optics_class = None
+    accountant_classes = ()
+
+    def __init__(self, *args, **kwargs):
+        self._opt = self.optics_class(*args, **kwargs)
+        self.accountants = [a() for a in self.accountant_classes]
+
+    def __call__(self, geometry, rays, selector):
+        new_bundle = self._opt(geometry, rays, selector)
+        for a in self.accountants:
+            a.count(geometry=geometry, rays=rays, selector=selector, new_bundle=new_bundle)
+        return new_bundle
+
+    def reset(self):
+        for a in self.accountants:
+            a.reset()
+
+    def get_all_hits(self):
+        return [a.get_data() for a in self.accountants]
+
+    def _native(self):
+        return self._opt._native()
+
+    @property
+    def _splits(self):
+        return getattr(self._opt, '_splits', False)
+
+
+def _optics_classes():
+    g = globals()
+    return dict((k, v) for k, v in g.items()
+                if isinstance(v, type) and issubclass(v, NativeOptics) and v is not NativeOptics)
+
+
+def __getattr__(name):
+    """Synthesise `<OpticsClass><AccountantSuffix>` classes on demand."""
+    global _SUFFIXES
+    if name.startswith('__'):
+        raise AttributeError(name)
+    if _SUFFIXES is None:
+        _SUFFIXES = _accountant_suffix_table()
+    classes = _optics_classes()
+    for cname in sorted(classes, key=len, reverse=True):
+        if name.startswith(cname) and name[len(cname):] in _SUFFIXES:
+            accs = _SUFFIXES[name[len(cname):]]
+            cls = type(name, (OpticsCallable,), {'optics_class': classes[cname], 'accountant_classes': accs})
+            globals()[name] = cls
+            return cls
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
+
+
+def native_optics_of(opt):
+    """The NativeOptics instance behind an optics object (itself or inside an accountant wrapper)."""
+    if isinstance(opt, OpticsCallable):
+        opt = opt._opt
+    return opt if isinstance(opt, NativeOptics) else None

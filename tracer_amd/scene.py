@@ -1,0 +1,332 @@
+"""
+Scene compiler and device-scene handle.
+
+compile_scene() flattens Assembly.get_surfaces() (reference ordering contract assembly.py:60-77)
+into the trc_surface_desc table of include/tracer_amd.h: one row per Surface with its global frame
+(Surface._temp_frame), its geometry kind/parameters and its optics kind/parameters.  DeviceScene
+owns the trc_scene handle and wraps the tally / flux-map / hit-buffer calls.
+
+A surface whose geometry manager or optics callable is not in the native table makes
+compile_scene raise NotNativeError; TracerEngine then drives such scenes through the per-surface
+protocol (engine='protocol'), in which native kinds still run on the GPU.
+"""
+import ctypes as C
+
+import numpy as N
+
+from . import _cabi
+from .geometry_manager import NativeGeometryManager, fill_desc
+from .optics_callables import OpticsCallable, native_optics_of, LocationAccountant, DirectionAccountant, \
+    AbsorptionAccountant, ReceptionAccountant, ScatteringAccountant, NormalAccountant
+
+
+class NotNativeError(NotImplementedError):
+    """The scene holds a geometry/optics plug-in that only exists in Python."""
+
+
+class CompiledScene(object):
+    def __init__(self, surfaces):
+        self.surfaces = list(surfaces)
+        n = len(self.surfaces)
+        if n == 0:
+            raise ValueError("the assembly has no surfaces")
+        self.descs = (_cabi.SurfaceDesc * n)()
+        extra = []
+        self.splits = False
+        self.capture = []
+        for i, s in enumerate(self.surfaces):
+            gm = s.get_geometry_manager()
+            opt = s.get_optics_manager()
+            nat = native_optics_of(opt)
+            if not isinstance(gm, NativeGeometryManager):
+                raise NotNativeError("surface %d: geometry manager %s is not in the native table" % (i, type(gm).__name__))
+            if nat is None:
+                raise NotNativeError("surface %d: optics %s is not in the native table" % (i, type(opt).__name__))
+            gkind, gpar, gextra = gm._native()
+            okind, opar, oextra = nat._native()
+            if len(gextra) and len(oextra):
+                raise NotNativeError("surface %d: both geometry and optics carry tables" % i)
+            ex = list(gextra) if len(gextra) else list(oextra)
+            off = len(extra) if len(ex) else -1
+            extra.extend(ex)
+            wants_hits = isinstance(opt, OpticsCallable) and len(opt.accountants) > 0
+            self.capture.append(wants_hits)
+            fill_desc(self.descs[i], s._temp_frame, gkind, gpar, okind, opar,
+                      flags=_cabi.SURF_CAPTURE_HITS if wants_hits else 0, extra_off=off, extra_len=len(ex))
+            if getattr(nat, '_splits', False):
+                self.splits = True
+        self.extra = _cabi.f64(extra)
+        self.n_surf = n
+
+    def signature(self):
+        """Bytes that identify everything uploaded to the device."""
+        return bytes(self.descs) + self.extra.tobytes()
+
+    def frames12(self):
+        fr = N.empty((self.n_surf, 12))
+        for i, s in enumerate(self.surfaces):
+            fr[i] = N.asarray(s._temp_frame, dtype=float)[:3].ravel()
+        return fr
+
+
+def compile_scene(assembly_or_surfaces):
+    surfaces = assembly_or_surfaces.get_surfaces() if hasattr(assembly_or_surfaces, 'get_surfaces') \
+        else assembly_or_surfaces
+    return CompiledScene(surfaces)
+
+
+class DeviceScene(object):
+    """trc_scene handle."""
+    def __init__(self, compiled, ctx=None):
+        self.ctx = ctx or _cabi.get_context()
+        self.lib = self.ctx.lib
+        self.compiled = compiled
+        h = C.c_void_p()
+        _cabi.check(self.lib.trc_scene_create(self.ctx.handle, compiled.n_surf, compiled.descs, len(compiled.extra),
+                                              _cabi.ptr(compiled.extra) if len(compiled.extra) else None, C.byref(h)))
+        self.handle = h
+        self.n_surf = compiled.n_surf
+        self.fluxmaps = {}
+        self.hit_capacity = 0
+        self._kd_keep = None
+
+    def close(self):
+        if self.handle is not None and self.handle.value:
+            self.lib.trc_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- acceleration ---------------------------------------------------------------------------
+    def set_kdtree(self, tree):
+        """tree: accel_tree.KdTree or None."""
+        if tree is None:
+            _cabi.check(self.lib.trc_scene_set_kdtree(self.handle, None))
+            self._kd_keep = None
+            return
+        f = tree.flat()
+        d = _cabi.KdTreeDesc()
+        d.n_nodes = len(f['flag'])
+        d.n_leaf_surfs = len(f['leaf_surfs'])
+        d.n_always = len(f['always_relevant'])
+        i32 = C.POINTER(C.c_int32)
+        d.flag = f['flag'].ctypes.data_as(i32)
+        d.split = _cabi.ptr(f['split'])
+        d.child = f['child'].ctypes.data_as(i32)
+        d.leaf_off = f['leaf_off'].ctypes.data_as(i32)
+        d.leaf_cnt = f['leaf_cnt'].ctypes.data_as(i32)
+        d.leaf_surfs = f['leaf_surfs'].ctypes.data_as(i32)
+        d.always_relevant = f['always_relevant'].ctypes.data_as(i32)
+        for i in range(6):
+            d.bounds[i] = f['bounds'][i]
+        self._kd_keep = f
+        _cabi.check(self.lib.trc_scene_set_kdtree(self.handle, C.byref(d)))
+
+    # -- tallies ----------------------------------------------------------------------------------
+    def set_fluxmap(self, surf_index, u_edges, v_edges, proj=None):
+        """
+        Accumulate absorbed energy of surface `surf_index` on the grid u_edges x v_edges of its local
+        x, y.  proj defaults to round(inv(frame), 9) (Surface.global_to_local, surface.py:125).
+        """
+        u = _cabi.f64(u_edges)
+        v = _cabi.f64(v_edges)
+        if proj is None:
+            proj = N.round(N.linalg.inv(self.compiled.surfaces[surf_index]._temp_frame), decimals=9)
+        p = _cabi.f64(N.asarray(proj)[:3].ravel())
+        _cabi.check(self.lib.trc_scene_set_fluxmap(self.handle, surf_index, len(u) - 1, len(v) - 1, _cabi.ptr(u),
+                                                   _cabi.ptr(v), _cabi.ptr(p)))
+        self.fluxmaps[surf_index] = (len(u) - 1, len(v) - 1)
+
+    def get_fluxmap(self, surf_index):
+        nu, nv = self.fluxmaps[surf_index]
+        out = N.empty((nu, nv))
+        _cabi.check(self.lib.trc_scene_get_fluxmap(self.handle, surf_index, _cabi.ptr(out)))
+        return out
+
+    def set_hit_capacity(self, capacity):
+        capacity = int(capacity)
+        if capacity != self.hit_capacity:
+            _cabi.check(self.lib.trc_scene_set_hit_capacity(self.handle, capacity))
+            self.hit_capacity = capacity
+
+    def reset_tallies(self):
+        _cabi.check(self.lib.trc_scene_reset_tallies(self.handle))
+
+    def get_tallies(self):
+        a = N.empty(self.n_surf)
+        r = N.empty(self.n_surf)
+        h = N.empty(self.n_surf, dtype=N.int64)
+        _cabi.check(self.lib.trc_scene_get_tallies(self.handle, _cabi.ptr(a), _cabi.ptr(r),
+                                                   h.ctypes.data_as(C.POINTER(C.c_int64))))
+        return a, r, h
+
+    def get_hits(self):
+        """dict of the captured hits, device arrival order."""
+        n = C.c_int64(0)
+        nul = C.POINTER(C.c_double)()
+        _cabi.check(self.lib.trc_scene_get_hits(self.handle, C.byref(n), None, nul, nul, nul, nul, nul, nul, nul, nul))
+        k = n.value
+        surf = N.empty(k, dtype=N.int32)
+        cols = [N.empty(k) for _ in range(8)]
+        if k:
+            _cabi.check(self.lib.trc_scene_get_hits(self.handle, C.byref(n), surf.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                    *[_cabi.ptr(c) for c in cols]))
+        return dict(surf=surf, e_abs=cols[0], e_in=cols[1], points=N.vstack(cols[2:5]), directions=N.vstack(cols[5:8]))
+
+    def tally_size(self):
+        n = C.c_int64(0)
+        _cabi.check(self.lib.trc_scene_tally_size(self.handle, C.byref(n)))
+        return n.value
+
+    def export_tallies(self, out=None):
+        """Packed tally buffer as a host array, or into a device pointer (int) when `out` is given."""
+        if out is None:
+            buf = N.empty(self.tally_size())
+            _cabi.check(self.lib.trc_scene_export_tallies(self.handle, buf.ctypes.data_as(C.c_void_p), 0))
+            return buf
+        _cabi.check(self.lib.trc_scene_export_tallies(self.handle, C.c_void_p(int(out)), 1))
+        return None
+
+    def import_tallies(self, src):
+        if isinstance(src, N.ndarray):
+            src = _cabi.f64(src)
+            _cabi.check(self.lib.trc_scene_import_tallies(self.handle, src.ctypes.data_as(C.c_void_p), 0))
+        else:
+            _cabi.check(self.lib.trc_scene_import_tallies(self.handle, C.c_void_p(int(src)), 1))
+
+    # -- tracing --------------------------------------------------------------------------------
+    def _bundle_args(self, bundle):
+        """(rays struct or None, source desc or None, n, seed override, offset, keepalive)"""
+        from .sources import LazySourceBundle
+        if isinstance(bundle, LazySourceBundle) and bundle.is_pending():
+            desc, n, seed, off = bundle.source_args()
+            return None, desc, n, seed, off, None
+        cols = bundle.columns_soa()
+        n = cols['x'].shape[0]
+        rays = _cabi.make_rays(n, cols['x'], cols['y'], cols['z'], cols['dx'], cols['dy'], cols['dz'], cols['e'],
+                               ref_index=cols.get('ref_index'), wavelength=cols.get('wavelength'))
+        return rays, None, n, None, 0, cols
+
+    def trace_fast(self, bundle, reps, min_energy, seed, accel=False, keep_last=False):
+        rays, src, n, src_seed, off, keep = self._bundle_args(bundle)
+        if src_seed is not None:
+            seed = src_seed
+        flags = (_cabi.TRACE_ACCEL if accel else 0) | (_cabi.TRACE_KEEP_LAST if keep_last else 0)
+        stats = _cabi.TraceStats()
+        last = None
+        last_cols = None
+        if keep_last:
+            last_cols = [N.empty(n) for _ in range(7)]
+            last = _cabi.make_rays(n, *last_cols)
+        _cabi.check(self.lib.trc_trace_fast(self.handle, C.byref(rays) if rays is not None else None,
+                                            C.byref(src) if src is not None else None, n, int(reps), float(min_energy),
+                                            int(seed), int(off), flags, C.byref(last) if last is not None else None,
+                                            C.byref(stats)))
+        if keep_last:
+            m = last.n
+            last_cols = [c[:m] for c in last_cols]
+        return stats, last_cols
+
+    def trace_ordered(self, bundle, reps, min_energy, seed, accel=False):
+        rays, src, n, src_seed, off, keep = self._bundle_args(bundle)
+        if src_seed is not None:
+            seed = src_seed
+        flags = _cabi.TRACE_ACCEL if accel else 0
+        stats = _cabi.TraceStats()
+        res = C.c_void_p()
+        _cabi.check(self.lib.trc_trace_ordered(self.handle, C.byref(rays) if rays is not None else None,
+                                               C.byref(src) if src is not None else None, n, int(reps),
+                                               float(min_energy), int(seed), int(off), flags, C.byref(res),
+                                               C.byref(stats)))
+        return OrderedResult(self, res), stats
+
+
+class OrderedResult(object):
+    """trc_result handle: the RayTree levels of an ordered trace, fetched level by level."""
+    def __init__(self, scene, handle):
+        self.scene = scene
+        self.lib = scene.lib
+        self.handle = handle
+
+    def close(self):
+        if self.handle is not None and self.handle.value:
+            self.lib.trc_result_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_levels(self):
+        n = C.c_int32(0)
+        _cabi.check(self.lib.trc_result_num_levels(self.handle, C.byref(n)))
+        return n.value
+
+    def level_size(self, level):
+        a, b = C.c_int64(0), C.c_int64(0)
+        _cabi.check(self.lib.trc_result_level_size(self.handle, level, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def level(self, level, with_ref_index=True, with_wavelength=False):
+        """dict: vertices (3,n), directions (3,n), energy, parents, surf, ref_index[, wavelengths], n_live"""
+        n, n_live = self.level_size(level)
+        v = N.empty((3, n))
+        d = N.empty((3, n))
+        e = N.empty(n)
+        par = N.empty(n, dtype=N.int64)
+        ri = N.empty(n) if with_ref_index else None
+        wl = N.empty(n) if with_wavelength else None
+        surf = N.empty(n, dtype=N.int32)
+        rays = _cabi.make_rays(n, v[0], v[1], v[2], d[0], d[1], d[2], e, parent=par, ref_index=ri, wavelength=wl)
+        _cabi.check(self.lib.trc_result_level_get(self.handle, level, C.byref(rays),
+                                                  surf.ctypes.data_as(C.POINTER(C.c_int32))))
+        out = dict(vertices=v, directions=d, energy=e, parents=par, surf=surf, n_live=n_live)
+        if ri is not None:
+            out['ref_index'] = ri
+        if wl is not None:
+            out['wavelengths'] = wl
+        return out
+
+
+def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavelengths=None):
+    """
+    Hand per-hit data to the accountants of each surface's optics (fused engines).  Inside one call
+    the hits of a surface are kept in the order given.
+    """
+    surf_ids = N.asarray(surf_ids)
+    if len(surf_ids) == 0:
+        return
+    order = N.argsort(surf_ids, kind='stable')
+    sorted_ids = surf_ids[order]
+    uniq, start = N.unique(sorted_ids, return_index=True)
+    stop = list(start[1:]) + [len(order)]
+    for s, a, b in zip(uniq, start, stop):
+        opt = surfaces[s].get_optics_manager()
+        if not isinstance(opt, OpticsCallable) or not opt.accountants:
+            continue
+        idx = order[a:b]
+        surf = surfaces[s]
+        pts = points[:, idx]
+        dirs = directions[:, idx]
+
+        def normals(surf=surf, pts=pts, dirs=dirs):
+            gm = surf.get_geometry_manager()
+            desc, _ = gm._desc(surf._temp_frame)
+            ctx = _cabi.get_context()
+            h = _cabi.f64(pts)
+            d = _cabi.f64(dirs)
+            out = N.empty_like(h)
+            _cabi.check(ctx.lib.trc_gm_get_normals(ctx.handle, C.byref(desc), h.shape[1], _cabi.ptr(h[0]), _cabi.ptr(h[1]),
+                                                   _cabi.ptr(h[2]), _cabi.ptr(d[0]), _cabi.ptr(d[1]), _cabi.ptr(d[2]),
+                                                   _cabi.ptr(out[0]), _cabi.ptr(out[1]), _cabi.ptr(out[2])))
+            return out
+        hit = dict(e_in=e_in[idx], e_out=e_out[idx], points=pts, directions=dirs, normals=normals,
+                   wavelengths=None if wavelengths is None else wavelengths[idx])
+        for acc in opt.accountants:
+            acc.feed(hit)

@@ -1,0 +1,101 @@
+"""
+The benchmark / parity scenes of BASELINE.json, restated with the current public API from the
+parameters given in SURVEY.md section 8(d) (the reference's own example scripts are Python-2 and
+API-stale and cannot run).  Used by bench.py, __graft_entry__.smoke() and the tests.
+
+  nsttf_field()   Sandia NSTTF: 218 heliostats 6.1 x 6.1 m (absorptivity 0.04, sigma 1 mrad
+                  bi-variate, 'fast' option), all aimed at (0,0,60), sun azimuth 0 / zenith 35.05 deg,
+                  11 x 11 m one-sided receiver at z = 60 facing the field, Buie sunshape CSR 0.01.
+                  Parameters: examples/Sandia_NSTTF_field example.py:31-36, :82-112, :135-182 and
+                  examples/sandia_hstat_coordinates.csv (data file shipped as
+                  tracer_amd/data/sandia_hstat_coordinates.csv).
+  dish()          parabolic dish D=5 f=3 + round receiver r=0.15 at the focus, Buie CSR 0.05 (config 2).
+  flat_pair()     2x2 flat mirror + 4x4 Lambertian receiver, pillbox rect source (config 1).
+"""
+import os
+
+import numpy as N
+
+from .assembly import Assembly
+from .object import AssembledObject
+from .surface import Surface
+from .flat_surface import RectPlateGM, RoundPlateGM
+from .paraboloid import ParabolicDishGM
+from . import optics_callables as opt
+from .spatial_geometry import rotx, translate
+from .models.heliostat_field import HeliostatField, solar_vector
+from .models.one_sided_mirror import one_sided_receiver
+from . import sources
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
+
+
+def nsttf_positions():
+    pos = N.loadtxt(os.path.join(_DATA, 'sandia_hstat_coordinates.csv'), delimiter=',')
+    pos[:, 1] -= 4.   # examples/Sandia_NSTTF_field example.py:84
+    return pos
+
+
+def nsttf_field(sigma=1e-3, n_heliostats=None):
+    """Returns (plant Assembly, field, receiver object, source-argument dict)."""
+    pos = nsttf_positions()
+    if n_heliostats is not None:
+        pos = pos[:n_heliostats]
+    field = HeliostatField(pos, 6.1, 6.1, absorptivity=0.04, sigma=sigma, bi_var=True, MCRT_option='fast')
+    aim = N.tile(N.array([0., 0., 60.]), (pos.shape[0], 1))
+    zenith = 35.05 * N.pi / 180.
+    field.track_sun(0., zenith, aim_points=aim)
+    rec = one_sided_receiver(11., 11.)
+    rec.set_transform(N.dot(translate(0., 0., 60.), rotx(-N.pi / 2.)))
+    plant = Assembly(objects=[rec], subassemblies=[field])
+    sun = solar_vector(0., zenith)
+    x0, x1 = pos[:, 0].min(), pos[:, 0].max()
+    y0, y1 = pos[:, 1].min(), pos[:, 1].max()
+    centre = N.array([(x0 + x1) / 2., (y0 + y1) / 2., 0.])
+    radius = 1.10 * N.sqrt(((x1 - x0) / 2.) ** 2 + ((y1 - y0) / 2.) ** 2)
+    src = dict(center=N.vstack(300. * sun + centre), direction=-sun, radius=radius, CSR=0.01, flux=1000.,
+               pre_process_CSR=False)
+    return plant, field, rec, src
+
+
+def nsttf_source(n, src, seed=None, ray_offset=0):
+    return sources.buie_sunshape(n, src['center'], src['direction'], src['radius'], src['CSR'], flux=src['flux'],
+                                 pre_process_CSR=src['pre_process_CSR'], seed=seed, ray_offset=ray_offset)
+
+
+def nsttf_fluxmap_edges(bins=50):
+    e = N.linspace(-5.5, 5.5, bins + 1)
+    return e, e
+
+
+def dish(sigma=2e-3):
+    dish_surf = Surface(ParabolicDishGM(5., 3.), opt.RealReflective(0.06, sigma, bi_var=False))
+    dish_obj = AssembledObject(surfs=[dish_surf])
+    rec_surf = Surface(RoundPlateGM(0.15), opt.LambertianReceiver(1.))
+    rec_obj = AssembledObject(surfs=[rec_surf], transform=N.dot(translate(0., 0., 3.), rotx(N.pi)))
+    asm = Assembly(objects=[dish_obj, rec_obj])
+    src = dict(center=N.c_[[0., 0., 6.]], direction=N.r_[0., 0., -1.], radius=2.5, CSR=0.05, flux=1000.)
+    return asm, dish_surf, rec_surf, src
+
+
+def dish_source(n, src, seed=None, ray_offset=0):
+    return sources.buie_sunshape(n, src['center'], src['direction'], src['radius'], src['CSR'], flux=src['flux'],
+                                 seed=seed, ray_offset=ray_offset)
+
+
+def flat_pair():
+    d = N.r_[-0.15, 0., -1.]
+    d = d / N.sqrt(N.sum(d ** 2))
+    mirror = Surface(RectPlateGM(2., 2.), opt.RealReflective(0.05, 2e-3, bi_var=True))
+    m_obj = AssembledObject(surfs=[mirror])
+    out = d - 2. * d[2] * N.r_[0., 0., 1.]          # specular direction off the z=0 mirror
+    rec = Surface(RectPlateGM(4., 4.), opt.LambertianReceiver(1.))
+    r_obj = AssembledObject(surfs=[rec], transform=N.dot(translate(*(out * 10. / out[2])), rotx(N.pi)))
+    asm = Assembly(objects=[m_obj, r_obj])
+    src = dict(center=N.vstack(-d * 5.), direction=d, x=2., y=2., ang_range=4.65e-3, flux=1000.)
+    return asm, mirror, rec, src
+
+
+def flat_pair_source(n, src, seed=None, ray_offset=0):
+    return sources.rect_bundle(n, src['center'], src['direction'], src['x'], src['y'], src['ang_range'],
+                               flux=src['flux'], seed=seed, ray_offset=ray_offset)

@@ -1,0 +1,199 @@
+"""
+Source bundles.  Function names and arguments follow the reference's tracer/sources.py
+(:88-117 direction samplers, :175-239 disk_bundle, :241-264 rect_bundle, :330-384 Buie sampling,
+:412-464 buie_sunshape, :466-515 rect_buie_sunshape).
+
+Everything that does not depend on the random draws -- the rotation_to_z frames, the per-ray
+energy, the 210-interval Buie CDF table -- is evaluated here on the host once per call and packed
+into a trc_source_desc; the rays themselves are sampled on the GPU (csrc/trc_core.h,
+trc_source_ray), either materialised as a bundle (trc_source_generate) or fused into the trace
+kernel.  The functions return a LazySourceBundle: a RayBundle whose columns appear on first access.
+"""
+import ctypes as C
+
+import numpy as N
+
+from . import _cabi, rng
+from .ray_bundle import RayBundle
+from .spatial_geometry import rotation_to_z
+
+
+class LazySourceBundle(RayBundle):
+    """
+    A source bundle described by (descriptor, n, seed, ray_offset).  Ray i has random stream id
+    ray_offset + i.  Any column access generates the rays on the device; an engine that receives an
+    untouched LazySourceBundle generates them inside its own kernel instead.
+    """
+    def __init__(self, desc, n, seed, ray_offset=0):
+        RayBundle.__init__(self)
+        object.__setattr__(self, '_src_desc', desc)
+        object.__setattr__(self, '_src_n', int(n))
+        object.__setattr__(self, '_src_seed', int(seed))
+        object.__setattr__(self, '_src_offset', int(ray_offset))
+        object.__setattr__(self, '_src_done', False)
+
+    def is_pending(self):
+        return not self._src_done
+
+    def get_num_rays(self):
+        if not self._src_done:
+            return self._src_n
+        return RayBundle.get_num_rays(self)
+
+    def source_args(self):
+        return self._src_desc, self._src_n, self._src_seed, self._src_offset
+
+    def _materialize(self):
+        if self._src_done:
+            return
+        object.__setattr__(self, '_src_done', True)
+        n = self._src_n
+        ctx = _cabi.get_context()
+        v = N.empty((3, n))
+        d = N.empty((3, n))
+        e = N.empty(n)
+        rays = _cabi.make_rays(n, v[0], v[1], v[2], d[0], d[1], d[2], e)
+        _cabi.check(ctx.lib.trc_source_generate(ctx.handle, C.byref(self._src_desc), n, self._src_seed,
+                                                self._src_offset, C.byref(rays)))
+        self._cols['vertices'] = v
+        self._cols['directions'] = d
+        self._cols['energy'] = e
+
+
+def _fill_source(kind, center, rot_pos, rot_dir, params, energy, buie=None):
+    s = _cabi.SourceDesc()
+    s.kind = kind
+    c = N.ravel(N.asarray(center, dtype=float))
+    for i in range(3):
+        s.center[i] = c[i]
+    rp = N.ravel(N.asarray(rot_pos, dtype=float))
+    rd = N.ravel(N.asarray(rot_dir, dtype=float))
+    for i in range(9):
+        s.rot_pos[i] = rp[i]
+        s.rot_dir[i] = rd[i]
+    for i, p in enumerate(params):
+        s.p[i] = float(p)
+    s.energy = float(energy)
+    if buie is not None:
+        for i, b in enumerate(buie):
+            s.buie[i] = b
+    return s
+
+
+def _new_bundle(desc, num_rays, seed, ray_offset):
+    if seed is None:
+        seed = rng.next_seed()
+    return LazySourceBundle(desc, int(num_rays), seed, ray_offset)
+
+
+def _tilt_cos(rays_direction, direction):
+    """cos of the angle between the bundle axis and the emitting plane normal (sources.py:235, :445)."""
+    chord = N.sqrt(N.sum((N.asarray(rays_direction, dtype=float) - N.asarray(direction, dtype=float)) ** 2))
+    return N.cos(2. * N.sin(chord / 2.))
+
+
+def disk_bundle(num_rays, center, direction, radius, ang_range, flux=None, radius_in=0., angular_span=[0., 2. * N.pi],
+                x_cut=None, procs=1, rays_direction=None, seed=None, ray_offset=0):
+    """
+    Pillbox/Lambertian-cone rays leaving an annular disc.  center: 3x1 column, direction: 3-vector
+    normal of the disc; energies flux*area/N*cos(tilt), or 1/N/procs without flux.
+    """
+    if x_cut is not None:
+        raise NotImplementedError("disk_bundle(x_cut=...) uses rejection sampling and is not in the native table")
+    radius, radius_in = float(radius), float(radius_in)
+    if rays_direction is None:
+        rays_direction = direction
+    if flux is not None:
+        energy = N.pi * (radius ** 2. - radius_in ** 2.) / num_rays * flux * _tilt_cos(rays_direction, direction)
+    else:
+        energy = 1. / float(num_rays) / procs
+    rot = rotation_to_z(rays_direction)
+    desc = _fill_source(_cabi.SRC_PILLBOX_DISK, center, rot, rot,
+                        [radius, radius_in, angular_span[0], angular_span[1], ang_range], energy)
+    return _new_bundle(desc, num_rays, seed, ray_offset)
+
+
+def rect_bundle(num_rays, center, direction, x, y, ang_range, flux=None, procs=1, seed=None, ray_offset=0):
+    """Pillbox rays leaving an x by y rectangle normal to `direction` (sources.py:241-264)."""
+    direction = N.asarray(direction)
+    swap = bool((direction == N.array([0, 0, -1])).all())
+    energy = x * y / num_rays * flux if flux is not None else 1. / float(num_rays) / procs
+    rot = rotation_to_z(direction)
+    desc = _fill_source(_cabi.SRC_PILLBOX_RECT, center, rot, rot, [x, y, ang_range, 1. if swap else 0.], energy)
+    return _new_bundle(desc, num_rays, seed, ray_offset)
+
+
+def solar_disk_bundle(num_rays, center, direction, radius, ang_range, flux=None, radius_in=0., angular_span=[0., 2. * N.pi],
+                      procs=1, seed=None, ray_offset=0):
+    """Older name of disk_bundle still used by scene scripts."""
+    return disk_bundle(num_rays, center, direction, radius, ang_range, flux, radius_in, angular_span, None, procs,
+                       None, seed, ray_offset)
+
+
+def buie_table(CSR, pre_process_CSR=True):
+    """
+    The Buie sunshape sampling table of the reference (sources.py:333-361): 211 polar angles up to
+    4.65 mrad, g = phi*cos*sin with phi = cos(0.326 theta)/cos(0.308 theta) (theta in mrad), the
+    trapezoid CDF of the disc part, and the aureole constants kappa, gamma for CSR > 0.
+    Layout: trc_source_desc.buie.
+    """
+    theta_dni = 4.65e-3
+    theta_tot = 43.6e-3
+    nelem = _cabi.TRC_BUIE_NELEM
+    theta = N.linspace(0., theta_dni, nelem + 1)
+    phi = N.cos(0.326 * theta * 1e3) / N.cos(0.308 * theta * 1e3)
+    g = phi * N.cos(theta) * N.sin(theta)
+    integ = 0.5 * (phi[:-1] * N.cos(theta[:-1]) * N.sin(theta[:-1]) + phi[1:] * N.cos(theta[1:]) * N.sin(theta[1:])) * \
+        (theta[1:] - theta[:-1])
+    I_dni = N.sum(integ)
+    gamma = kappa = 0.
+    if CSR == 0.:
+        total = I_dni
+    else:
+        if pre_process_CSR:
+            if CSR <= 0.1:
+                CSR = -2.245e+03 * CSR ** 4. + 5.207e+02 * CSR ** 3. - 3.939e+01 * CSR ** 2. + 1.891e+00 * CSR + 8e-03
+            else:
+                CSR = 1.973 * CSR ** 4. - 2.481 * CSR ** 3. + 0.607 * CSR ** 2. + 1.151 * CSR - 0.020
+        kappa = 0.9 * N.log(13.5 * CSR) * CSR ** (-0.3)
+        gamma = 2.2 * N.log(0.52 * CSR) * CSR ** (0.43) - 0.1
+        I_csr = 1e-6 * N.exp(kappa) / (gamma + 2.) * ((theta_tot * 1000.) ** (gamma + 2.) - (theta_dni * 1000.) ** (gamma + 2.))
+        total = I_dni + I_csr
+    cdf = N.add.accumulate(N.hstack(([0], integ / total)))
+    return N.concatenate((theta, g, cdf, [I_dni, gamma, kappa, theta_dni, theta_tot, 1. if CSR > 0. else 0.]))
+
+
+def buie_sunshape(num_rays, center, direction, radius, CSR, flux=None, pre_process_CSR=True, rays_direction=None,
+                  seed=None, ray_offset=0):
+    """
+    Disc source with the Buie sunshape (sources.py:412-464): start points uniform on a disc of
+    `radius` normal to `direction`, directions about `rays_direction` (default `direction`).
+    """
+    direction = N.asarray(direction, dtype=float)
+    if rays_direction is None:
+        rays_direction = direction
+    energy = flux * (N.pi * radius ** 2.) / num_rays * _tilt_cos(rays_direction, direction)
+    desc = _fill_source(_cabi.SRC_BUIE_DISK, center, rotation_to_z(direction), rotation_to_z(rays_direction),
+                        [radius], energy, buie_table(CSR, pre_process_CSR))
+    return _new_bundle(desc, num_rays, seed, ray_offset)
+
+
+def rect_buie_sunshape(num_rays, center, direction, width, height, CSR, flux=None, pre_process_CSR=True,
+                       rays_direction=None, seed=None, ray_offset=0):
+    """Rectangular source with the Buie sunshape (sources.py:466-515)."""
+    direction = N.asarray(direction, dtype=float)
+    if rays_direction is None:
+        rays_direction = direction
+    energy = flux * (width * height) / num_rays * _tilt_cos(rays_direction, direction)
+    desc = _fill_source(_cabi.SRC_BUIE_RECT, center, rotation_to_z(direction), rotation_to_z(rays_direction),
+                        [width, height], energy, buie_table(CSR, pre_process_CSR))
+    return _new_bundle(desc, num_rays, seed, ray_offset)
+
+
+def single_ray_source(position, direction, flux=None):
+    """One ray (sources.py:68-86)."""
+    d = N.array(direction, dtype=float).reshape(3, 1)
+    d /= N.sqrt(N.sum(d ** 2, axis=0))
+    b = RayBundle(vertices=N.asarray(position, dtype=float).reshape(3, 1), directions=d)
+    b.set_energy(flux * N.ones(1))
+    return b

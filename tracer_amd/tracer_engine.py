@@ -1,0 +1,295 @@
+"""
+TracerEngine: the entry point of the hot path.
+
+Signature and side effects follow the reference's tracer/tracer_engine.py:16-25, :124-295:
+`ray_tracer(bundle, reps, min_energy, tree, accel, Kd_Tree, **kwargs)` returns the vertices and
+directions of the rays still alive, fills `self.tree` (RayTree) and the accountants of the
+surfaces' optics.  What differs is where the work happens:
+
+  engine='ordered'  (default when tree=True)  one device launch set per bounce; bundle ordering,
+                    parents and culled-rays-last layout identical to the reference (trc_trace_ordered).
+  engine='fast'     (default when tree=False) persistent-wavefront kernel, rays stay in registers for
+                    all bounces, tallies / flux maps / hit buffer on the device (trc_trace_fast);
+                    `self.tree` stays empty.
+  engine='protocol' host loop over surfaces calling register_incoming / select_rays / get_outgoing
+                    (the reference's four-step protocol) for scenes with user-defined Python geometry
+                    or optics; native kinds inside such a scene still run their device kernels.
+
+There is no CPU implementation of the native kinds: without the HIP library or a GPU every path
+raises.
+"""
+import logging
+import time
+
+import numpy as N
+
+from . import rng
+from .accel_tree import KdTree
+from .ray_bundle import RayBundle, concatenate_rays
+from .scene import compile_scene, DeviceScene, NotNativeError, feed_accountants
+from .trace_tree import RayTree
+
+
+class TracerEngine(object):
+    def __init__(self, parent_assembly, loglevel=logging.DEBUG):
+        self._asm = parent_assembly
+        self.loglevel = loglevel
+        self._dev = None
+        self._dev_sig = None
+        self._fluxmap_requests = {}
+        self.stats = {}
+
+    # -- device scene management ------------------------------------------------------------------
+    def _device_scene(self):
+        compiled = compile_scene(self._asm)
+        sig = compiled.signature()
+        if self._dev is None or sig != self._dev_sig:
+            if self._dev is not None:
+                self._dev.close()
+            self._dev = DeviceScene(compiled)
+            self._dev_sig = sig
+            self._kd_on_device = None
+            for si, (u, v) in self._fluxmap_requests.items():
+                self._dev.set_fluxmap(si, u, v)
+        else:
+            self._dev.compiled = compiled   # same numbers, fresh Surface objects
+        return self._dev
+
+    def set_fluxmap(self, surface, u_edges, v_edges):
+        """
+        Ask the device to bin the energy absorbed by `surface` (a Surface of the assembly, or its
+        index) on u_edges x v_edges of its local x, y -- the on-device form of the caller-side
+        numpy.histogram2d of the reference's examples.  Read it back with get_fluxmap().
+        """
+        si = surface if isinstance(surface, int) else self._asm.get_surfaces().index(surface)
+        self._fluxmap_requests[si] = (N.asarray(u_edges, dtype=float), N.asarray(v_edges, dtype=float))
+        if self._dev is not None:
+            self._dev.close()
+            self._dev = None
+
+    def get_fluxmap(self, surface):
+        si = surface if isinstance(surface, int) else self._asm.get_surfaces().index(surface)
+        return self._dev.get_fluxmap(si)
+
+    def get_tallies(self):
+        """(absorbed, received, hits) per surface, accumulated on the device since the last reset."""
+        return self._dev.get_tallies()
+
+    def reset_tallies(self):
+        if self._dev is not None:
+            self._dev.reset_tallies()
+
+    # -- the entry point ------------------------------------------------------------------------------
+    def ray_tracer(self, bundle, reps=100, min_energy=1e-10, tree=True, accel=False, Kd_Tree=None, **kwargs):
+        """
+        Trace `bundle` through the assembly for at most `reps` interactions per ray, dropping rays
+        whose energy falls to `min_energy` or below.  accel: False, True, 'fast' or 'lightweight'
+        (Kd-tree over the objects' BoundaryBoxes; 'lightweight' is accepted and gives the same results).
+        Extra keywords: engine ('auto'|'ordered'|'fast'|'protocol'), seed, hit_capacity, and the
+        KdTree keywords of the reference (min_leaf, t_trav, t_isec, empty_bonus).
+        """
+        engine = kwargs.pop('engine', 'auto')
+        seed = kwargs.pop('seed', None)
+        hit_capacity = kwargs.pop('hit_capacity', None)
+        if seed is None:
+            seed = rng.next_seed()
+        self.reps = reps
+        self.minener = min_energy
+        self.tree = RayTree()
+
+        if engine == 'protocol':
+            return self._trace_protocol(bundle, reps, min_energy, tree)
+        try:
+            dev = self._device_scene()
+        except NotNativeError as err:
+            if engine != 'auto':
+                raise
+            logging.log(self.loglevel, 'protocol engine: %s' % err)
+            return self._trace_protocol(bundle, reps, min_energy, tree)
+
+        if accel:
+            if Kd_Tree is None:
+                num_surfs = dev.n_surf
+                max_depth = 8 + 1.3 * N.log(num_surfs)
+                logging.log(self.loglevel, 'Maximum Kd tree depth %i' % max_depth)
+                kw = dict(kwargs)
+                kw.setdefault('min_leaf', 1)
+                self.Kd_Tree = KdTree(self._asm, max_depth, loglevel=self.loglevel, fast=(accel == 'fast'), **kw)
+            else:
+                self.Kd_Tree = Kd_Tree
+            if self._kd_on_device is not self.Kd_Tree:
+                dev.set_kdtree(self.Kd_Tree)
+                self._kd_on_device = self.Kd_Tree
+
+        if engine == 'auto':
+            engine = 'ordered' if (tree or dev.compiled.splits) else 'fast'
+        if engine == 'fast':
+            return self._trace_fast(dev, bundle, reps, min_energy, seed, bool(accel), hit_capacity)
+        if engine == 'ordered':
+            return self._trace_ordered(dev, bundle, reps, min_energy, seed, bool(accel), tree)
+        raise ValueError("unknown engine %r" % (engine,))
+
+    # -- fast engine --------------------------------------------------------------------------------
+    def _trace_fast(self, dev, bundle, reps, min_energy, seed, accel, hit_capacity):
+        n = bundle.get_num_rays()
+        capture = any(dev.compiled.capture)
+        if capture:
+            dev.set_hit_capacity(hit_capacity if hit_capacity is not None else 2 * n + 1024)
+            dev.lib.trc_scene_clear_hits(dev.handle)
+        t0 = time.time()
+        stats, last = dev.trace_fast(bundle, reps, min_energy, seed, accel=accel, keep_last=True)
+        wall = time.time() - t0
+        self._set_stats(stats, wall, 'fast')
+        if stats.hits_dropped:
+            raise RuntimeError("%d hits were not captured: the hit buffer holds %d; pass hit_capacity=..."
+                               % (stats.hits_dropped, dev.hit_capacity))
+        if capture:
+            h = dev.get_hits()
+            feed_accountants(dev.compiled.surfaces, h['surf'], h['e_in'], h['e_in'] - h['e_abs'], h['points'],
+                             h['directions'])
+        self._warn_left(stats.rays_left, stats.energy_left, bundle)
+        return N.vstack(last[0:3]), N.vstack(last[3:6])
+
+    # -- ordered engine -----------------------------------------------------------------------------
+    def _trace_ordered(self, dev, bundle, reps, min_energy, seed, accel, tree):
+        has_ref = bundle._has_column('ref_index') if not _pending(bundle) else False
+        has_wl = bundle._has_column('wavelengths') if not _pending(bundle) else False
+        t0 = time.time()
+        res, stats = dev.trace_ordered(bundle, reps, min_energy, seed, accel=accel)
+        wall = time.time() - t0
+        self._set_stats(stats, wall, 'ordered')
+        try:
+            nlev = res.num_levels()
+            if tree is True:
+                self.tree.append(bundle)
+            prev = None
+            last = None
+            for lv in range(1, nlev):
+                L = res.level(lv, with_ref_index=True, with_wavelength=has_wl)
+                if prev is None:
+                    prev = dict(energy=N.asarray(bundle.get_energy()), directions=N.asarray(bundle.get_directions()),
+                                wavelengths=bundle.get_wavelengths() if has_wl else None)
+                # accountants: hits of a surface in the order the reference selects them (ascending parent)
+                par = L['parents']
+                order = N.lexsort((par, L['surf']))
+                po = par[order]
+                feed_accountants(dev.compiled.surfaces, L['surf'][order], prev['energy'][po], L['energy'][order],
+                                 L['vertices'][:, order], prev['directions'][:, po],
+                                 None if prev['wavelengths'] is None else prev['wavelengths'][po])
+                kw = {}
+                if has_ref or dev.compiled.splits or _has_refractive(dev):
+                    kw['ref_index'] = L['ref_index']
+                if has_wl:
+                    kw['wavelengths'] = L['wavelengths']
+                rec = RayBundle(vertices=L['vertices'], directions=L['directions'], energy=L['energy'],
+                                parents=L['parents'], **kw)
+                if tree is True or lv == nlev - 1:
+                    self.tree.append(rec)
+                prev = dict(energy=L['energy'], directions=L['directions'], wavelengths=L.get('wavelengths'))
+                last = L
+        finally:
+            res.close()
+        if last is None or stats.rays_left == 0:
+            if stats.rays_left == 0 and nlev > 1 or nlev == 1:
+                logging.log(self.loglevel, 'Ray bundle depleted')
+            return N.zeros((3, 0)), N.zeros((3, 0))
+        k = last['n_live']
+        self._warn_left(stats.rays_left, stats.energy_left, bundle)
+        return last['vertices'][:, :k], last['directions'][:, :k]
+
+    # -- protocol engine ----------------------------------------------------------------------------
+    def intersect_ray(self, bundle, surfaces, surf_relevancy):
+        """
+        First surface hit by each ray, surfaces driven one at a time through register_incoming
+        (tracer_engine.py:27-64): t == 0 is no hit, ties go to the lowest surface index.
+        Returns (earliest_surf (-1 = none), surf_relevancy).
+        """
+        n = bundle.get_num_rays()
+        best = N.full(n, N.inf)
+        earliest = N.full(n, -1, dtype=int)
+        for si, surf in enumerate(surfaces):
+            rel = N.asarray(surf_relevancy[si], dtype=bool)
+            if not rel.any():
+                continue
+            sub = bundle if rel.all() else bundle.inherit(rel)
+            t = N.array(surf.register_incoming(sub), dtype=float)
+            t[t == 0.] = N.inf
+            idx = N.nonzero(rel)[0]
+            closer = t < best[idx]
+            best[idx[closer]] = t[closer]
+            earliest[idx[closer]] = si
+        return earliest, surf_relevancy
+
+    def _trace_protocol(self, bundle, reps, min_energy, tree):
+        surfaces = self._asm.get_surfaces()
+        objects = self._asm.get_objects()
+        S = len(surfaces)
+        owner = N.repeat(N.arange(len(objects)), [len(o.get_surfaces()) for o in objects])
+        first_of_obj = N.concatenate(([0], N.cumsum([len(o.get_surfaces()) for o in objects])))
+        bund = bundle
+        if tree is True:
+            self.tree.append(bund)
+        relevancy = N.ones((S, bund.get_num_rays()), dtype=bool)
+        record = []
+        for it in range(reps):
+            front, _ = self.intersect_ray(bund, surfaces, relevancy)
+            outg, record, weak, next_rel = [], [], [], []
+            for si in range(S):
+                rel_idx = N.nonzero(relevancy[si])[0]
+                hit_here = front[rel_idx] == si
+                if not hit_here.any():
+                    surfaces[si].done()
+                    continue
+                surfaces[si].select_rays(N.nonzero(hit_here)[0])
+                new = surfaces[si].get_outgoing()
+                new.set_parents(rel_idx[new.get_parents()])        # index into the full bundle
+                record.append(new)
+                low = new.get_energy() <= min_energy
+                weak.append(low)
+                if low.any():
+                    new = new.delete_rays(N.nonzero(low)[0])
+                surfaces[si].done()
+                outg.append(new)
+                oi = owner[si]
+                rel = N.ones((S, new.get_num_rays()), dtype=bool)
+                rel[owner == oi] = objects[oi].surfaces_for_next_iteration(new, si - first_of_obj[oi])
+                next_rel.append(rel)
+            bund = concatenate_rays(outg)
+            if tree:
+                rec = concatenate_rays(record)
+                if rec.get_num_rays() != 0:
+                    self.tree.append(bund + rec.inherit(N.nonzero(N.hstack(weak))[0]))
+            if bund.get_num_rays() == 0:
+                logging.log(self.loglevel, 'Ray bundle depleted')
+                break
+            relevancy = N.hstack(next_rel)
+        if not tree:
+            self.tree.append(concatenate_rays(record))
+        if bund.get_num_rays() != 0:
+            self._warn_left(bund.get_num_rays(), N.sum(bund.get_energy()), bundle)
+        return bund.get_vertices(), bund.get_directions()
+
+    # -- helpers ------------------------------------------------------------------------------------
+    def _set_stats(self, stats, wall, engine):
+        self.stats = dict(engine=engine, segments=stats.segments, hits=stats.hits, rays_left=stats.rays_left,
+                          energy_left=stats.energy_left, kernel_ms=stats.kernel_ms, bounces=stats.bounces,
+                          launches=stats.launches, wall_s=wall)
+        logging.log(self.loglevel, 'trace time %s s' % wall)
+
+    def _warn_left(self, rays_left, energy_left, bundle):
+        if rays_left:
+            logging.warning('%d rays left at the end of the simulation' % rays_left)
+            try:
+                tot = N.sum(bundle.get_energy()) if not _pending(bundle) else bundle.source_args()[0].energy * bundle.get_num_rays()
+                logging.warning('Remaining energy in last bundle: %s%%' % (energy_left / tot * 100.))
+            except Exception:
+                pass
+
+
+def _pending(bundle):
+    return hasattr(bundle, 'is_pending') and bundle.is_pending()
+
+
+def _has_refractive(dev):
+    from . import _cabi
+    return any(d.optics_kind == _cabi.OPT_REFRACTIVE_HOMOGENOUS for d in dev.compiled.descs)
