@@ -1,0 +1,196 @@
+"""
+Optics laws and callables, restated.  Each law takes its random variates as arguments so that it can be
+pinned against the reference by replaying numpy.random draws; `shade()` draws them from Philox in the
+device's order.
+"""
+import numpy as N
+from .kinds import *
+from . import philox
+
+
+def reflections(d, n):
+    """optics.py:145-157"""
+    vertical = N.sum(d * n, axis=0) * n
+    return d - 2. * vertical
+
+
+def general_axis_rotation(axis, ang):
+    """spatial_geometry.py:8-22 (sin/cos rounded to 14 decimals)"""
+    s = N.round(N.sin(ang), decimals=14)
+    c = N.round(N.cos(ang), decimals=14)
+    v = 1 - c
+    add = N.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return N.multiply.outer(axis, axis) * v + N.eye(3) * c + add * s
+
+
+def rotate_z_to_normal(vecs, normals):
+    """ray_trace_utils/vector_manipulations.py:56-90: minimal rotation z -> normal, applied per ray"""
+    z = N.zeros(vecs.shape)
+    z[2] = 1.
+    with N.errstate(invalid='ignore', divide='ignore'):
+        axes = N.cross(z.T, normals.T).T
+        axes = axes / N.sqrt(N.sum(axes ** 2, axis=0))
+    nans = N.isnan(axes[0])
+    axes[:, nans] = N.array([[1., 0., 0.]]).T
+    angles = N.arccos(normals[2])
+    out = N.empty_like(vecs)
+    for i in range(vecs.shape[1]):
+        if angles[i] != 0.:
+            out[:, i] = N.dot(general_axis_rotation(axes[:, i], angles[i]), vecs[:, i])
+        else:
+            out[:, i] = vecs[:, i]
+    return out
+
+
+def rotation_to_z(vecs):
+    """spatial_geometry.py:24-48: (n,3) unit vectors -> (n,3,3) frames with columns (perp, v x perp, v)"""
+    vecs = N.atleast_2d(vecs)
+    perp = N.hstack((vecs[:, 1][:, None], -vecs[:, 0][:, None], N.zeros((vecs.shape[0], 1))))
+    perp[N.all(perp == 0., axis=1)] = N.r_[1., 0., 0.]
+    perp /= N.sqrt(N.sum(perp ** 2., axis=1))[:, None]
+    return N.concatenate((perp[..., None], N.cross(vecs, perp)[..., None], vecs[..., None]), axis=2)
+
+
+def pillbox_directions(xi1, xi2, ang_range):
+    """sources.py:91-98 with the uniforms given: xi1 in [0,2pi), xi2 in [0,1)"""
+    if ang_range == 0.:
+        dirs = N.zeros((3, len(xi1)))
+        dirs[2] = 1.
+        return dirs
+    sinsqrt = N.sin(ang_range) * N.sqrt(xi2)
+    return N.vstack((N.cos(xi1) * sinsqrt, N.sin(xi1) * sinsqrt, N.sqrt(1. - sinsqrt ** 2.)))
+
+
+def slope_error_normals(ideal_normals, sigma, bi_var, g0, g1, u):
+    """optics_callables.py:234-257; g0,g1 standard normal variates, u uniform [0,1)"""
+    if bi_var:
+        tanx = N.tan(sigma * g0)
+        tany = N.tan(sigma * g1)
+        ez = (1. / (1. + tanx ** 2. + tany ** 2.)) ** 0.5
+        ex = tanx * ez
+        ey = tany * ez
+    else:
+        th = sigma * g0
+        phi = 2. * N.pi * u
+        ez = N.cos(th)
+        ex = N.sin(th) * N.cos(phi)
+        ey = N.sin(th) * N.sin(phi)
+    real = rotate_z_to_normal(N.vstack((ex, ey, ez)), ideal_normals)
+    return real / N.sqrt(N.sum(real ** 2, axis=0))
+
+
+def lambertian_directions(normals, xi1, xi2, ang_range):
+    """optics_callables.py:163-165"""
+    directs = pillbox_directions(xi1, xi2, ang_range)
+    return N.sum(rotation_to_z(normals.T) * directs.T[:, None, :], axis=2).T
+
+
+def refractions(n1, n2, d, n):
+    """optics.py:159-192"""
+    eta = N.broadcast_arrays(n2 / n1, d[0])[0]
+    n = N.broadcast_arrays(n, d)[0]
+    cos1 = (n * d).sum(axis=0)
+    refracted = cos1 ** 2 >= 1. - eta ** 2
+    cos1 = cos1[refracted]
+    dd = d[:, refracted]
+    nn = n[:, refracted]
+    eta = eta[refracted]
+    refr = (dd - cos1 * nn) / eta
+    cos2 = N.sqrt(1 - 1. / eta ** 2 * (1. - cos1 ** 2))
+    refr = refr + nn * cos2 * N.where(cos1 < 0., -1, 1)
+    return refracted, refr
+
+
+def fresnel(d, n, n1, n2):
+    """optics.py:13-39"""
+    theta_in = N.arccos(N.abs((n * d).sum(axis=0)))
+    foo = N.cos(theta_in)
+    bar = N.sqrt(1 - (n1 / n2 * N.sin(theta_in)) ** 2)
+    Rs = ((n1 * foo - n2 * bar) / (n1 * foo + n2 * bar)) ** 2
+    Rp = ((n1 * bar - n2 * foo) / (n1 * bar + n2 * foo)) ** 2
+    return (Rs + Rp) / 2
+
+
+def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event):
+    """
+    One optics call on H hits.  Returns a list of blocks (reflected block first, refracted second), each a dict
+    with sel (indices into the H hits), directions (3,k), energy (k,), ref (k,), rid (k,).
+    Draw order = csrc/trc_core.h trc_shade.
+    """
+    H = d.shape[1]
+    allsel = N.arange(H)
+    if opt_kind == OPT_TRANSPARENT:                              # optics_callables.py:106-113
+        return [dict(sel=allsel, directions=d.copy(), energy=e.copy(), ref=ref.copy(), rid=rid)]
+    if opt_kind in (OPT_REFLECTIVE, OPT_ONE_SIDED_REFLECTIVE):   # :130-140, :201-212
+        eo = e * (1. - opt[0])
+        if opt_kind == OPT_ONE_SIDED_REFLECTIVE:
+            eo = eo.copy()
+            eo[N.sum(d * up[:, None], axis=0) > 0] = 0
+        return [dict(sel=allsel, directions=reflections(d, nrm), energy=eo, ref=ref.copy(), rid=rid)]
+    if opt_kind == OPT_REFLECTIVE_SPECTRAL:                      # :183-193
+        k = len(extra) // 2
+        eo = e * (1. - N.interp(wl, extra[:k], extra[k:]))
+        return [dict(sel=allsel, directions=reflections(d, nrm), energy=eo, ref=ref.copy(), rid=rid)]
+    if opt_kind in (OPT_REAL_REFLECTIVE, OPT_ONE_SIDED_REAL_REFLECTIVE):   # :231-269, :498-504
+        sigma, bi = opt[1], opt[2] != 0.
+        real = nrm
+        if sigma > 0.:
+            u0, u1 = philox.uniform_pair(seed, rid, event, 0)
+            g0, g1 = philox.normal_pair(u0, u1)
+            u2 = philox.uniform_pair(seed, rid, event, 1)[0] if not bi else N.zeros(H)
+            real = slope_error_normals(nrm, sigma, bi, g0, g1, u2)
+        eo = e * (1 - opt[0])
+        if opt_kind == OPT_ONE_SIDED_REAL_REFLECTIVE:
+            eo = eo.copy()
+            eo[N.sum(d * up[:, None], axis=0) > 0] = 0
+        return [dict(sel=allsel, directions=reflections(d, real), energy=eo, ref=ref.copy(), rid=rid)]
+    if opt_kind == OPT_LAMBERTIAN:                               # :154-176
+        u0, u1 = philox.uniform_pair(seed, rid, event, 0)
+        dirs = lambertian_directions(nrm, 2. * N.pi * u0, u1, opt[1])
+        return [dict(sel=allsel, directions=dirs, energy=e * (1. - opt[0]), ref=ref.copy(), rid=rid)]
+    if opt_kind == OPT_LAMBERTIAN_SPECULAR:                      # :561-585
+        u0, u1 = philox.uniform_pair(seed, rid, event, 0)
+        u2, _ = philox.uniform_pair(seed, rid, event, 1)
+        specular = u0 < opt[1]
+        dirs = N.zeros(d.shape)
+        dirs[:, specular] = reflections(d[:, specular], nrm[:, specular])
+        ns = ~specular
+        dirs[:, ns] = lambertian_directions(nrm[:, ns], 2. * N.pi * u1[ns], u2[ns], N.pi / 2.)
+        return [dict(sel=allsel, directions=dirs, energy=e * (1. - opt[0]), ref=ref.copy(), rid=rid)]
+    if opt_kind == OPT_REFRACTIVE_HOMOGENOUS:                    # :1226-1296 on :836-858
+        na, nb, single, sigma = opt[0], opt[1], opt[2] != 0., opt[3]
+        u0, u1 = philox.uniform_pair(seed, rid, event, 0)
+        u2, u3 = philox.uniform_pair(seed, rid, event, 1)
+        nrm = nrm.copy()
+        if sigma >= 0.:                                          # :1227-1239
+            g0, _ = philox.normal_pair(u0, u1)
+            th = sigma * g0
+            phi = 2. * N.pi * u2
+            err = N.vstack((N.sin(th) * N.cos(phi), N.sin(th) * N.sin(phi), N.cos(th)))
+            rots = rotation_to_z(nrm.T)
+            for i in range(H):
+                nrm[:, i] = N.dot(rots[i], err[:, i])
+        n1 = ref
+        n2 = N.where(n1 == na, nb, na)                           # :1217-1218
+        refr, out_dirs = refractions(n1, n2, d, nrm)
+        R = N.ones(H)
+        R[refr] = fresnel(d[:, refr], nrm[:, refr], n1[refr], n2[refr])
+        refl_dirs = reflections(d, nrm)
+        if single:                                               # :1254-1280
+            refl = u3 <= R
+            dirs_refr = N.zeros((3, H))
+            dirs_refr[:, refr] = out_dirs
+            blocks = []
+            if refl.any():
+                blocks.append(dict(sel=allsel[refl], directions=refl_dirs[:, refl], energy=e[refl], ref=ref[refl],
+                                   rid=rid[refl]))
+            if (~refl).any():
+                blocks.append(dict(sel=allsel[~refl], directions=dirs_refr[:, ~refl], energy=e[~refl], ref=n2[~refl],
+                                   rid=rid[~refl]))
+            return blocks
+        blocks = [dict(sel=allsel, directions=refl_dirs, energy=e * R, ref=ref.copy(), rid=rid)]      # :1284-1294
+        if refr.any():
+            blocks.append(dict(sel=allsel[refr], directions=out_dirs, energy=e[refr] * (1. - R[refr]), ref=n2[refr],
+                               rid=philox.child_rid(rid[refr], event)))
+        return blocks
+    raise ValueError(opt_kind)

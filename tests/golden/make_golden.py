@@ -1,0 +1,602 @@
+"""
+Generate the golden fixtures by running the REAL reference (casselineau/Tracer at /root/reference).
+
+Run in the build container only (the reference never travels):
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py
+It imports the reference unmodified (a 3-attribute stub stands in for the absent `shapely`, which only
+polygon sampling / polygon meshes touch -- SURVEY.md section 8(c)) next to the tracer_amd host classes, builds
+every case twice from the same constructor arguments (reference classes -> expected outputs; tracer_amd
+classes -> the parameter table that is the input of the oracle and of the C-ABI) and writes small .npz/.json
+files into tests/golden/.  A fixture is data: inputs and the reference's outputs.
+"""
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as N
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = '/root/reference'
+
+
+def import_reference():
+    stub = types.ModuleType('shapely')
+    stub.Polygon = stub.constrained_delaunay_triangles = stub.MultiPolygon = None
+    sys.modules.setdefault('shapely', stub)
+    sys.dont_write_bytecode = True
+    if REFERENCE not in sys.path:
+        sys.path.insert(0, REFERENCE)
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+
+
+class NS(object):
+    """The same module names in either package."""
+    def __init__(self, pkg):
+        self.pkg = pkg
+
+    def __getattr__(self, name):
+        return importlib.import_module(self.pkg + '.' + name)
+
+
+def rot(axis, ang):
+    import tracer_amd.spatial_geometry as sg
+    return sg.general_axis_rotation(N.asarray(axis, dtype=float) / N.linalg.norm(axis), ang)
+
+
+def frame_of(R, c):
+    f = N.eye(4)
+    f[:3, :3] = R
+    f[:3, 3] = c
+    return f
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 1. geometry: (frame, params, rays) -> (t, hit points, normals) for every native kind
+# ---------------------------------------------------------------------------------------------------------
+def gm_cases():
+    """(name, module, class, args, kwargs, scale): constructor arguments valid in both packages."""
+    tri = N.array([[1.2, 0.], [0.1, 0.9], [0., 0.]])
+    return [
+        ('flat', 'flat_surface', 'FlatGeometryManager', (), {}, 2.),
+        ('rect', 'flat_surface', 'RectPlateGM', (1.5, 0.8), {}, 1.5),
+        ('rect_extruded', 'flat_surface', 'ExtrudedRectPlateGM', (2., 1.6, N.c_[[0.2, -0.1]], 0.5, 0.4), {}, 1.5),
+        ('rect_perforated', 'flat_surface', 'PerforatedRectPlateGM',
+         (2., 2., N.array([[0.3, 0.3], [-0.4, 0.1], [0., -0.5]]), N.array([0.2, 0.15, 0.25])), {}, 1.5),
+        ('round', 'flat_surface', 'RoundPlateGM', (1.,), {}, 1.5),
+        ('annulus', 'flat_surface', 'RoundPlateGM', (1., 0.4), {}, 1.5),
+        ('round_cut', 'flat_surface', 'StraightCutRoundPlateGM', (1., 0.3), {}, 1.5),
+        ('triangle', 'triangular_face', 'TriangularFace', (tri,), {}, 1.5),
+        ('paraboloid', 'paraboloid', 'Paraboloid', (1.3, 0.9), {}, 1.5),
+        ('parab_dish', 'paraboloid', 'ParabolicDishGM', (2., 1.5), {}, 1.5),
+        ('parab_hex', 'paraboloid', 'HexagonalParabolicDishGM', (2., 1.5), {}, 1.5),
+        ('parab_rect', 'paraboloid', 'RectangularParabolicDishGM', (1.6, 1.2, 2.), {}, 1.5),
+        ('parab_rect_offaxis', 'paraboloid', 'RectangularParabolicDishGM', (1.0, 0.8, 3.),
+         {'off_axis_normal': N.array([N.sin(0.2) * N.cos(0.4), N.sin(0.2) * N.sin(0.4), N.cos(0.2)])}, 2.5),
+        ('parab_cyl', 'paraboloid', 'ParabolicCylinder', (1.2,), {}, 1.5),
+        ('parab_trough', 'paraboloid', 'ParabolicTroughGM', (2., 1., 3.), {}, 2.),
+        ('sphere', 'sphere_surface', 'SphericalGM', (1.1,), {}, 1.5),
+        ('hemisphere', 'sphere_surface', 'HemisphereGM', (1.1,), {}, 1.5),
+        ('sphere_rect', 'sphere_surface', 'SphericalRectFacet', (2., 1.2, 0.9), {}, 1.5),
+        ('cyl_inf', 'cylinder', 'InfiniteCylinder', (1.4,), {}, 1.5),
+        ('cyl_finite', 'cylinder', 'FiniteCylinder', (1.4, 2.), {}, 1.5),
+        ('cyl_finite_arc', 'cylinder', 'FiniteCylinder', (1.4, 2.), {'ang_range': [0.5, 4.0]}, 1.5),
+        ('cyl_rectcut', 'cylinder', 'RectCutCylinder', (1.4, 2., 1.2, 1.1), {}, 1.5),
+        ('cone_inf', 'cone', 'InfiniteCone', (0.7,), {'a': 0.3}, 1.5),
+        ('cone_finite', 'cone', 'FiniteCone', (0.8, 1.5), {}, 1.5),
+        ('frustum', 'cone', 'ConicalFrustum', (0.2, 0.5, 1.4, 1.1), {}, 1.5),
+        ('frustum_rectcut', 'cone', 'RectCutConicalFrustum', (0.2, 0.5, 1.4, 1.1, 1.2, 1.3), {}, 1.5),
+        ('quadratic', 'quadratic_surface', 'FlatQuadricSurfaceGM', (0.05, 0.08, 0.01, 0.02, -0.03, 0.1), {}, 1.5),
+        ('quadratic_rect', 'quadratic_surface', 'RectFlatQuadricSurfaceGM', (2., 1.5, 0.05, 0.08, 0.01, 0.02, -0.03, 0.1), {}, 1.5),
+        ('ellipsoid', 'ellipsoid', 'Ellipsoid', (1.2, 0.8, 1.5), {}, 1.5),
+        ('ellipsoid_cut', 'ellipsoid', 'EllipsoidGM', (1.2, 0.8, 1.5), {'xlim': [-0.5, 1.0], 'ylim': None, 'zlim': [-1., 0.7]}, 1.5),
+        ('ellipsoid_alllims', 'ellipsoid', 'EllipsoidGM', (1.2, 0.8, 1.5), {'xlim': [-0.5, 1.0], 'ylim': [-0.3, 0.3], 'zlim': [-1., 0.7]}, 1.5),
+    ]
+
+
+def ray_fan(rng, n, frame, scale):
+    """Rays aimed at points near the surface from outside, from inside (origin within the shape), grazing ones,
+    and a few exactly axis-parallel ones -- in global coordinates of `frame`."""
+    c = frame[:3, 3]
+    R = frame[:3, :3]
+    k = n // 4
+    targets = N.dot(R, (rng.uniform(-1., 1., size=(3, n)) * scale * N.array([[1.], [1.], [0.6]]))) + c[:, None]
+    origins = N.empty((3, n))
+    origins[:, :k] = N.dot(R, rng.uniform(-1, 1, size=(3, k)) * 4. * scale + N.array([[0.], [0.], [5. * scale]])) + c[:, None]   # above
+    origins[:, k:2 * k] = N.dot(R, rng.uniform(-1, 1, size=(3, k)) * 6. * scale) + c[:, None]                                  # around
+    origins[:, 2 * k:3 * k] = N.dot(R, rng.uniform(-0.3, 0.3, size=(3, k)) * scale) + c[:, None]                              # inside
+    graz = rng.uniform(-1, 1, size=(3, n - 3 * k)) * 5. * scale
+    graz[2] *= 0.02
+    origins[:, 3 * k:] = N.dot(R, graz) + c[:, None]                                                                         # grazing
+    d = targets - origins
+    d[:, -3:] = N.dot(R, N.array([[0., 0., 1.], [1., 0., 0.], [0., 0., -1.]]).T)      # exactly along local axes
+    d /= N.sqrt(N.sum(d ** 2, axis=0))
+    return origins, d
+
+
+def make_geometry(ref, amd, out):
+    rng = N.random.RandomState(20240601)
+    frames = [N.eye(4),
+              frame_of(rot([1, 2, 3], 0.7), [0.5, -1.0, 2.0]),
+              frame_of(rot([-1, 0.5, 0.2], 2.4), [-30., 12., 7.])]
+    index = []
+    ci = 0
+    for name, mod, cls, args, kwargs, scale in gm_cases():
+        for fi, frame in enumerate(frames):
+            gm_ref = getattr(getattr(ref, mod), cls)(*args, **kwargs)
+            gm_amd = getattr(getattr(amd, mod), cls)(*args, **kwargs)
+            kind, params, extra = gm_amd._native()
+            v, d = ray_fan(rng, 240, frame, scale)
+            if cls in ('HemisphereGM', 'SphericalRectFacet'):
+                # Reference defect: these two classes assign the chosen root with
+                # `N.nonzero(mask[:, one_hit])[0]` (sphere_surface.py:137, :227), which lists the root indices
+                # sorted, not per ray -- in a bundle where some rays keep root 0 and others root 1 the choices are
+                # shuffled between rays.  One ray at a time the same code is well defined, so that is how the
+                # expected values are produced here.
+                t = N.empty(v.shape[1])
+                normals = []
+                pts = []
+                for r in range(v.shape[1]):
+                    b1 = ref.ray_bundle.RayBundle(vertices=v[:, r:r + 1].copy(), directions=d[:, r:r + 1].copy())
+                    with N.errstate(all='ignore'):
+                        t[r] = gm_ref.find_intersections(frame, b1)[0]
+                        if N.isfinite(t[r]):
+                            gm_ref.select_rays(N.array([0]))
+                            normals.append(N.array(gm_ref.get_normals()))
+                            pts.append(N.array(gm_ref.get_intersection_points_global()))
+                    gm_ref.done()
+                    if hasattr(gm_ref, '_params'):
+                        del gm_ref._params
+                hit_idx = N.nonzero(N.isfinite(t))[0]
+                normals = N.hstack(normals) if normals else N.zeros((3, 0))
+                pts = N.hstack(pts) if pts else N.zeros((3, 0))
+            else:
+                bund = ref.ray_bundle.RayBundle(vertices=v.copy(), directions=d.copy())
+                with N.errstate(all='ignore'):
+                    t = N.array(gm_ref.find_intersections(frame, bund), dtype=float)
+                    hit_idx = N.nonzero(N.isfinite(t))[0]
+                    gm_ref.select_rays(hit_idx)
+                    normals = N.array(gm_ref.get_normals()) if len(hit_idx) else N.zeros((3, 0))
+                    pts = N.array(gm_ref.get_intersection_points_global()) if len(hit_idx) else N.zeros((3, 0))
+                gm_ref.done()
+            pre = 'g%d_' % ci
+            gm16 = N.zeros(16)
+            gm16[:len(params)] = params
+            out[pre + 'kind'] = N.int32(kind)
+            out[pre + 'frame'] = frame
+            out[pre + 'gm'] = gm16
+            out[pre + 'extra'] = N.asarray(extra, dtype=float)
+            out[pre + 'v'] = v
+            out[pre + 'd'] = d
+            out[pre + 't'] = t
+            out[pre + 'hit_idx'] = hit_idx
+            out[pre + 'hits'] = pts
+            out[pre + 'normals'] = normals
+            index.append('%s/frame%d' % (name, fi))
+            ci += 1
+    out['n_cases'] = N.int32(ci)
+    out['names'] = N.array(index)
+    print('geometry: %d cases' % ci)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 2. optics with replayed variates
+# ---------------------------------------------------------------------------------------------------------
+class FakeGeometry(object):
+    """What an optics callable asks of its geometry manager."""
+    def __init__(self, frame, normals, points):
+        self._working_frame = frame
+        self._n = normals
+        self._p = points
+
+    def get_normals(self):
+        return self._n.copy()
+
+    def get_intersection_points_global(self):
+        return self._p
+
+    def up(self):
+        return self._working_frame[:3, 2]
+
+
+def make_optics(ref, amd, out):
+    rng = N.random.RandomState(77)
+    H = 64
+    frame = frame_of(rot([0.3, -1, 0.5], 1.1), [1., 2., 3.])
+    up = frame[:3, 2]
+    # normals scattered around `up` (and its opposite), unit incident directions with both orientations
+    nrm = up[:, None] + 0.6 * rng.normal(size=(3, H))
+    nrm /= N.sqrt(N.sum(nrm ** 2, axis=0))
+    nrm[:, :3] = N.array([[0., 0., 1.], [0., 0., -1.], [1., 0., 0.]]).T      # the degenerate frames of rotation_to_z / z x n
+    d = rng.normal(size=(3, H))
+    d /= N.sqrt(N.sum(d ** 2, axis=0))
+    flip = N.sum(d * nrm, axis=0) > 0
+    nrm[:, flip] *= -1         # oriented normals oppose the ray, as get_normals() returns them
+    pts = rng.uniform(-1, 1, size=(3, H))
+    e = rng.uniform(0.5, 2., size=H)
+    wl = rng.uniform(0.3e-6, 2.5e-6, size=H)
+    sel = N.arange(H)
+    oc = ref.optics_callables
+    cases = []
+
+    def run(name, opt_ref, opt_amd, ref_index=None, draws=None, wavelengths=None):
+        kw = {}
+        if ref_index is not None:
+            kw['ref_index'] = ref_index
+        if wavelengths is not None:
+            kw['wavelengths'] = wavelengths
+        bund = ref.ray_bundle.RayBundle(vertices=pts - d, directions=d.copy(), energy=e.copy(), **kw)
+        geo = FakeGeometry(frame, nrm, pts)
+        N.random.seed(len(cases) + 5)
+        with N.errstate(all='ignore'):
+            outg = opt_ref(geo, bund, sel)
+        N.random.seed(len(cases) + 5)
+        rec = draws() if draws else {}
+        kind, params, extra = opt_amd._native()
+        pre = 'o%d_' % len(cases)
+        p8 = N.zeros(8)
+        p8[:len(params)] = params
+        out[pre + 'kind'] = N.int32(kind)
+        out[pre + 'opt'] = p8
+        out[pre + 'extra'] = N.asarray(extra, dtype=float)
+        out[pre + 'ref_in'] = N.ones(H) if ref_index is None else ref_index
+        out[pre + 'out_dirs'] = outg.get_directions()
+        out[pre + 'out_energy'] = outg.get_energy()
+        out[pre + 'out_parents'] = N.asarray(outg.get_parents())
+        out[pre + 'out_vertices'] = outg.get_vertices()
+        if ref_index is not None:
+            out[pre + 'out_ref'] = N.asarray(outg.get_ref_index(), dtype=float)
+        for k, val in rec.items():
+            out[pre + 'draw_' + k] = val
+        cases.append(name)
+
+    A = amd.optics_callables
+    run('transparent', oc.Transparent(), A.Transparent())
+    run('reflective', oc.Reflective(0.1), A.Reflective(0.1))
+    run('one_sided_reflective', oc.OneSidedReflective(0.2), A.OneSidedReflective(0.2))
+    run('real_reflective_bivar', oc.RealReflective(0.05, 3e-3, True), A.RealReflective(0.05, 3e-3, True),
+        draws=lambda: dict(g0=N.random.normal(scale=3e-3, size=H), g1=N.random.normal(scale=3e-3, size=H)))
+    run('real_reflective_radial', oc.RealReflective(0.05, 3e-3, False), A.RealReflective(0.05, 3e-3, False),
+        draws=lambda: dict(g0=N.random.normal(scale=3e-3, size=H), phi=N.random.uniform(low=0., high=2. * N.pi, size=H)))
+    run('real_reflective_sigma0', oc.RealReflective(0.05, 0., True), A.RealReflective(0.05, 0., True))
+    run('one_sided_real_reflective', oc.OneSidedRealReflective(0.04, 1e-3, True), A.OneSidedRealReflective(0.04, 1e-3, True),
+        draws=lambda: dict(g0=N.random.normal(scale=1e-3, size=H), g1=N.random.normal(scale=1e-3, size=H)))
+    run('lambertian', oc.Lambertian(0.3), A.Lambertian(0.3),
+        draws=lambda: dict(xi1=N.random.uniform(low=0., high=2. * N.pi, size=H), xi2=N.random.uniform(size=H)))
+    run('lambertian_narrow', oc.Lambertian(0.3, 0.4), A.Lambertian(0.3, 0.4),
+        draws=lambda: dict(xi1=N.random.uniform(low=0., high=2. * N.pi, size=H), xi2=N.random.uniform(size=H)))
+
+    def ls_draws():
+        u = N.random.rand(H)
+        k = int(N.sum(~(u < 0.4)))
+        return dict(u=u, xi1=N.random.uniform(low=0., high=2. * N.pi, size=k), xi2=N.random.uniform(size=k))
+    run('lambertian_specular', oc.LambertianSpecular(0.1, 0.4), A.LambertianSpecular(0.1, 0.4), draws=ls_draws)
+    n_in = N.where(N.arange(H) % 2 == 0, 1.0, 1.5)
+    run('refractive_split', oc.RefractiveHomogenous(1.0, 1.5, single_ray=False), A.RefractiveHomogenous(1.0, 1.5, single_ray=False),
+        ref_index=n_in)
+    run('refractive_single', oc.RefractiveHomogenous(1.0, 1.5, single_ray=True), A.RefractiveHomogenous(1.0, 1.5, single_ray=True),
+        ref_index=N.ones(H) * 1.5, draws=lambda: dict(u=N.random.uniform(size=H)))
+    run('refractive_split_sigma', oc.RefractiveHomogenous(1.0, 1.33, single_ray=False, sigma=2e-3),
+        A.RefractiveHomogenous(1.0, 1.33, single_ray=False, sigma=2e-3), ref_index=N.ones(H),
+        draws=lambda: dict(g0=N.random.normal(scale=2e-3, size=H), phi=N.random.uniform(low=0., high=2. * N.pi, size=H)))
+    lam = N.linspace(0.2e-6, 3e-6, 9)
+    ab = N.array([0.1, 0.2, 0.15, 0.4, 0.9, 0.5, 0.3, 0.2, 0.25])
+    run('reflective_spectral', oc.Reflective_spectral(ab, lam), A.Reflective_spectral(ab, lam), wavelengths=wl)
+
+    out['n_cases'] = N.int32(len(cases))
+    out['names'] = N.array(cases)
+    out['frame'] = frame
+    out['normals'] = nrm
+    out['dirs'] = d
+    out['points'] = pts
+    out['energy'] = e
+    out['wavelengths'] = wl
+    print('optics: %d cases' % len(cases))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 3. sources with replayed variates
+# ---------------------------------------------------------------------------------------------------------
+def desc_arrays(bundle):
+    d = bundle.source_args()[0]
+    return dict(kind=N.int32(d.kind), center=N.array(list(d.center)), rot_pos=N.array(list(d.rot_pos)).reshape(3, 3),
+                rot_dir=N.array(list(d.rot_dir)).reshape(3, 3), p=N.array(list(d.p)), energy=N.float64(d.energy),
+                buie=N.array(list(d.buie)))
+
+
+def make_sources(ref, amd, out):
+    n = 1500
+    cases = []
+    S = ref.sources
+    A = amd.sources
+
+    def store(name, bund_ref, bund_amd, uniforms):
+        pre = 's%d_' % len(cases)
+        for k, val in desc_arrays(bund_amd).items():
+            out[pre + 'desc_' + k] = val
+        for i, u in enumerate(uniforms):
+            out[pre + 'u%d' % i] = u
+        out[pre + 'vertices'] = bund_ref.get_vertices()
+        out[pre + 'directions'] = bund_ref.get_directions()
+        out[pre + 'energy'] = bund_ref.get_energy()
+        cases.append(name)
+
+    sun = N.array([0., N.sin(0.6), N.cos(0.6)])
+    centre = N.c_[[10., 250., 200.]]
+    for name, csr, pre_csr in (('buie_csr0.01_raw', 0.01, False), ('buie_csr0.05', 0.05, True), ('buie_csr0.3', 0.3, True),
+                               ('buie_csr0', 0., True)):
+        N.random.seed(11)
+        b = S.buie_sunshape(n, centre, -sun, 163., csr, flux=1000., pre_process_CSR=pre_csr)
+        N.random.seed(11)
+        xv1 = N.random.uniform(size=n)
+        phiv = N.random.uniform(high=2. * N.pi, size=n)
+        R = N.random.uniform(size=n)
+        xi = N.random.uniform(high=2. * N.pi, size=n)
+        store(name, b, A.buie_sunshape(n, centre, -sun, 163., csr, flux=1000., pre_process_CSR=pre_csr, seed=1),
+              (xv1, phiv / (2. * N.pi), R, xi / (2. * N.pi)))
+    # straight down (degenerate rotation_to_z frame); NB the reference's buie_sunshape cannot take an array
+    # rays_direction (`== None` on an array, sources.py:441) -- the oblique case is covered by rect_buie below
+    N.random.seed(12)
+    b = S.buie_sunshape(n, N.c_[[0., 0., 6.]], N.r_[0., 0., -1.], 2.5, 0.05, flux=1000.)
+    N.random.seed(12)
+    xv1 = N.random.uniform(size=n); phiv = N.random.uniform(high=2. * N.pi, size=n); R = N.random.uniform(size=n); xi = N.random.uniform(high=2. * N.pi, size=n)
+    store('buie_down', b, A.buie_sunshape(n, N.c_[[0., 0., 6.]], N.r_[0., 0., -1.], 2.5, 0.05, flux=1000., seed=1),
+          (xv1, phiv / (2. * N.pi), R, xi / (2. * N.pi)))
+    N.random.seed(17)
+    rd = N.r_[0.1, 0., -0.99498743710662]
+    b = S.rect_buie_sunshape(n, N.c_[[0., 0., 6.]], N.r_[0., 0., -1.], 3., 2., 0.02, flux=1000., rays_direction=rd)
+    N.random.seed(17)
+    ux = N.random.uniform(size=n); uy = N.random.uniform(size=n); R = N.random.uniform(size=n); xi = N.random.uniform(high=2. * N.pi, size=n)
+    store('rect_buie_oblique', b, A.rect_buie_sunshape(n, N.c_[[0., 0., 6.]], N.r_[0., 0., -1.], 3., 2., 0.02, flux=1000., rays_direction=rd, seed=1),
+          (ux, uy, R, xi / (2. * N.pi)))
+    N.random.seed(13)
+    b = S.rect_buie_sunshape(n, centre, -sun, 30., 20., 0.1, flux=900.)
+    N.random.seed(13)
+    ux = N.random.uniform(size=n); uy = N.random.uniform(size=n); R = N.random.uniform(size=n); xi = N.random.uniform(high=2. * N.pi, size=n)
+    store('rect_buie', b, A.rect_buie_sunshape(n, centre, -sun, 30., 20., 0.1, flux=900., seed=1), (ux, uy, R, xi / (2. * N.pi)))
+    for name, direction in (('rect_bundle', N.r_[-0.15, 0., -1.] / N.sqrt(1.0225)), ('rect_bundle_down', N.r_[0., 0., -1.])):
+        N.random.seed(14)
+        b = S.rect_bundle(n, N.c_[[1., 2., 5.]], direction, 2., 3., 4.65e-3, flux=1000.)
+        N.random.seed(14)
+        xi1 = N.random.uniform(low=0., high=2. * N.pi, size=n); xi2 = N.random.uniform(size=n)
+        xs = N.random.uniform(low=-1., high=1., size=n); ys = N.random.uniform(low=-1.5, high=1.5, size=n)
+        store(name, b, A.rect_bundle(n, N.c_[[1., 2., 5.]], direction, 2., 3., 4.65e-3, flux=1000., seed=1),
+              (xi1 / (2. * N.pi), xi2, (xs + 1.) / 2., (ys + 1.5) / 3.))
+    N.random.seed(15)
+    b = S.disk_bundle(n, N.c_[[0., 1., 4.]], N.r_[0., N.sin(0.3), -N.cos(0.3)], 1.5, 0.02, flux=800., radius_in=0.3)
+    N.random.seed(15)
+    xi1 = N.random.uniform(low=0., high=2. * N.pi, size=n); xi2 = N.random.uniform(size=n)
+    r1 = N.random.uniform(size=n); th = N.random.uniform(low=0., high=2. * N.pi, size=n)
+    store('disk_bundle', b, A.disk_bundle(n, N.c_[[0., 1., 4.]], N.r_[0., N.sin(0.3), -N.cos(0.3)], 1.5, 0.02, flux=800., radius_in=0.3, seed=1),
+          (xi1 / (2. * N.pi), xi2, r1, th / (2. * N.pi)))
+    N.random.seed(16)
+    b = S.disk_bundle(n, N.c_[[0., 0., 0.]], N.r_[0., 0., 1.], 1., N.pi / 2.)
+    N.random.seed(16)
+    xi1 = N.random.uniform(low=0., high=2. * N.pi, size=n); xi2 = N.random.uniform(size=n)
+    r1 = N.random.uniform(size=n); th = N.random.uniform(low=0., high=2. * N.pi, size=n)
+    store('disk_bundle_lambertian_noflux', b, A.disk_bundle(n, N.c_[[0., 0., 0.]], N.r_[0., 0., 1.], 1., N.pi / 2., seed=1),
+          (xi1 / (2. * N.pi), xi2, r1, th / (2. * N.pi)))
+    out['n_cases'] = N.int32(len(cases))
+    out['names'] = N.array(cases)
+    print('sources: %d cases' % len(cases))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 4. deterministic end-to-end scenes traced by the reference engine
+# ---------------------------------------------------------------------------------------------------------
+def scene_two_planes(T):
+    """tests/test_tracer_engine.py TestTraceProtocol-like: two perpendicular absorbing mirrors"""
+    s1 = T.surface.Surface(T.flat_surface.FlatGeometryManager(), T.optics_callables.Reflective(0.1))
+    s2 = T.surface.Surface(T.flat_surface.FlatGeometryManager(), T.optics_callables.Reflective(0.2),
+                           rotation=T.spatial_geometry.general_axis_rotation(N.r_[1., 0., 0.], N.pi / 2.))
+    o1 = T.object.AssembledObject(surfs=[s1])
+    o2 = T.object.AssembledObject(surfs=[s2], location=N.r_[0., 1., 0.])
+    return T.assembly.Assembly(objects=[o1, o2])
+
+
+def scene_mixed(T):
+    """plates, a dish, a hemisphere, a cylinder and a cone around the origin, mirrors of various kinds (sigma=0)"""
+    O = T.optics_callables
+    sg = T.spatial_geometry
+    objs = []
+    objs.append(T.object.AssembledObject(surfs=[T.surface.Surface(T.flat_surface.RectPlateGM(3., 3.), O.Reflective(0.05))],
+                                         transform=sg.translate(0, 0, -2.)))
+    objs.append(T.object.AssembledObject(surfs=[T.surface.Surface(T.paraboloid.ParabolicDishGM(3., 2.), O.RealReflective(0.1, 0., True))],
+                                         transform=N.dot(sg.translate(0, 0, 3.), sg.rotx(N.pi))))
+    objs.append(T.object.AssembledObject(surfs=[T.surface.Surface(T.sphere_surface.HemisphereGM(1.5), O.Reflective(0.3))],
+                                         transform=N.dot(sg.translate(3., 0, 0.), sg.roty(N.pi / 2.))))
+    objs.append(T.object.AssembledObject(surfs=[T.surface.Surface(T.cylinder.FiniteCylinder(1., 2.), O.OneSidedReflective(0.2))],
+                                         transform=N.dot(sg.translate(-3., 0.5, 0.), sg.rotx(0.4))))
+    objs.append(T.object.AssembledObject(surfs=[T.surface.Surface(T.cone.ConicalFrustum(0., 0.5, 1., 1.2), O.Reflective(0.5))],
+                                         transform=sg.translate(0., 3., -0.5)))
+    objs.append(T.object.AssembledObject(surfs=[T.surface.Surface(T.flat_surface.RoundPlateGM(1.2), O.Reflective(0.97))],
+                                         transform=N.dot(sg.translate(0., -3., 0.), sg.rotx(-N.pi / 2.))))
+    sub = T.assembly.Assembly(objects=objs[3:], location=N.r_[0.1, 0.2, 0.3], rotation=sg.rotz(0.3)[:3, :3])
+    return T.assembly.Assembly(objects=objs[:3], subassemblies=[sub])
+
+
+def scene_lens(T):
+    """plano-convex lens: paraboloidal cap over a round plate, split-mode refraction, mirror behind.
+    (A HemisphereGM cap is avoided on purpose: with rays crossing it in both directions in one bundle the
+    reference's root assignment gets shuffled between rays, see make_geometry.)"""
+    O = T.optics_callables
+    sg = T.spatial_geometry
+    h = (2. / (2. * N.sqrt(1.5))) ** 2
+    front = T.surface.Surface(T.paraboloid.ParabolicDishGM(4., 1.5), O.RefractiveHomogenous(1., 1.5, single_ray=False),
+                              location=N.r_[0., 0., h], rotation=sg.rotx(N.pi)[:3, :3])
+    back = T.surface.Surface(T.flat_surface.RoundPlateGM(2.), O.RefractiveHomogenous(1., 1.5, single_ray=False))
+    lens = T.object.AssembledObject(surfs=[front, back], transform=sg.translate(0, 0, 1.))
+    mirror = T.object.AssembledObject(surfs=[T.surface.Surface(T.flat_surface.RectPlateGM(6., 6.), O.Reflective(0.9))],
+                                      transform=sg.translate(0, 0, -4.))
+    return T.assembly.Assembly(objects=[lens, mirror])
+
+
+def scene_nsttf(T, n_hel, with_bounds=True):
+    pos = N.loadtxt(os.path.join(REFERENCE, 'examples', 'sandia_hstat_coordinates.csv'), delimiter=',')
+    pos[:, 1] -= 4.
+    if n_hel:
+        pos = pos[:n_hel]
+    hf = importlib.import_module(T.pkg + '.models.heliostat_field')
+    osm = importlib.import_module(T.pkg + '.models.one_sided_mirror')
+    field = hf.HeliostatField(pos, 6.1, 6.1, absorptivity=0.04, sigma=0., bi_var=True, MCRT_option='fast')
+    aim = N.tile(N.array([0., 0., 60.]), (pos.shape[0], 1))
+    field.track_sun(0., 35.05 * N.pi / 180., aim_points=aim)
+    rec = osm.one_sided_receiver(11., 11.)
+    rec.set_transform(N.dot(T.spatial_geometry.translate(0., 0., 60.), T.spatial_geometry.rotx(-N.pi / 2.)))
+    return T.assembly.Assembly(objects=[rec], subassemblies=[field])
+
+
+def tree_arrays(engine, out, pre):
+    tree = engine.tree
+    out[pre + 'n_levels'] = N.int32(tree.num_bunds())
+    for k in range(tree.num_bunds()):
+        b = tree[k]
+        out[pre + 'L%d_vertices' % k] = b.get_vertices()
+        out[pre + 'L%d_directions' % k] = b.get_directions()
+        out[pre + 'L%d_energy' % k] = b.get_energy()
+        if k > 0:
+            out[pre + 'L%d_parents' % k] = N.asarray(b.get_parents(), dtype=N.int64)
+        if b.has_property('ref_index') and hasattr(b, '_ref_index') and b._ref_index is not None and k > 0:
+            try:
+                out[pre + 'L%d_ref_index' % k] = N.asarray(b.get_ref_index(), dtype=float)
+            except Exception:
+                pass
+
+
+def make_engine(ref, amd, out):
+    from tracer_amd.scene import compile_scene, scene_arrays
+    rng = N.random.RandomState(5)
+    cases = []
+
+    def run(name, builder, v, d, e, reps, min_energy, accel=False, ref_index=None, **bkw):
+        asm_ref = builder(ref, **bkw)
+        asm_amd = builder(amd, **bkw)
+        pre = 'e%d_' % len(cases)
+        for k, val in scene_arrays(compile_scene(asm_amd)).items():
+            out[pre + 'scene_' + k] = val
+        kw = {}
+        if ref_index is not None:
+            kw['ref_index'] = ref_index
+        bund = ref.ray_bundle.RayBundle(vertices=v.copy(), directions=d.copy(), energy=e.copy(), **kw)
+        eng = ref.tracer_engine.TracerEngine(asm_ref)
+        with N.errstate(all='ignore'):
+            lv, ld = eng.ray_tracer(bund, reps=reps, min_energy=min_energy, tree=True, accel=accel)
+        out[pre + 'v'] = v
+        out[pre + 'd'] = d
+        out[pre + 'e'] = e
+        if ref_index is not None:
+            out[pre + 'ref_index'] = ref_index
+        out[pre + 'reps'] = N.int32(reps)
+        out[pre + 'min_energy'] = N.float64(min_energy)
+        out[pre + 'accel'] = N.int32(1 if accel else 0)
+        out[pre + 'last_vertices'] = lv
+        out[pre + 'last_directions'] = ld
+        tree_arrays(eng, out, pre)
+        # accountants of the last surface, if any
+        surfs = asm_ref.get_surfaces()
+        for si, s in enumerate(surfs):
+            o = s.get_optics_manager()
+            if hasattr(o, 'get_all_hits'):
+                for ai, arr in enumerate(o.get_all_hits()):
+                    out[pre + 'acc_s%d_%d' % (si, ai)] = N.asarray(arr)
+        cases.append(name)
+        print('  engine case %s: levels %s' % (name, [eng.tree[k].get_num_rays() for k in range(eng.tree.num_bunds())]))
+
+    # (a) two planes, the classic four rays + extras
+    n = 12
+    d = N.tile(N.r_[0., 1. / N.sqrt(2.), -1. / N.sqrt(2.)][:, None], (1, n))
+    v = N.vstack((rng.uniform(-1, 1, n), rng.uniform(-2., 0.5, n), N.ones(n) * 1.))
+    run('two_planes', scene_two_planes, v, d, N.ones(n), reps=6, min_energy=0.05)
+    # (b) mixed scene, many bounces, culling in play
+    n = 600
+    v = rng.uniform(-0.5, 0.5, size=(3, n))
+    d = rng.normal(size=(3, n))
+    d /= N.sqrt(N.sum(d ** 2, axis=0))
+    run('mixed', scene_mixed, v, d, rng.uniform(0.5, 1.5, n), reps=12, min_energy=0.05)
+    run('mixed_reps3', scene_mixed, v, d, rng.uniform(0.5, 1.5, n), reps=3, min_energy=1e-10)
+    # (c) lens with ray splitting
+    n = 80
+    v = N.vstack((rng.uniform(-1.2, 1.2, n), rng.uniform(-1.2, 1.2, n), N.ones(n) * 6.))
+    d = N.vstack((rng.normal(scale=0.03, size=n), rng.normal(scale=0.03, size=n), -N.ones(n)))
+    d /= N.sqrt(N.sum(d ** 2, axis=0))
+    run('lens_split', scene_lens, v, d, N.ones(n), reps=5, min_energy=1e-3, ref_index=N.ones(n))
+    # (d) NSTTF subset with deterministic mirrors, brute force and Kd-tree
+    N.random.seed(3)
+    sun = N.r_[0., N.sin(35.05 * N.pi / 180.), N.cos(35.05 * N.pi / 180.)]
+    src = ref.sources.buie_sunshape(3000, N.vstack(300. * sun + N.r_[0., 80., 0.]), -sun, 60., 0.01, flux=1000., pre_process_CSR=False)
+    v, d, e = src.get_vertices(), src.get_directions(), src.get_energy()
+    run('nsttf30', scene_nsttf, v, d, e, reps=100, min_energy=1e-10, n_hel=30)
+    run('nsttf30_accel', scene_nsttf, v, d, e, reps=100, min_energy=1e-10, accel=True, n_hel=30)
+    out['n_cases'] = N.int32(len(cases))
+    out['names'] = N.array(cases)
+    print('engine: %d cases' % len(cases))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 5. Kd-tree of the full NSTTF field, 6. accountant naming table
+# ---------------------------------------------------------------------------------------------------------
+def make_kdtree(ref, out):
+    for tag, fast in (('', False), ('fast_', True)):
+        asm = scene_nsttf(ref, None)
+        S = len(asm.get_surfaces())
+        kd = ref.accel_tree.KdTree(asm, 8 + 1.3 * N.log(S), fast=fast, min_leaf=1)
+        n = len(kd.nodes)
+        flag = N.array([nd.flag for nd in kd.nodes], dtype=N.int32)
+        split = N.array([nd.split if nd.flag != 3 else 0. for nd in kd.nodes], dtype=float)
+        child = N.array([nd.child if nd.flag != 3 else 0 for nd in kd.nodes], dtype=N.int32)
+        leaf_off, leaf_cnt, leaf_surfs = [], [], []
+        for nd in kd.nodes:
+            if nd.flag == 3:
+                s = sorted(set(int(x) for arr in nd.surfaces_idxs for x in N.ravel(arr)))
+                leaf_off.append(len(leaf_surfs)); leaf_cnt.append(len(s)); leaf_surfs.extend(s)
+            else:
+                leaf_off.append(0); leaf_cnt.append(0)
+        out[tag + 'flag'] = flag
+        out[tag + 'split'] = split
+        out[tag + 'child'] = child
+        out[tag + 'leaf_off'] = N.array(leaf_off, dtype=N.int32)
+        out[tag + 'leaf_cnt'] = N.array(leaf_cnt, dtype=N.int32)
+        out[tag + 'leaf_surfs'] = N.array(leaf_surfs, dtype=N.int32)
+        out[tag + 'always_relevant'] = N.asarray(kd.always_relevant, dtype=N.int32)
+        out[tag + 'minpoint'] = N.ravel(kd.minpoint)
+        out[tag + 'maxpoint'] = N.ravel(kd.maxpoint)
+        print('kdtree%s: %d nodes, %d leaves' % (' (fast)' if fast else '', n, int((flag == 3).sum())))
+
+
+def make_accountant_names(ref):
+    oc = ref.optics_callables
+    table = {}
+    for name in dir(oc):
+        if not name.startswith('Reflective') or name.startswith('Reflective_'):
+            continue
+        cls = getattr(oc, name)
+        if not isinstance(cls, type) or name == 'Reflective':
+            continue
+        inst = cls(0.1)
+        table[name[len('Reflective'):]] = [type(a).__name__ for a in inst.accountants]
+    return table
+
+
+def main():
+    import_reference()
+    ref = NS('tracer')
+    amd = NS('tracer_amd')
+    for fname, maker in (('geometry.npz', make_geometry), ('optics.npz', make_optics), ('sources.npz', make_sources),
+                         ('engine.npz', make_engine)):
+        out = {}
+        maker(ref, amd, out)
+        N.savez_compressed(os.path.join(HERE, fname), **out)
+    out = {}
+    make_kdtree(ref, out)
+    N.savez_compressed(os.path.join(HERE, 'kdtree_nsttf.npz'), **out)
+    with open(os.path.join(HERE, 'accountant_names.json'), 'w') as f:
+        json.dump(make_accountant_names(ref), f, indent=0, sort_keys=True)
+    for fn in sorted(os.listdir(HERE)):
+        print('%-28s %8d bytes' % (fn, os.path.getsize(os.path.join(HERE, fn))))
+
+
+if __name__ == '__main__':
+    main()

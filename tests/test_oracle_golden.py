@@ -1,0 +1,210 @@
+"""
+Pins the oracle (oracle/, the CPU restatement) against fixtures produced by the REAL reference
+(tests/golden/make_golden.py).  CPU only.
+"""
+import json
+import os
+
+import numpy as N
+import pytest
+
+from oracle import geometry, optics, sources, engine, kinds
+from helpers import load, case_names, oracle_scene, source_dict, GOLDEN
+
+TOL = dict(rtol=1e-9, atol=1e-9)
+
+
+def test_geometry_all_kinds():
+    g = load('geometry.npz')
+    names = case_names(g)
+    seen = set()
+    for ci in range(int(g['n_cases'])):
+        pre = 'g%d_' % ci
+        kind = int(g[pre + 'kind'])
+        seen.add(kind)
+        t = geometry.intersect(kind, g[pre + 'frame'], list(g[pre + 'gm']), g[pre + 'extra'], g[pre + 'v'], g[pre + 'd'])
+        t_ref = g[pre + 't']
+        assert N.array_equal(N.isfinite(t), N.isfinite(t_ref)), names[ci]
+        idx = g[pre + 'hit_idx']
+        assert N.allclose(t[idx], t_ref[idx], **TOL), names[ci]
+        if len(idx):
+            pts = g[pre + 'v'][:, idx] + t[idx] * g[pre + 'd'][:, idx]
+            assert N.allclose(pts, g[pre + 'hits'], **TOL), names[ci]
+            nrm = geometry.normals(kind, g[pre + 'frame'], list(g[pre + 'gm']), g[pre + 'hits'], g[pre + 'd'][:, idx])
+            ok = N.all(N.isclose(nrm, g[pre + 'normals'], **TOL) | (N.isnan(nrm) & N.isnan(g[pre + 'normals'])), axis=0)
+            assert ok.all(), (names[ci], N.nonzero(~ok)[0][:5])
+    assert seen == set(range(28)), "every native geometry kind has a fixture"
+    assert sum(int(N.isfinite(g['g%d_t' % ci]).sum()) for ci in range(int(g['n_cases']))) > 5000
+
+
+def _optics_case(o, name):
+    names = case_names(o)
+    i = names.index(name)
+    return 'o%d_' % i
+
+
+def test_optics_variate_replay():
+    o = load('optics.npz')
+    frame, nrm, d, pts, e, wl = o['frame'], o['normals'], o['dirs'], o['points'], o['energy'], o['wavelengths']
+    H = d.shape[1]
+    up = frame[:3, 2]
+
+    def check(pre, dirs, energy, parents=None, ref=None):
+        assert N.allclose(dirs, o[pre + 'out_dirs'], **TOL), pre
+        assert N.allclose(energy, o[pre + 'out_energy'], **TOL), pre
+        if parents is not None:
+            assert N.array_equal(parents, o[pre + 'out_parents']), pre
+        if ref is not None:
+            assert N.allclose(ref, o[pre + 'out_ref'], **TOL), pre
+
+    # deterministic kinds go through shade() itself
+    rid = N.arange(H, dtype=N.uint64)
+    for name in ('transparent', 'reflective', 'one_sided_reflective', 'real_reflective_sigma0', 'reflective_spectral',
+                 'refractive_split'):
+        pre = _optics_case(o, name)
+        blocks = optics.shade(int(o[pre + 'kind']), list(o[pre + 'opt']), o[pre + 'extra'], up, d, e, o[pre + 'ref_in'], wl, nrm, 1, rid, 1)
+        dirs = N.hstack([b['directions'] for b in blocks])
+        en = N.hstack([b['energy'] for b in blocks])
+        par = N.hstack([b['sel'] for b in blocks])
+        ref = N.hstack([b['ref'] for b in blocks]) if (pre + 'out_ref') in o.files else None
+        check(pre, dirs, en, par, ref)
+        assert N.allclose(o[pre + 'out_vertices'], pts[:, par], **TOL)
+    # slope error: replay numpy's normal / uniform draws
+    for name, bi, onesided in (('real_reflective_bivar', True, False), ('real_reflective_radial', False, False),
+                               ('one_sided_real_reflective', True, True)):
+        pre = _optics_case(o, name)
+        absorb, sigma = o[pre + 'opt'][0], o[pre + 'opt'][1]
+        g0 = o[pre + 'draw_g0'] / sigma
+        g1 = o[pre + 'draw_g1'] / sigma if bi else N.zeros(H)
+        u = o[pre + 'draw_phi'] / (2. * N.pi) if not bi else N.zeros(H)
+        real = optics.slope_error_normals(nrm, sigma, bi, g0, g1, u)
+        en = e * (1. - absorb)
+        if onesided:
+            en = en.copy()
+            en[N.sum(d * up[:, None], axis=0) > 0] = 0
+        check(pre, optics.reflections(d, real), en, N.arange(H))
+    for name in ('lambertian', 'lambertian_narrow'):
+        pre = _optics_case(o, name)
+        dirs = optics.lambertian_directions(nrm, o[pre + 'draw_xi1'], o[pre + 'draw_xi2'], o[pre + 'opt'][1])
+        check(pre, dirs, e * (1. - o[pre + 'opt'][0]), N.arange(H))
+    pre = _optics_case(o, 'lambertian_specular')
+    spec = o[pre + 'draw_u'] < o[pre + 'opt'][1]
+    dirs = N.zeros((3, H))
+    dirs[:, spec] = optics.reflections(d[:, spec], nrm[:, spec])
+    dirs[:, ~spec] = optics.lambertian_directions(nrm[:, ~spec], o[pre + 'draw_xi1'], o[pre + 'draw_xi2'], N.pi / 2.)
+    check(pre, dirs, e * (1. - o[pre + 'opt'][0]), N.arange(H))
+    # single-ray refraction: replay the reflect-or-refract draw
+    pre = _optics_case(o, 'refractive_single')
+    n1 = o[pre + 'ref_in']
+    n2 = N.where(n1 == o[pre + 'opt'][0], o[pre + 'opt'][1], o[pre + 'opt'][0])
+    refr, out_dirs = optics.refractions(n1, n2, d, nrm)
+    R = N.ones(H)
+    R[refr] = optics.fresnel(d[:, refr], nrm[:, refr], n1[refr], n2[refr])
+    refl = o[pre + 'draw_u'] <= R
+    dr = N.zeros((3, H))
+    dr[:, refr] = out_dirs
+    dirs = N.hstack((optics.reflections(d, nrm)[:, refl], dr[:, ~refl]))
+    par = N.hstack((N.nonzero(refl)[0], N.nonzero(~refl)[0]))
+    check(pre, dirs, e[par], par)
+    assert refl.any() and (~refl).any() and (~refr).any(), "fixture exercises reflection, refraction and TIR"
+    # refraction with perturbed normals: replay theta, phi
+    pre = _optics_case(o, 'refractive_split_sigma')
+    sigma = o[pre + 'opt'][3]
+    th, phi = o[pre + 'draw_g0'], o[pre + 'draw_phi']
+    err = N.vstack((N.sin(th) * N.cos(phi), N.sin(th) * N.sin(phi), N.cos(th)))
+    rots = optics.rotation_to_z(nrm.T)
+    pn = N.array([N.dot(rots[i], err[:, i]) for i in range(H)]).T
+    n1 = o[pre + 'ref_in']
+    n2 = N.where(n1 == o[pre + 'opt'][0], o[pre + 'opt'][1], o[pre + 'opt'][0])
+    refr, out_dirs = optics.refractions(n1, n2, d, pn)
+    R = N.ones(H)
+    R[refr] = optics.fresnel(d[:, refr], pn[:, refr], n1[refr], n2[refr])
+    dirs = N.hstack((optics.reflections(d, pn), out_dirs))
+    en = N.hstack((e * R, e[refr] * (1. - R[refr])))
+    check(pre, dirs, en, N.hstack((N.arange(H), N.nonzero(refr)[0])))
+    assert sigma > 0
+
+
+def test_sources_variate_replay():
+    s = load('sources.npz')
+    names = case_names(s)
+    for i, name in enumerate(names):
+        pre = 's%d_' % i
+        src = source_dict(s, pre)
+        u = [s[pre + 'u%d' % k] for k in range(4)]
+        n = len(u[0])
+        v, d, e, rid = sources.generate(src, n, 0, 0, uniforms=u)
+        assert N.allclose(v, s[pre + 'vertices'], rtol=1e-10, atol=1e-9), name
+        assert N.allclose(d, s[pre + 'directions'], rtol=1e-9, atol=1e-11), name
+        assert N.allclose(e, s[pre + 'energy'], rtol=1e-12), name
+
+
+def test_buie_table_restatement_matches_packed_table():
+    """oracle.sources.buie_tables (straight restatement) == the packed table the host ships to the device"""
+    s = load('sources.npz')
+    names = case_names(s)
+    for name, csr, pre_csr in (('buie_csr0.01_raw', 0.01, False), ('buie_csr0.05', 0.05, True), ('buie_csr0.3', 0.3, True),
+                               ('buie_csr0', 0., True)):
+        pre = 's%d_' % names.index(name)
+        packed = sources.table_from_desc_buie(s[pre + 'desc_buie'])
+        tab = sources.buie_tables(csr, pre_csr)
+        R = N.linspace(0., 1., 20001)[:-1]
+        assert N.allclose(sources.buie_thetas(R, tab), sources.buie_thetas_packed(R, packed), rtol=1e-12, atol=1e-15), name
+
+
+def _check_tree(res, g, pre, name):
+    nlev = int(g[pre + 'n_levels'])
+    assert len(res['levels']) == nlev, (name, [l['vertices'].shape[1] for l in res['levels']])
+    for k in range(1, nlev):
+        L = res['levels'][k]
+        assert L['vertices'].shape == g[pre + 'L%d_vertices' % k].shape, (name, k)
+        assert N.array_equal(L['parents'], g[pre + 'L%d_parents' % k]), (name, k)
+        assert N.allclose(L['vertices'], g[pre + 'L%d_vertices' % k], rtol=1e-9, atol=1e-8), (name, k)
+        assert N.allclose(L['directions'], g[pre + 'L%d_directions' % k], rtol=1e-9, atol=1e-9), (name, k)
+        assert N.allclose(L['energy'], g[pre + 'L%d_energy' % k], rtol=1e-9, atol=1e-12), (name, k)
+
+
+def test_engine_deterministic_scenes():
+    g = load('engine.npz')
+    for i, name in enumerate(case_names(g)):
+        pre = 'e%d_' % i
+        scene = oracle_scene(g, pre)
+        v, d, e = g[pre + 'v'], g[pre + 'd'], g[pre + 'e']
+        n = v.shape[1]
+        ref = g[pre + 'ref_index'] if (pre + 'ref_index') in g.files else N.ones(n)
+        res = engine.trace(scene, v, d, e, ref, N.zeros(n), N.arange(n, dtype=N.uint64), int(g[pre + 'reps']),
+                           float(g[pre + 'min_energy']), 1)
+        _check_tree(res, g, pre, name)
+        assert res['last_vertices'].shape == g[pre + 'last_vertices'].shape, name
+        assert N.allclose(res['last_vertices'], g[pre + 'last_vertices'], rtol=1e-9, atol=1e-8), name
+        assert N.allclose(res['last_directions'], g[pre + 'last_directions'], rtol=1e-9, atol=1e-9), name
+
+
+def test_kdtree_build_matches_reference():
+    from tracer_amd import scenes
+    from tracer_amd.accel_tree import KdTree
+    g = load('kdtree_nsttf.npz')
+    plant, field, rec, src = scenes.nsttf_field(sigma=0.)
+    S = len(plant.get_surfaces())
+    for tag, fast in (('', False), ('fast_', True)):
+        kd = KdTree(plant, 8 + 1.3 * N.log(S), fast=fast, min_leaf=1)
+        f = kd.flat()
+        assert N.array_equal(f['flag'], g[tag + 'flag'])
+        assert N.array_equal(f['child'], g[tag + 'child'])
+        assert N.array_equal(f['split'], g[tag + 'split'])          # bit-exact: same planes
+        assert N.array_equal(f['leaf_cnt'], g[tag + 'leaf_cnt'])
+        assert N.array_equal(f['leaf_surfs'], g[tag + 'leaf_surfs'])
+        assert N.array_equal(f['always_relevant'], g[tag + 'always_relevant'])
+        assert N.array_equal(f['bounds'], N.concatenate((g[tag + 'minpoint'], g[tag + 'maxpoint'])))
+
+
+def test_accountant_name_table():
+    import tracer_amd.optics_callables as oc
+    with open(os.path.join(GOLDEN, 'accountant_names.json')) as f:
+        ref = json.load(f)
+    oc.__getattr__('ReflectiveReceiver')     # builds the table
+    mine = dict((k, [a.__name__ for a in v]) for k, v in oc._SUFFIXES.items())
+    assert set(mine) == set(ref)
+    for k in ref:
+        assert mine[k] == ref[k], k
+    assert [type(a).__name__ for a in oc.OneSidedReflectiveReceiver(1.).accountants] == ['AbsorptionAccountant', 'LocationAccountant']

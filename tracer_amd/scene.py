@@ -69,6 +69,42 @@ class CompiledScene(object):
         return fr
 
 
+class TableScene(object):
+    """
+    A scene given directly as arrays (kinds, frames, parameters) instead of Surface objects -- the form
+    in which the golden fixtures store scenes.  Same attributes as CompiledScene where the engines need them.
+    """
+    def __init__(self, gm_kind, optics_kind, frames, gm, opt, extra, extra_off, extra_len, flags=None):
+        n = len(gm_kind)
+        self.n_surf = n
+        self.surfaces = None
+        self.descs = (_cabi.SurfaceDesc * n)()
+        self.extra = _cabi.f64(extra)
+        self.splits = False
+        self.capture = [False] * n
+        for i in range(n):
+            fill_desc(self.descs[i], N.asarray(frames[i]), int(gm_kind[i]), list(gm[i]), int(optics_kind[i]), list(opt[i]),
+                      flags=0 if flags is None else int(flags[i]), extra_off=int(extra_off[i]), extra_len=int(extra_len[i]))
+            if optics_kind[i] == _cabi.OPT_REFRACTIVE_HOMOGENOUS and opt[i][2] == 0.:
+                self.splits = True
+
+    def signature(self):
+        return bytes(self.descs) + self.extra.tobytes()
+
+
+def scene_arrays(compiled):
+    """dict of plain arrays describing a CompiledScene / TableScene (what fixtures store)."""
+    d = compiled.descs
+    n = compiled.n_surf
+    return dict(gm_kind=N.array([d[i].gm_kind for i in range(n)], dtype=N.int32),
+                optics_kind=N.array([d[i].optics_kind for i in range(n)], dtype=N.int32),
+                frames=N.array([N.vstack((N.array(list(d[i].frame)).reshape(3, 4), [0., 0., 0., 1.])) for i in range(n)]),
+                gm=N.array([list(d[i].gm) for i in range(n)]), opt=N.array([list(d[i].opt) for i in range(n)]),
+                extra=N.array(compiled.extra, dtype=float),
+                extra_off=N.array([d[i].extra_off for i in range(n)], dtype=N.int32),
+                extra_len=N.array([d[i].extra_len for i in range(n)], dtype=N.int32))
+
+
 def compile_scene(assembly_or_surfaces):
     surfaces = assembly_or_surfaces.get_surfaces() if hasattr(assembly_or_surfaces, 'get_surfaces') \
         else assembly_or_surfaces
