@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""
+bench.py -- the headline benchmark of BASELINE.json: Mray-bounces/s on the Sandia NSTTF heliostat field.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: `--rays` source rays (default 1e8 =
+configs[2], "Sandia NSTTF field, 1e8 rays, 1xMI355X") generated on the device from the Buie-sunshape source
+descriptor, traced through the 218-heliostat field + receiver with the Kd-tree, every bounce until the rays
+escape or are absorbed, tallies + 50x50 receiver flux map + receiver hit list accumulated on the device.
+Rays are sharded over the GPUs by stream id (weak scaling: every rank traces `--rays` rays per step); the only
+exchange is ONE all-reduce (RCCL) of the packed tally buffer at the end of the job.
+
+Prints ONE JSON line on rank 0: metric/value/unit per BASELINE.json, plus
+  roofline      algorithmic HBM bytes of the dominant kernel (k_trace_fast: 112 B per ray segment)
+                over its launch time measured with HIP events on the launch stream, against the 8 TB/s HBM peak
+  cpu_baseline  the oracle (NumPy restatement of the reference's algorithm = the reference's own CPU path, which
+                is NumPy too) timed on this host on a bounded sample of the same workload, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B_SEG = 112.0          # algorithmic bytes per ray segment: read + write of x,y,z,dx,dy,dz,E in float64
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(n_rays):
+    """oracle (kind "port"), one core, brute force like the reference's default path, on n_rays NSTTF source rays"""
+    import numpy as N
+    from tracer_amd import scenes
+    from tracer_amd.scene import compile_scene
+    from oracle import engine as oracle_engine
+    plant, field, rec, src = scenes.nsttf_field()
+    cs = compile_scene(plant)
+    b = scenes.nsttf_source(n_rays, src, seed=99)
+    t0 = time.time()
+    with N.errstate(all='ignore'):
+        ref = oracle_engine.trace_from_compiled(cs, b.source_args(), reps=100, min_energy=1e-10)
+    dt = time.time() - t0
+    return dict(value=ref['segments'] / dt / 1e6, unit='Mray-bounces/s', cores=1, kind='port',
+                sample='NSTTF 218 heliostats + receiver, %d source rays (%d segments), brute force, %.1f s'
+                       % (n_rays, ref['segments'], dt),
+                receiver_kW=float(ref['absorbed'][-1] / 1e3))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--rays', type=float, default=1e8, help='source rays per step per GPU')
+    ap.add_argument('--cpu-rays', type=int, default=200000, help='source rays of the CPU baseline sample (0 = skip)')
+    ap.add_argument('--no-accel', action='store_true', help='brute force instead of the Kd-tree')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        log('note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE' % (world, args.gpus))
+    n = int(args.rays)
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+
+    import numpy as N
+    from tracer_amd import _cabi, scenes
+    from tracer_amd.accel_tree import KdTree
+    from tracer_amd.scene import compile_scene, DeviceScene
+
+    _cabi.set_default_device(local)
+    ctx = _cabi.get_context(local)
+    plant, field, rec, src = scenes.nsttf_field()
+    cs = compile_scene(plant)
+    dev = DeviceScene(cs, ctx)
+    accel = not args.no_accel
+    if accel:
+        dev.set_kdtree(KdTree(plant, 8 + 1.3 * N.log(cs.n_surf), min_leaf=1))
+    ue, ve = scenes.nsttf_fluxmap_edges()
+    dev.set_fluxmap(218, ue, ve)
+    dev.set_hit_capacity(int(0.08 * n * (args.steps + args.warmup)) + 4096)   # receiver hits ~6.4 % of the source rays
+
+    tally = torch.zeros(dev.tally_size(), dtype=torch.float64, device='cuda')
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(k):
+        # stream ids: disjoint per (step, rank) -- results do not depend on the number of GPUs
+        offset = (k * world + rank) * n
+        b = scenes.nsttf_source(n, src, seed=2024, ray_offset=offset)
+        stats, _ = dev.trace_fast(b, 100, 1e-10, 2024, accel=accel)
+        return stats
+
+    for k in range(args.warmup):
+        step(k)
+    if world > 1:
+        dist.all_reduce(torch.zeros(8, dtype=torch.float64, device='cuda'))   # communicator set-up outside the timed region
+    dev.reset_tallies()
+    dev.lib.trc_scene_clear_hits(dev.handle)
+
+    barrier()
+    t0 = time.time()
+    seg = 0
+    kms = 0.0
+    for k in range(args.steps):
+        st = step(args.warmup + k)
+        seg += st.segments
+        kms += st.kernel_ms
+    # the single exchange of the job: sum the tally buffers of all ranks (per-surface energies, counts, flux map)
+    dev.export_tallies(out=tally.data_ptr())
+    if world > 1:
+        dist.all_reduce(tally)
+        dev.import_tallies(tally.data_ptr())
+    barrier()
+    dt = time.time() - t0
+
+    seg_t = torch.tensor([float(seg), dt, kms], dtype=torch.float64, device='cuda')
+    if world > 1:
+        tot = seg_t.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        mx = seg_t.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        total_segments, dt_max = float(tot[0]), float(mx[1])
+    else:
+        total_segments, dt_max = float(seg), dt
+
+    if rank == 0:
+        a, r, h = dev.get_tallies()
+        fm = dev.get_fluxmap(218)
+        total_rays = float(n) * args.steps * world
+        e_ray = 1000. * N.pi * src['radius'] ** 2 / n        # energy per ray of ONE step's bundle
+        receiver_kw = a[218] / args.steps / world / 1e3       # mean over the independent batches
+        ach = (seg * B_SEG / 1e9) / (kms / 1e3) if kms > 0 else 0.0     # GB/s, this rank's launches
+        traffic = None
+        tf = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'Mray-bounces/s on Sandia NSTTF field',
+            'value': total_segments / dt_max / 1e6,
+            'unit': 'Mray-bounces/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt_max / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'Sandia NSTTF heliostat field: 218 heliostats + receiver, Buie sunshape CSR 0.01, '
+                                   '%.0e source rays per step per GPU, %s, reps=100, min_energy=1e-10; tallies + 50x50 '
+                                   'flux map + receiver hit list on device' % (n, 'Kd-tree (1065 nodes)' if accel else 'brute force'),
+                       'rays_per_step_per_gpu': n, 'segments_per_step_per_gpu': seg / args.steps, 'accel': accel,
+                       'parallelism': 'rays sharded by stream id over %d GPU(s), one all-reduce of tallies at the end' % world},
+            'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                         'traffic': traffic, 'kernel': 'k_trace_fast', 'kernel_ms_per_launch': kms / args.steps,
+                         'algorithmic_bytes_per_launch': seg / args.steps * B_SEG},
+            'check': {'receiver_kW': receiver_kw, 'receiver_hits_per_ray': h[218] / total_rays,
+                      'heliostat_hits_per_ray': float(h[:218].sum()) / total_rays,
+                      'fluxmap_sum_kW': float(fm.sum()) / args.steps / world / 1e3, 'energy_per_ray_W': e_ray},
+        }
+        if world == 1 and args.cpu_rays > 0:
+            log('timing the CPU baseline (oracle, %d rays) ...' % args.cpu_rays)
+            out['cpu_baseline'] = cpu_baseline(args.cpu_rays)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    dev.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

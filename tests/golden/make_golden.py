@@ -580,8 +580,100 @@ def make_accountant_names(ref):
     return table
 
 
+def make_mc(ref):
+    """
+    Monte-Carlo references: the reference engine itself on the benchmark scenes (restated as in SURVEY.md 8(d)),
+    K seeds x 1e5 rays each; mean and standard error of the scene-level quantities the GPU runs are compared to.
+    """
+    import time
+    out = {}
+    osm = importlib.import_module('tracer.models.one_sided_mirror')
+    hf = importlib.import_module('tracer.models.heliostat_field')
+    # --- NSTTF, 218 heliostats, sigma 1 mrad, Buie CSR 0.01 ---
+    pos = N.loadtxt(os.path.join(REFERENCE, 'examples', 'sandia_hstat_coordinates.csv'), delimiter=',')
+    pos[:, 1] -= 4.
+    field = hf.HeliostatField(pos, 6.1, 6.1, absorptivity=0.04, sigma=1e-3, bi_var=True, MCRT_option='fast')
+    zen = 35.05 * N.pi / 180.
+    field.track_sun(0., zen, aim_points=N.tile(N.array([0., 0., 60.]), (pos.shape[0], 1)))
+    rec = osm.one_sided_receiver(11., 11.)
+    rec.set_transform(N.dot(ref.spatial_geometry.translate(0., 0., 60.), ref.spatial_geometry.rotx(-N.pi / 2.)))
+    plant = ref.assembly.Assembly(objects=[rec], subassemblies=[field])
+    sun = hf.solar_vector(0., zen)
+    x0, x1, y0, y1 = pos[:, 0].min(), pos[:, 0].max(), pos[:, 1].min(), pos[:, 1].max()
+    centre = N.array([(x0 + x1) / 2., (y0 + y1) / 2., 0.])
+    radius = 1.10 * N.sqrt(((x1 - x0) / 2.) ** 2 + ((y1 - y0) / 2.) ** 2)
+    n = 100000
+    P, F, flux = [], [], []
+    edges = N.linspace(-5.5, 5.5, 51)
+    t0 = time.time()
+    for k in range(10):
+        N.random.seed(1000 + k)
+        plant.reset_all_optics()
+        src = ref.sources.buie_sunshape(n, N.vstack(300. * sun + centre), -sun, radius, 0.01, flux=1000., pre_process_CSR=False)
+        eng = ref.tracer_engine.TracerEngine(plant)
+        eng.ray_tracer(src, reps=100, min_energy=1e-10, tree=True)
+        en, pts = rec.get_surfaces()[0].get_optics_manager().get_all_hits()
+        P.append(en.sum())
+        F.append([eng.tree[1].get_num_rays() / float(n), len(en) / float(n)])
+        loc = rec.get_surfaces()[0].global_to_local(pts)
+        flux.append(N.histogram2d(loc[0], loc[1], bins=[edges, edges], weights=en)[0])
+    print('  nsttf mc: %.1f s, receiver %.1f +- %.1f kW' % (time.time() - t0, N.mean(P) / 1e3, N.std(P, ddof=1) / N.sqrt(len(P)) / 1e3))
+    out['nsttf_receiver_runs'] = N.array(P)
+    out['nsttf_receiver_mean'] = N.mean(P)
+    out['nsttf_receiver_se'] = N.std(P, ddof=1) / N.sqrt(len(P))
+    out['nsttf_bounce_fractions_mean'] = N.mean(F, axis=0)
+    out['nsttf_bounce_fractions_se'] = N.std(F, axis=0, ddof=1) / N.sqrt(len(F))
+    out['nsttf_flux_mean'] = N.mean(flux, axis=0)
+    out['nsttf_flux_se'] = N.std(flux, axis=0, ddof=1) / N.sqrt(len(flux))
+    out['nsttf_rays_per_run'] = N.int64(n)
+    # --- dish (config 2): D=5 f=3, RealReflective(0.06, 2 mrad radial), round receiver r=0.15, Buie CSR 0.05 ---
+    O = ref.optics_callables
+    dish_s = ref.surface.Surface(ref.paraboloid.ParabolicDishGM(5., 3.), O.RealReflective(0.06, 2e-3, bi_var=False))
+    rec_s = ref.surface.Surface(ref.flat_surface.RoundPlateGM(0.15), O.LambertianReceiver(1.))
+    asm = ref.assembly.Assembly(objects=[ref.object.AssembledObject(surfs=[dish_s]),
+                                         ref.object.AssembledObject(surfs=[rec_s], transform=N.dot(ref.spatial_geometry.translate(0., 0., 3.), ref.spatial_geometry.rotx(N.pi)))])
+    D = []
+    t0 = time.time()
+    for k in range(8):
+        N.random.seed(2000 + k)
+        asm.reset_all_optics()
+        src = ref.sources.buie_sunshape(n, N.c_[[0., 0., 6.]], N.r_[0., 0., -1.], 2.5, 0.05, flux=1000.)
+        eng = ref.tracer_engine.TracerEngine(asm)
+        eng.ray_tracer(src, reps=10, min_energy=1e-10, tree=True)
+        D.append(rec_s.get_optics_manager().get_all_hits()[0].sum())
+    print('  dish mc: %.1f s, receiver %.2f +- %.2f W' % (time.time() - t0, N.mean(D), N.std(D, ddof=1) / N.sqrt(len(D))))
+    out['dish_receiver_mean'] = N.mean(D)
+    out['dish_receiver_se'] = N.std(D, ddof=1) / N.sqrt(len(D))
+    out['dish_source_power'] = 1000. * N.pi * 2.5 ** 2
+    # --- flat pair (config 1): 2x2 mirror RealReflective(0.05, 2 mrad bi-variate), 4x4 LambertianReceiver, pillbox rect source ---
+    dvec = N.r_[-0.15, 0., -1.]
+    dvec = dvec / N.sqrt(N.sum(dvec ** 2))
+    mirror = ref.surface.Surface(ref.flat_surface.RectPlateGM(2., 2.), O.RealReflective(0.05, 2e-3, bi_var=True))
+    outd = dvec - 2. * dvec[2] * N.r_[0., 0., 1.]
+    recp = ref.surface.Surface(ref.flat_surface.RectPlateGM(4., 4.), O.LambertianReceiver(1.))
+    asm = ref.assembly.Assembly(objects=[ref.object.AssembledObject(surfs=[mirror]),
+                                         ref.object.AssembledObject(surfs=[recp], transform=N.dot(ref.spatial_geometry.translate(*(outd * 10. / outd[2])), ref.spatial_geometry.rotx(N.pi)))])
+    Fp = []
+    for k in range(8):
+        N.random.seed(3000 + k)
+        asm.reset_all_optics()
+        src = ref.sources.rect_bundle(n, N.vstack(-dvec * 5.), dvec, 2., 2., 4.65e-3, flux=1000.)
+        eng = ref.tracer_engine.TracerEngine(asm)
+        eng.ray_tracer(src, reps=10, min_energy=1e-10, tree=True)
+        en, pts = recp.get_optics_manager().get_all_hits()
+        loc = recp.global_to_local(pts)
+        Fp.append([en.sum(), N.sqrt(N.mean(loc[0] ** 2)), N.sqrt(N.mean(loc[1] ** 2))])
+    out['flat_receiver_mean'] = N.mean(Fp, axis=0)
+    out['flat_receiver_se'] = N.std(Fp, axis=0, ddof=1) / N.sqrt(len(Fp))
+    print('  flat mc: receiver W, rms x, rms y =', out['flat_receiver_mean'], '+-', out['flat_receiver_se'])
+    N.savez_compressed(os.path.join(HERE, 'mc_reference.npz'), **out)
+
+
 def main():
     import_reference()
+    if '--mc' in sys.argv:
+        make_mc(NS('tracer'))
+        return
     ref = NS('tracer')
     amd = NS('tracer_amd')
     for fname, maker in (('geometry.npz', make_geometry), ('optics.npz', make_optics), ('sources.npz', make_sources),

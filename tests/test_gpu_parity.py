@@ -1,0 +1,379 @@
+"""
+GPU parity tests (run with -m gpu on the MI355X box).  Everything here goes through the C-ABI of
+include/tracer_amd.h: the HIP path is compared (1) directly with the reference's outputs stored in tests/golden,
+(2) ray by ray with the oracle on identical Philox seeds, (3) at full benchmark sizes through size-independent
+properties.  Tolerances: the device computes in float64 like the reference; differences come from FMA
+contraction, R^T(p-c) instead of inv(frame).p and the device libm -- 1e-9 relative / 1e-8 m absolute on lengths
+of up to a few hundred metres is asserted, and hit/miss patterns, parents and orderings are exact.
+"""
+import ctypes as C
+
+import numpy as N
+import pytest
+
+from helpers import load, case_names, oracle_scene, table_scene, source_dict
+
+pytestmark = pytest.mark.gpu
+
+RT, AT = 1e-9, 1e-8
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from tracer_amd import _cabi
+    return _cabi.get_context(0)
+
+
+def _desc(kind, frame, gm, extra, opt_kind=0, opt=()):
+    from tracer_amd import _cabi
+    from tracer_amd.geometry_manager import fill_desc
+    d = _cabi.SurfaceDesc()
+    fill_desc(d, frame, kind, list(gm), opt_kind, list(opt), extra_off=0 if len(extra) else -1, extra_len=len(extra))
+    return d
+
+
+def gm_intersect(ctx, kind, frame, gm, extra, v, d):
+    from tracer_amd import _cabi
+    desc = _desc(kind, frame, gm, extra)
+    v = _cabi.f64(v); d = _cabi.f64(d); extra = _cabi.f64(extra)
+    n = v.shape[1]
+    rays = _cabi.make_rays(n, v[0], v[1], v[2], d[0], d[1], d[2])
+    t = N.empty(n); h = N.empty((3, n))
+    _cabi.check(ctx.lib.trc_gm_find_intersections(ctx.handle, C.byref(desc), len(extra), _cabi.ptr(extra) if len(extra) else None,
+                                                  C.byref(rays), _cabi.ptr(t), _cabi.ptr(h[0]), _cabi.ptr(h[1]), _cabi.ptr(h[2])))
+    return t, h
+
+
+def gm_normals(ctx, kind, frame, gm, hits, dirs):
+    from tracer_amd import _cabi
+    desc = _desc(kind, frame, gm, [])
+    if kind == _cabi.GM_RECT_PERFORATED:
+        desc.gm_kind = _cabi.GM_RECT
+    h = _cabi.f64(hits); d = _cabi.f64(dirs)
+    out = N.empty_like(h)
+    _cabi.check(ctx.lib.trc_gm_get_normals(ctx.handle, C.byref(desc), h.shape[1], _cabi.ptr(h[0]), _cabi.ptr(h[1]), _cabi.ptr(h[2]),
+                                           _cabi.ptr(d[0]), _cabi.ptr(d[1]), _cabi.ptr(d[2]), _cabi.ptr(out[0]), _cabi.ptr(out[1]),
+                                           _cabi.ptr(out[2])))
+    return out
+
+
+def test_geometry_vs_reference_fixtures(ctx):
+    """every native kind: t, hit points and normals against the reference's own outputs"""
+    g = load('geometry.npz')
+    names = case_names(g)
+    for ci in range(int(g['n_cases'])):
+        pre = 'g%d_' % ci
+        kind = int(g[pre + 'kind'])
+        t, h = gm_intersect(ctx, kind, g[pre + 'frame'], g[pre + 'gm'], g[pre + 'extra'], g[pre + 'v'], g[pre + 'd'])
+        t_ref = g[pre + 't']
+        assert N.array_equal(N.isfinite(t), N.isfinite(t_ref)), names[ci]
+        idx = g[pre + 'hit_idx']
+        assert N.allclose(t[idx], t_ref[idx], rtol=RT, atol=AT), names[ci]
+        if len(idx):
+            assert N.allclose(h[:, idx], g[pre + 'hits'], rtol=RT, atol=AT), names[ci]
+            nrm = gm_normals(ctx, kind, g[pre + 'frame'], g[pre + 'gm'], g[pre + 'hits'], g[pre + 'd'][:, idx])
+            ok = N.all(N.isclose(nrm, g[pre + 'normals'], rtol=RT, atol=1e-9) | (N.isnan(nrm) & N.isnan(g[pre + 'normals'])), axis=0)
+            assert ok.all(), (names[ci], N.nonzero(~ok)[0][:5])
+
+
+def test_geometry_vs_oracle_large_fans(ctx):
+    """2e4 random rays per kind against the oracle (denser coverage of apertures and root choices)"""
+    from oracle import geometry
+    g = load('geometry.npz')
+    rng = N.random.RandomState(99)
+    done = set()
+    for ci in range(int(g['n_cases'])):
+        pre = 'g%d_' % ci
+        kind = int(g[pre + 'kind'])
+        frame = g[pre + 'frame']
+        key = (kind, ci % 3)
+        if ci % 3 != 1 or key in done:       # the rotated + translated frame of each kind
+            continue
+        done.add(key)
+        n = 20000
+        c, R = frame[:3, 3], frame[:3, :3]
+        o = N.dot(R, rng.uniform(-1, 1, size=(3, n)) * 6.) + c[:, None]
+        tg = N.dot(R, rng.uniform(-1, 1, size=(3, n)) * 1.5) + c[:, None]
+        d = tg - o
+        d /= N.sqrt(N.sum(d ** 2, axis=0))
+        t, h = gm_intersect(ctx, kind, frame, g[pre + 'gm'], g[pre + 'extra'], o, d)
+        with N.errstate(all='ignore'):
+            t_o = geometry.intersect(kind, frame, list(g[pre + 'gm']), g[pre + 'extra'], o, d)
+        fin = N.isfinite(t_o)
+        mism = N.isfinite(t) != fin
+        # a ray grazing an aperture edge or a threshold within rounding may flip; none is expected in 2e4 random rays
+        assert mism.sum() == 0, (kind, int(mism.sum()))
+        assert N.allclose(t[fin], t_o[fin], rtol=RT, atol=AT), kind
+        if fin.any():
+            pts = o[:, fin] + t_o[fin] * d[:, fin]
+            with N.errstate(all='ignore'):
+                n_o = geometry.normals(kind, frame, list(g[pre + 'gm']), pts, d[:, fin])
+            n_d = gm_normals(ctx, kind, frame, g[pre + 'gm'], pts, d[:, fin])
+            # the flip test `d.n > 0` can go either way for a ray tangent to the surface within rounding
+            close = N.all(N.isclose(n_d, n_o, rtol=RT, atol=1e-9), axis=0) | N.all(N.isclose(n_d, -n_o, rtol=RT, atol=1e-9), axis=0) & (N.abs(N.sum(n_o * d[:, fin], axis=0)) < 1e-7)
+            assert close.all(), (kind, int((~close).sum()))
+
+
+def optics_apply(ctx, kind, opt, extra, frame, d, e, ref, wl, nrm, pts, seed, event):
+    from tracer_amd import _cabi
+    desc = _desc(0, frame, [], extra, kind, opt)
+    n = d.shape[1]
+    d = _cabi.f64(d); e = _cabi.f64(e); ref = _cabi.f64(ref); wl = _cabi.f64(wl); nrm = _cabi.f64(nrm); pts = _cabi.f64(pts)
+    extra = _cabi.f64(extra)
+    rid = N.arange(n, dtype=N.uint64) + N.uint64(1000)
+    rin = _cabi.make_rays(n, dx=d[0], dy=d[1], dz=d[2], e=e, ref_index=ref, wavelength=wl, rid=rid)
+    m = 2 * n
+    o = dict((k, N.empty(m)) for k in ('x', 'y', 'z', 'dx', 'dy', 'dz', 'e', 'ref'))
+    par = N.empty(m, dtype=N.int64)
+    rout = _cabi.make_rays(m, o['x'], o['y'], o['z'], o['dx'], o['dy'], o['dz'], o['e'], parent=par, ref_index=o['ref'])
+    _cabi.check(ctx.lib.trc_optics_apply(ctx.handle, C.byref(desc), len(extra), _cabi.ptr(extra) if len(extra) else None, C.byref(rin),
+                                         _cabi.ptr(pts[0]), _cabi.ptr(pts[1]), _cabi.ptr(pts[2]), _cabi.ptr(nrm[0]), _cabi.ptr(nrm[1]),
+                                         _cabi.ptr(nrm[2]), seed, event, C.byref(rout)))
+    k = rout.n
+    return N.vstack((o['dx'][:k], o['dy'][:k], o['dz'][:k])), o['e'][:k], par[:k], o['ref'][:k], rid
+
+
+def test_optics_vs_reference_and_oracle(ctx):
+    """deterministic kinds against the reference fixtures; random kinds ray by ray against the oracle on the same Philox streams"""
+    from oracle import optics
+    o = load('optics.npz')
+    frame, nrm, d, pts, e, wl = o['frame'], o['normals'], o['dirs'], o['points'], o['energy'], o['wavelengths']
+    up = frame[:3, 2]
+    names = case_names(o)
+    for i, name in enumerate(names):
+        pre = 'o%d_' % i
+        kind, opt, extra, ref_in = int(o[pre + 'kind']), list(o[pre + 'opt']), o[pre + 'extra'], o[pre + 'ref_in']
+        dirs, en, par, ref, rid = optics_apply(ctx, kind, opt, extra, frame, d, e, ref_in, wl, nrm, pts, 4242, 3)
+        if name in ('transparent', 'reflective', 'one_sided_reflective', 'real_reflective_sigma0', 'reflective_spectral',
+                    'refractive_split'):
+            assert N.array_equal(par, o[pre + 'out_parents']), name
+            assert N.allclose(dirs, o[pre + 'out_dirs'], rtol=RT, atol=1e-9), name
+            assert N.allclose(en, o[pre + 'out_energy'], rtol=RT, atol=1e-12), name
+            if (pre + 'out_ref') in o.files:
+                assert N.allclose(ref, o[pre + 'out_ref']), name
+        blocks = optics.shade(kind, opt, extra, up, d, e, ref_in, wl, nrm, 4242, rid, 3)
+        assert N.array_equal(par, N.hstack([b['sel'] for b in blocks])), name
+        # trig of ~2*pi*u on the device vs numpy differ in the last bits; 1e-9 still holds
+        assert N.allclose(dirs, N.hstack([b['directions'] for b in blocks]), rtol=RT, atol=1e-9), name
+        assert N.allclose(en, N.hstack([b['energy'] for b in blocks]), rtol=RT, atol=1e-12), name
+        assert N.allclose(ref, N.hstack([b['ref'] for b in blocks])), name
+
+
+def test_sources_vs_oracle(ctx):
+    """trc_source_generate against the oracle generator on the same seeds, every source kind of the fixtures"""
+    from oracle import sources
+    from tracer_amd import _cabi
+    s = load('sources.npz')
+    for i, name in enumerate(case_names(s)):
+        pre = 's%d_' % i
+        src = source_dict(s, pre)
+        desc = _cabi.SourceDesc()
+        desc.kind = src['kind']
+        for k in range(3):
+            desc.center[k] = src['center'][k]
+        for k in range(9):
+            desc.rot_pos[k] = src['rot_pos'].ravel()[k]
+            desc.rot_dir[k] = src['rot_dir'].ravel()[k]
+        for k in range(8):
+            desc.p[k] = src['p'][k]
+        desc.energy = src['energy']
+        for k in range(_cabi.BUIE_LEN):
+            desc.buie[k] = src['buie'][k]
+        n = 50000
+        v = N.empty((3, n)); d = N.empty((3, n)); e = N.empty(n)
+        rays = _cabi.make_rays(n, v[0], v[1], v[2], d[0], d[1], d[2], e)
+        _cabi.check(ctx.lib.trc_source_generate(ctx.handle, C.byref(desc), n, 777, 123456789012, C.byref(rays)))
+        vo, do, eo, rid = sources.generate(src, n, 777, 123456789012)
+        assert N.allclose(v, vo, rtol=1e-10, atol=1e-8), name
+        assert N.allclose(d, do, rtol=1e-9, atol=1e-11), name
+        assert N.allclose(e, eo, rtol=1e-14), name
+        assert N.allclose(N.sum(d ** 2, axis=0), 1., atol=1e-12), name
+
+
+def _ordered(ctx, ts, v, d, e, reps, min_energy, seed, accel=False, ref_index=None, kd=None):
+    from tracer_amd.scene import DeviceScene
+    from tracer_amd.ray_bundle import RayBundle
+    dev = DeviceScene(ts, ctx)
+    if kd is not None:
+        dev.set_kdtree(kd)
+    kw = {} if ref_index is None else dict(ref_index=ref_index)
+    res, stats = dev.trace_ordered(RayBundle(vertices=v, directions=d, energy=e, **kw), reps, min_energy, seed, accel=accel)
+    levels = [res.level(k) for k in range(res.num_levels())]
+    tallies = dev.get_tallies()
+    res.close()
+    dev.close()
+    return levels, stats, tallies
+
+
+def test_ordered_engine_vs_reference_trees(ctx):
+    """deterministic scenes: every RayTree level (order, parents, vertices, directions, energies) equals the reference's"""
+    g = load('engine.npz')
+    for i, name in enumerate(case_names(g)):
+        pre = 'e%d_' % i
+        if int(g[pre + 'accel']):
+            continue
+        ts = table_scene(g, pre)
+        ref = g[pre + 'ref_index'] if (pre + 'ref_index') in g.files else None
+        levels, stats, _ = _ordered(ctx, ts, g[pre + 'v'], g[pre + 'd'], g[pre + 'e'], int(g[pre + 'reps']), float(g[pre + 'min_energy']), 5,
+                                    ref_index=ref)
+        nlev = int(g[pre + 'n_levels'])
+        assert len(levels) == nlev, (name, [l['vertices'].shape[1] for l in levels])
+        for k in range(1, nlev):
+            L = levels[k]
+            assert L['vertices'].shape == g[pre + 'L%d_vertices' % k].shape, (name, k)
+            assert N.array_equal(L['parents'], g[pre + 'L%d_parents' % k]), (name, k)
+            assert N.allclose(L['vertices'], g[pre + 'L%d_vertices' % k], rtol=RT, atol=AT), (name, k)
+            assert N.allclose(L['directions'], g[pre + 'L%d_directions' % k], rtol=RT, atol=1e-9), (name, k)
+            assert N.allclose(L['energy'], g[pre + 'L%d_energy' % k], rtol=RT, atol=1e-12), (name, k)
+        n_last = g[pre + 'last_vertices'].shape[1]
+        assert stats.rays_left == n_last, name
+        if n_last:
+            assert N.allclose(levels[-1]['vertices'][:, :n_last], g[pre + 'last_vertices'], rtol=RT, atol=AT), name
+
+
+def _mc_scene():
+    """every random optics kind in one scene"""
+    from tracer_amd import _cabi as K
+    from tracer_amd.scene import TableScene
+    from tracer_amd.spatial_geometry import rotx, roty, translate
+    frames = [translate(0, 0, -2.), N.dot(translate(0, 0, 3.), rotx(N.pi)), N.dot(translate(3., 0, 0.), roty(-N.pi / 2.)),
+              N.dot(translate(-3., 0, 0.), roty(N.pi / 2.)), N.dot(translate(0., 3., 0.), rotx(N.pi / 2.)),
+              N.dot(translate(0., -3., 0.), rotx(-N.pi / 2.))]
+    gm_kind = [K.GM_RECT, K.GM_PARAB_DISH, K.GM_ROUND, K.GM_RECT, K.GM_RECT, K.GM_RECT]
+    gm = N.zeros((6, 16))
+    gm[0, :2] = 3.5, 3.5
+    gm[1, :3] = 1. / (4 * 2.), 1. / (4 * 2.), (3. / (2 * N.sqrt(2.))) ** 2
+    gm[2, :2] = 3., -1.
+    gm[3, :2] = 3.5, 3.5
+    gm[4, :2] = 3.5, 3.5
+    gm[5, :2] = 3.5, 3.5
+    ok = [K.OPT_REAL_REFLECTIVE, K.OPT_REAL_REFLECTIVE, K.OPT_LAMBERTIAN, K.OPT_LAMBERTIAN_SPECULAR,
+          K.OPT_ONE_SIDED_REAL_REFLECTIVE, K.OPT_REFRACTIVE_HOMOGENOUS]
+    opt = N.zeros((6, 8))
+    opt[0, :3] = 0.1, 5e-3, 1.
+    opt[1, :3] = 0.1, 5e-3, 0.
+    opt[2, :2] = 0.3, N.pi / 2.
+    opt[3, :2] = 0.2, 0.5
+    opt[4, :3] = 0.15, 2e-3, 1.
+    opt[5, :4] = 1.0, 1.5, 1., 1e-3      # single-ray refraction with normal perturbation
+    return TableScene(gm_kind, ok, frames, gm, opt, N.zeros(0), -N.ones(6, dtype=int), N.zeros(6, dtype=int))
+
+
+def test_engines_vs_oracle_monte_carlo(ctx):
+    """slope error / Lambertian / mixed / refractive sampling: both device engines against the oracle, ray by ray"""
+    from oracle import engine
+    from tracer_amd.scene import DeviceScene
+    from tracer_amd.ray_bundle import RayBundle
+    ts = _mc_scene()
+    rng = N.random.RandomState(1)
+    n = 6000
+    v = rng.uniform(-0.5, 0.5, size=(3, n))
+    d = rng.normal(size=(3, n)); d /= N.sqrt(N.sum(d ** 2, axis=0))
+    e = rng.uniform(0.5, 1.5, n)
+    seed, reps, emin = 20240901, 8, 0.02
+    levels, stats, tallies = _ordered(ctx, ts, v, d, e, reps, emin, seed, ref_index=N.ones(n))
+    ref = engine.trace_bundle(ts, v, d, e, reps, emin, seed, ref_index=N.ones(n))
+    assert [l['vertices'].shape[1] for l in levels] == [l['vertices'].shape[1] for l in ref['levels']]
+    for k in range(1, len(levels)):
+        L, O = levels[k], ref['levels'][k]
+        assert N.array_equal(L['parents'], O['parents']), k
+        assert N.array_equal(L['surf'], O['surf']), k
+        assert L['n_live'] == O['n_live'], k
+        assert N.allclose(L['vertices'], O['vertices'], rtol=RT, atol=AT), k
+        assert N.allclose(L['directions'], O['directions'], rtol=1e-8, atol=1e-8), k
+        assert N.allclose(L['energy'], O['energy'], rtol=RT, atol=1e-12), k
+    assert N.array_equal(tallies[2], ref['hits'])
+    assert N.allclose(tallies[0], ref['absorbed'], rtol=1e-9, atol=1e-9)
+    assert stats.segments == ref['segments']
+    # fast engine: same per-surface tallies, same surviving rays (as a set)
+    dev = DeviceScene(ts, ctx)
+    st, last = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e, ref_index=N.ones(n)), reps, emin, seed, keep_last=True)
+    a, r, h = dev.get_tallies()
+    dev.close()
+    assert N.array_equal(h, ref['hits'])
+    assert N.allclose(a, ref['absorbed'], rtol=1e-9, atol=1e-9)
+    assert N.allclose(r, ref['received'], rtol=1e-9, atol=1e-9)
+    assert st.segments == ref['segments'] and st.rays_left == ref['last_vertices'].shape[1]
+    if st.rays_left:
+        mine = N.vstack(last)[:, N.lexsort(N.round(N.vstack(last[:3]), 6))]
+        theirs = N.vstack((ref['last_vertices'], ref['last_directions'], ref['last_energy'][None, :]))
+        theirs = theirs[:, N.lexsort(N.round(ref['last_vertices'], 6))]
+        assert N.allclose(mine, theirs, rtol=1e-8, atol=1e-7)
+
+
+def test_kd_accel_equals_brute_and_reference(ctx):
+    """accel=True gives the brute-force results (and the reference's) on the NSTTF subset fixture, both engines"""
+    from tracer_amd import scenes
+    from tracer_amd.accel_tree import KdTree
+    from tracer_amd.scene import compile_scene, DeviceScene
+    from tracer_amd.ray_bundle import RayBundle
+    g = load('engine.npz')
+    names = case_names(g)
+    pre = 'e%d_' % names.index('nsttf30_accel')
+    plant, field, rec, src = scenes.nsttf_field(sigma=0., n_heliostats=30)
+    cs = compile_scene(plant)
+    assert N.allclose(N.array([list(d.frame) for d in cs.descs]), g[pre + 'scene_frames'][:, :3].reshape(31, 12))
+    kd = KdTree(plant, 8 + 1.3 * N.log(31), min_leaf=1)
+    v, d, e = g[pre + 'v'], g[pre + 'd'], g[pre + 'e']
+    lv_b, st_b, tl_b = _ordered(ctx, cs, v, d, e, 100, 1e-10, 1)
+    lv_a, st_a, tl_a = _ordered(ctx, cs, v, d, e, 100, 1e-10, 1, accel=True, kd=kd)
+    assert len(lv_a) == len(lv_b) == int(g[pre + 'n_levels'])
+    for k in range(1, len(lv_a)):
+        for key in ('vertices', 'directions', 'energy', 'parents', 'surf'):
+            assert N.array_equal(lv_a[k][key], lv_b[k][key]), (k, key)
+        assert N.array_equal(lv_a[k]['parents'], g[pre + 'L%d_parents' % k])
+        assert N.allclose(lv_a[k]['vertices'], g[pre + 'L%d_vertices' % k], rtol=RT, atol=AT)
+        assert N.allclose(lv_a[k]['energy'], g[pre + 'L%d_energy' % k], rtol=RT)
+    # receiver accountant of the reference = absorbed energies and hit points on surface 30
+    acc_e = g[pre + 'acc_s30_0']
+    assert N.isclose(tl_a[0][30], acc_e.sum(), rtol=1e-9)
+    dev = DeviceScene(cs, ctx)
+    dev.set_kdtree(kd)
+    st, _ = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e), 100, 1e-10, 1, accel=True)
+    a, r, h = dev.get_tallies()
+    dev.close()
+    assert N.array_equal(h, tl_b[2]) and N.allclose(a, tl_b[0], rtol=1e-12, atol=1e-9)
+
+
+def test_full_size_properties(ctx):
+    """
+    Benchmark-size run (NSTTF, 1e7 rays -- the per-GPU share of configs[3]) checked through size-independent
+    properties: energy conservation, accel == brute force, flux map == receiver tally, hit buffer == tally, and
+    the Monte-Carlo mean against the reference's own runs (tests/golden/mc_reference.npz, 3 sigma).
+    """
+    from tracer_amd import scenes
+    from tracer_amd.tracer_engine import TracerEngine
+    n = 10 ** 7
+    plant, field, rec, src = scenes.nsttf_field()
+    eng = TracerEngine(plant)
+    ue, ve = scenes.nsttf_fluxmap_edges()
+    eng.set_fluxmap(218, ue, ve)
+    out = {}
+    for accel in (False, True):
+        eng.reset_tallies(); plant.reset_all_optics()
+        eng.ray_tracer(scenes.nsttf_source(n, src, seed=31), reps=100, min_energy=1e-10, tree=False, accel=accel, seed=31)
+        a, r, h = eng.get_tallies()
+        out[accel] = (a.copy(), r.copy(), h.copy(), eng.get_fluxmap(218).copy(), dict(eng.stats))
+    (a0, r0, h0, f0, s0), (a1, r1, h1, f1, s1) = out[False], out[True]
+    assert N.array_equal(h0, h1) and s0['segments'] == s1['segments']
+    assert N.allclose(a0, a1, rtol=1e-10) and N.allclose(f0, f1, rtol=1e-9, atol=1e-9)
+    # energy: what a surface received is absorbed or reflected; reflected energy is received downstream or escapes
+    assert N.all(a1 <= r1 * (1 + 1e-12))
+    e_ray = 1000. * N.pi * src['radius'] ** 2 / n
+    assert N.isclose(r1[:218].sum(), h1[:218].sum() * e_ray, rtol=1e-9)      # heliostats only see source rays
+    assert s1['segments'] == n + h1.sum()                                      # every hit spawns exactly one more segment
+    assert N.isclose(f1.sum(), a1[218], rtol=1e-9)                           # all receiver hits fall on the 11 x 11 m map
+    hits = rec.get_surfaces()[0].get_optics_manager().get_all_hits()
+    assert len(hits[0]) == h1[218] and N.isclose(hits[0].sum(), a1[218], rtol=1e-9)
+    loc = rec.get_surfaces()[0].global_to_local(hits[1])
+    assert N.abs(loc[0]).max() <= 5.5 + 1e-9 and N.abs(loc[1]).max() <= 5.5 + 1e-9 and N.abs(loc[2]).max() < 1e-6
+    H2 = N.histogram2d(loc[0], loc[1], bins=[ue, ve], weights=hits[0])[0]
+    assert N.allclose(H2, f1, rtol=1e-9, atol=1e-6)                           # device flux map == caller-side histogram2d
+    mc = load('mc_reference.npz')
+    p_ref, se_ref = mc['nsttf_receiver_mean'], mc['nsttf_receiver_se']
+    # per-ray variance of the receiver power from the hit list -> standard error of this run
+    se_gpu = N.sqrt(N.sum(hits[0] ** 2))
+    assert abs(a1[218] - p_ref) <= 3. * N.sqrt(se_gpu ** 2 + se_ref ** 2), (a1[218], p_ref, se_gpu, se_ref)
+    frac_ref, frac_se = mc['nsttf_bounce_fractions_mean'], mc['nsttf_bounce_fractions_se']
+    frac = N.array([h1[:218].sum() / n, h1[218] / n])
+    assert N.all(N.abs(frac - frac_ref) <= 4. * N.sqrt(frac_se ** 2 + frac * (1 - frac) / n)), (frac, frac_ref)

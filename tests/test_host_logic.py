@@ -1,0 +1,140 @@
+"""Host-side logic (no GPU): bundles, frames, scene compilation, sources' host part, RNG plumbing, sharding."""
+import numpy as N
+import pytest
+
+from tracer_amd.ray_bundle import RayBundle, concatenate_rays
+from tracer_amd.assembly import Assembly
+from tracer_amd.object import AssembledObject
+from tracer_amd.surface import Surface
+from tracer_amd.flat_surface import RectPlateGM, RoundPlateGM, FlatGeometryManager
+from tracer_amd import optics_callables as opt
+from tracer_amd.spatial_geometry import general_axis_rotation, rotation_to_z, rotx, roty, rotz, translate
+from tracer_amd import _cabi, rng, sources, distributed
+from tracer_amd.scene import compile_scene, NotNativeError, scene_arrays, TableScene
+
+
+def test_ray_bundle_accessors_inherit_add_delete():
+    """behaviour pinned by the reference's tests/test_ray_bundle.py:12-100 (restated inputs)"""
+    v = N.arange(12.).reshape(3, 4)
+    d = N.tile(N.c_[[0., 0., 1.]], (1, 4))
+    b = RayBundle(vertices=v, directions=d, energy=N.r_[1., 2., 3., 4.], parents=N.arange(4), ref_index=N.ones(4), wavelengths=N.r_[5., 6., 7., 8.])
+    assert b.get_num_rays() == 4 and b.has_property('wavelengths') and not b.has_property('spectra')
+    assert N.array_equal(b.get_energy([1, 3]), [2., 4.])
+    assert N.array_equal(b.get_vertices(N.r_[0, 2]), v[:, [0, 2]])
+    c = b.inherit(N.r_[2, 0], energy=N.r_[9., 8.])
+    assert N.array_equal(c.get_energy(), [9., 8.]) and N.array_equal(c.get_wavelengths(), [7., 5.])
+    assert N.array_equal(c.get_vertices(), v[:, [2, 0]])
+    s = b + c
+    assert s.get_num_rays() == 6 and N.array_equal(s.get_parents(), [0, 1, 2, 3, 2, 0])
+    k = b.delete_rays(N.r_[1, 2])
+    assert N.array_equal(k.get_energy(), [1., 4.])
+    b.set_energy(N.r_[0., 0.], selector=N.r_[0, 1])
+    assert N.array_equal(b.get_energy(), [0., 0., 3., 4.])
+    e = RayBundle.empty_bund()
+    assert e.get_num_rays() == 0 and concatenate_rays([]).get_num_rays() == 0
+    assert concatenate_rays([k, c]).get_num_rays() == 4
+    with pytest.raises(AttributeError):
+        b.get_nonexistent()
+
+
+def test_frames_propagate_through_nested_assemblies():
+    """transform_children semantics of tests/test_objects.py:191-269 (restated)"""
+    s = Surface(FlatGeometryManager(), opt.perfect_mirror, location=N.r_[0., 0., 1.])
+    o = AssembledObject(surfs=[s], transform=translate(1., 0., 0.))
+    inner = Assembly(objects=[o], location=N.r_[0., 2., 0.])
+    outer = Assembly(subassemblies=[inner], rotation=rotz(N.pi / 2.)[:3, :3])
+    expected = N.dot(rotz(N.pi / 2.), N.dot(translate(0, 2., 0), N.dot(translate(1., 0, 0), translate(0, 0, 1.))))
+    assert N.allclose(s._temp_frame, expected)
+    outer.set_location(N.r_[5., 5., 5.])
+    assert N.allclose(s._temp_frame[:3, 3], expected[:3, 3] + 5.)
+    assert outer.get_surfaces() == [s] and outer.get_objects() == [o]
+    # ordering contract: objects of sub-assemblies first, own objects last
+    o2 = AssembledObject(surfs=[Surface(FlatGeometryManager(), opt.perfect_mirror)])
+    top = Assembly(objects=[o2], subassemblies=[inner])
+    assert top.get_objects() == [o, o2]
+
+
+def test_rotation_helpers():
+    R = general_axis_rotation(N.r_[0., 0., 1.], N.pi / 2.)
+    assert N.allclose(R, [[0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    for v in (N.r_[0., 0., 1.], N.r_[0., 0., -1.], N.r_[0.6, 0., 0.8], N.r_[0.36, 0.48, 0.8]):
+        M = rotation_to_z(v)
+        assert N.allclose(M[:, 2], v) and N.allclose(N.dot(M.T, M), N.eye(3), atol=1e-14)
+    assert N.allclose(N.dot(rotx(0.3), rotx(-0.3)), N.eye(4)) and N.allclose(roty(0.2)[:3, :3].T, roty(-0.2)[:3, :3])
+
+
+def test_scene_compilation_and_table_roundtrip():
+    m = Surface(RectPlateGM(2., 3.), opt.OneSidedRealReflectiveDetector(0.04, 1e-3, True))
+    r = Surface(RoundPlateGM(1., 0.25), opt.LambertianReceiver(0.9), location=N.r_[0., 0., 5.], rotation=rotx(N.pi)[:3, :3])
+    asm = Assembly(objects=[AssembledObject(surfs=[m]), AssembledObject(surfs=[r], transform=translate(0, 1., 0))])
+    cs = compile_scene(asm)
+    assert cs.n_surf == 2 and cs.capture == [True, True] and not cs.splits
+    d0, d1 = cs.descs[0], cs.descs[1]
+    assert (d0.gm_kind, d0.optics_kind) == (_cabi.GM_RECT, _cabi.OPT_ONE_SIDED_REAL_REFLECTIVE)
+    assert list(d0.gm)[:2] == [1., 1.5] and list(d0.opt)[:3] == [0.04, 1e-3, 1.]
+    assert (d1.gm_kind, d1.optics_kind) == (_cabi.GM_ROUND, _cabi.OPT_LAMBERTIAN) and list(d1.gm)[:2] == [1., 0.25]
+    assert N.allclose(N.array(list(d1.frame)).reshape(3, 4)[:, 3], [0., 1., 5.])
+    a = scene_arrays(cs)
+    ts = TableScene(a['gm_kind'], a['optics_kind'], a['frames'], a['gm'], a['opt'], a['extra'], a['extra_off'], a['extra_len'])
+    assert bytes(ts.descs)[:8] == bytes(cs.descs)[:8] and N.allclose(scene_arrays(ts)['frames'], a['frames'])
+
+    class MyOptics(object):
+        def __call__(self, geometry, rays, selector):
+            return rays.inherit(selector)
+    asm2 = Assembly(objects=[AssembledObject(surfs=[Surface(RectPlateGM(1., 1.), MyOptics())])])
+    with pytest.raises(NotNativeError):
+        compile_scene(asm2)
+    with pytest.raises(ValueError):
+        RectPlateGM(-1., 1.)
+    with pytest.raises(ValueError):
+        RoundPlateGM(1., 2.)
+
+
+def test_source_descriptors_host_part():
+    b = sources.buie_sunshape(1000, N.c_[[0., 0., 6.]], N.r_[0., 0., -1.], 2.5, 0.05, flux=1000., seed=3)
+    desc, n, seed, off = b.source_args()
+    assert (n, seed, off) == (1000, 3, 0) and b.is_pending() and b.get_num_rays() == 1000
+    assert N.isclose(desc.energy, 1000. * N.pi * 2.5 ** 2 / 1000.)
+    tab = N.array(list(desc.buie))
+    cdf = tab[422:633]
+    assert cdf[0] == 0. and N.all(N.diff(cdf) > 0) and cdf[-1] < 1. and tab[638] == 1.
+    assert N.allclose(N.array(list(desc.rot_dir)).reshape(3, 3)[:, 2], [0., 0., -1.])
+    r = sources.rect_bundle(10, N.c_[[0., 0., 1.]], N.r_[0., 0., -1.], 2., 3., 0.1)
+    assert list(r.source_args()[0].p)[:4] == [2., 3., 0.1, 1.] and N.isclose(r.source_args()[0].energy, 1. / 10.)
+    d = sources.disk_bundle(10, N.c_[[0., 0., 1.]], N.r_[0., 0., 1.], 1., N.pi / 2., flux=2.)
+    assert N.isclose(d.source_args()[0].energy, N.pi / 10. * 2.)
+    with pytest.raises(NotImplementedError):
+        sources.disk_bundle(10, N.c_[[0., 0., 1.]], N.r_[0., 0., 1.], 1., 0.1, x_cut=0.5)
+
+
+def test_rng_plumbing_and_sharding():
+    rng.seed(5)
+    a = [rng.next_seed() for _ in range(3)]
+    rng.seed(5)
+    assert a == [rng.next_seed() for _ in range(3)] and len(set(a)) == 3
+    covered = []
+    for r in range(8):
+        lo, hi = distributed.shard(1003, r, 8)
+        covered += list(range(lo, hi))
+    assert covered == list(range(1003))
+    offs = sorted(distributed.batch_offset(s, r, 4, 100) for s in range(3) for r in range(4))
+    assert offs == [100 * k for k in range(12)]
+
+
+def test_compat_aliases():
+    import sys
+    saved = dict((k, v) for k, v in sys.modules.items() if k == 'tracer' or k.startswith('tracer.'))
+    try:
+        for k in list(saved):
+            del sys.modules[k]
+        import tracer_amd.compat as compat
+        compat.install()
+        from tracer.surface import Surface as S2
+        from tracer.models.heliostat_field import HeliostatField
+        from tracer.optics_callables import LambertianReceiver
+        assert S2 is Surface and HeliostatField.__module__ == 'tracer_amd.models.heliostat_field'
+        assert LambertianReceiver(1.)._native()[0] == _cabi.OPT_LAMBERTIAN
+    finally:
+        for k in [k for k in sys.modules if k == 'tracer' or k.startswith('tracer.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
