@@ -61,7 +61,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--rays', type=float, default=1e8, help='source rays per step per GPU')
-    ap.add_argument('--cpu-rays', type=int, default=200000, help='source rays of the CPU baseline sample (0 = skip)')
+    ap.add_argument('--cpu-rays', type=int, default=600000, help='source rays of the CPU baseline sample (0 = skip)')
     ap.add_argument('--no-accel', action='store_true', help='brute force instead of the Kd-tree')
     args = ap.parse_args()
 

@@ -1,0 +1,109 @@
+// hostcheck.cpp -- TEST-ONLY host build of the per-ray core (tracer_amd/csrc/trc_core.h).
+//
+// The same header that hipcc compiles into the gfx950 kernels is compiled here by g++ so that the core math
+// can be checked against the golden fixtures and the oracle in the CPU-only test tier (and under sanitizers)
+// before GPU minutes are spent.  This library is built by `make hostcheck` into tests/hostcheck/, is loaded
+// only by tests/test_hostcheck.py, and is NOT a product path: nothing under tracer_amd/ knows it exists and
+// the product fails loudly without a GPU.
+#include <vector>
+#include <cstring>
+#include "../../tracer_amd/csrc/trc_core.h"
+
+static void pack_record(const trc_surface_desc &s, double *rec, int stride) {
+    for (int i = 0; i < stride; ++i) rec[i] = 0.0;
+    for (int r = 0; r < 3; ++r) {
+        for (int k = 0; k < 3; ++k) rec[3 * r + k] = s.frame[4 * r + k];
+        rec[9 + r] = s.frame[4 * r + 3];
+    }
+    int32_t *h = (int32_t *)(rec + 12);
+    h[0] = s.gm_kind; h[1] = s.optics_kind; h[2] = s.extra_off; h[3] = s.extra_len;
+    int np = trc_gm_nparams(s.gm_kind);
+    for (int i = 0; i < np; ++i) rec[TRC_REC_HDR + i] = s.gm[i];
+}
+
+struct HostKdStack {
+    int node[TRC_KD_STACK];
+    double tmax[TRC_KD_STACK];
+    void push(int sp, int n, double t) { node[sp] = n; tmax[sp] = t; }
+    void pop(int sp, int *n, double *t) { *n = node[sp]; *t = tmax[sp]; }
+};
+
+extern "C" {
+
+int hc_intersect(const trc_surface_desc *s, const double *extra, long n, const double *x, const double *y, const double *z,
+                 const double *dx, const double *dy, const double *dz, double *t) {
+    double rec[TRC_REC_HDR + 16];
+    pack_record(*s, rec, TRC_REC_HDR + 16);
+    for (long i = 0; i < n; ++i) t[i] = trc_intersect(rec, extra, x[i], y[i], z[i], dx[i], dy[i], dz[i]);
+    return 0;
+}
+
+int hc_normals(const trc_surface_desc *s, long n, const double *hx, const double *hy, const double *hz, const double *dx,
+               const double *dy, const double *dz, double *nx, double *ny, double *nz) {
+    double rec[TRC_REC_HDR + 16];
+    pack_record(*s, rec, TRC_REC_HDR + 16);
+    for (long i = 0; i < n; ++i) trc_normal(rec, hx[i], hy[i], hz[i], dx[i], dy[i], dz[i], &nx[i], &ny[i], &nz[i]);
+    return 0;
+}
+
+// shade: outputs 2n slots (child 0 at i, child 1 at n+i), blk = -1 when empty
+int hc_shade(const trc_surface_desc *s, const double *extra, long n, const double *dx, const double *dy, const double *dz,
+             const double *e, const double *ref, const double *wl, const double *nx, const double *ny, const double *nz,
+             const uint64_t *rid, uint64_t seed, int event, double *odx, double *ody, double *odz, double *oe, double *oref,
+             int *oblk) {
+    for (long i = 0; i < n; ++i) {
+        trc_ray_out out[2];
+        int no = trc_shade(s->optics_kind, s->opt, extra, s->extra_off, s->extra_len, s->frame[2], s->frame[6], s->frame[10],
+                           dx[i], dy[i], dz[i], e[i], ref[i], wl[i], nx[i], ny[i], nz[i], seed, rid[i], (uint32_t)event, out);
+        for (int c = 0; c < 2; ++c) {
+            long slot = c == 0 ? i : n + i;
+            if (c < no) {
+                odx[slot] = out[c].dx; ody[slot] = out[c].dy; odz[slot] = out[c].dz; oe[slot] = out[c].e; oref[slot] = out[c].ref;
+                oblk[slot] = out[c].blk;
+            } else oblk[slot] = -1;
+        }
+    }
+    return 0;
+}
+
+int hc_source(const trc_source_desc *src, long n, uint64_t seed, uint64_t offset, double *x, double *y, double *z, double *dx,
+              double *dy, double *dz) {
+    for (long i = 0; i < n; ++i)
+        trc_source_ray(src, src->buie, seed, offset + (uint64_t)i, &x[i], &y[i], &z[i], &dx[i], &dy[i], &dz[i]);
+    return 0;
+}
+
+// nearest hit over a whole scene, brute force and Kd-tree
+int hc_nearest(int n_surf, const trc_surface_desc *surfs, const double *extra, const trc_kdtree_desc *kd, long n, const double *x,
+               const double *y, const double *z, const double *dx, const double *dy, const double *dz, double *t_brute,
+               int *s_brute, double *t_kd, int *s_kd) {
+    int max_np = 0;
+    for (int i = 0; i < n_surf; ++i) { int np = trc_gm_nparams(surfs[i].gm_kind); if (np > max_np) max_np = np; }
+    int stride = TRC_REC_HDR + max_np;
+    if ((stride & 1) == 0) stride += 1;
+    std::vector<double> recs((size_t)n_surf * stride);
+    for (int i = 0; i < n_surf; ++i) pack_record(surfs[i], recs.data() + (size_t)i * stride, stride);
+    std::vector<int32_t> a, b;
+    trc_kd_view view;
+    memset(&view, 0, sizeof(view));
+    if (kd) {
+        a.resize(kd->n_nodes); b.resize(kd->n_nodes);
+        for (int i = 0; i < kd->n_nodes; ++i) {
+            if (kd->flag[i] == 3) { a[i] = (kd->leaf_off[i] << 2) | 3; b[i] = kd->leaf_cnt[i]; }
+            else { a[i] = (kd->child[i] << 2) | kd->flag[i]; b[i] = 0; }
+        }
+        view.node_a = a.data(); view.node_b = b.data(); view.split = kd->split; view.leaf_surfs = kd->leaf_surfs;
+        view.always = kd->always_relevant; view.n_always = kd->n_always;
+        for (int i = 0; i < 3; ++i) { view.bmin[i] = kd->bounds[i]; view.bmax[i] = kd->bounds[3 + i]; }
+    }
+    for (long i = 0; i < n; ++i) {
+        trc_nearest_brute(recs.data(), stride, n_surf, extra, x[i], y[i], z[i], dx[i], dy[i], dz[i], &t_brute[i], &s_brute[i]);
+        if (kd) {
+            HostKdStack stk;
+            trc_nearest_kd(view, stk, recs.data(), stride, extra, x[i], y[i], z[i], dx[i], dy[i], dz[i], &t_kd[i], &s_kd[i]);
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+"""
+CPU tier check of the per-ray core that the HIP kernels are made of: tracer_amd/csrc/trc_core.h compiled by g++
+(tests/hostcheck, test-only, never loaded by the product) against the reference fixtures and the oracle.  The
+authoritative parity tests are the GPU ones (test_gpu_parity.py); this tier catches core regressions in the build
+container, where there is no GPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as N
+import pytest
+
+from helpers import load, case_names, source_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, 'tests', 'hostcheck', 'libtrc_hostcheck.so')
+
+
+@pytest.fixture(scope='module')
+def hc():
+    subprocess.check_call(['make', '-C', ROOT, 'hostcheck'])
+    return C.CDLL(SO)
+
+
+def _p(a, typ=C.c_double):
+    return a.ctypes.data_as(C.POINTER(typ))
+
+
+def _desc(kind, frame, gm, extra, opt_kind=0, opt=()):
+    from tracer_amd import _cabi
+    from tracer_amd.geometry_manager import fill_desc
+    d = _cabi.SurfaceDesc()
+    fill_desc(d, frame, kind, list(gm), opt_kind, list(opt), extra_off=0 if len(extra) else -1, extra_len=len(extra))
+    return d
+
+
+def test_core_geometry_vs_reference(hc):
+    g = load('geometry.npz')
+    names = case_names(g)
+    for ci in range(int(g['n_cases'])):
+        pre = 'g%d_' % ci
+        kind = int(g[pre + 'kind'])
+        desc = _desc(kind, g[pre + 'frame'], g[pre + 'gm'], g[pre + 'extra'])
+        v = N.ascontiguousarray(g[pre + 'v']); d = N.ascontiguousarray(g[pre + 'd']); extra = N.ascontiguousarray(g[pre + 'extra'])
+        n = v.shape[1]
+        t = N.empty(n)
+        hc.hc_intersect(C.byref(desc), _p(extra), C.c_long(n), _p(v[0]), _p(v[1]), _p(v[2]), _p(d[0]), _p(d[1]), _p(d[2]), _p(t))
+        assert N.array_equal(N.isfinite(t), N.isfinite(g[pre + 't'])), names[ci]
+        idx = g[pre + 'hit_idx']
+        assert N.allclose(t[idx], g[pre + 't'][idx], rtol=1e-9, atol=1e-8), names[ci]
+        if len(idx):
+            h = N.ascontiguousarray(g[pre + 'hits']); dd = N.ascontiguousarray(d[:, idx])
+            nrm = N.empty_like(h)
+            hc.hc_normals(C.byref(desc), C.c_long(len(idx)), _p(h[0]), _p(h[1]), _p(h[2]), _p(dd[0]), _p(dd[1]), _p(dd[2]),
+                          _p(nrm[0]), _p(nrm[1]), _p(nrm[2]))
+            ok = N.all(N.isclose(nrm, g[pre + 'normals'], rtol=1e-9, atol=1e-9) | (N.isnan(nrm) & N.isnan(g[pre + 'normals'])), axis=0)
+            assert ok.all(), (names[ci], N.nonzero(~ok)[0][:5])
+
+
+def test_core_optics_vs_oracle_same_streams(hc):
+    from oracle import optics
+    o = load('optics.npz')
+    frame = o['frame']
+    nrm, d, e, wl = [N.ascontiguousarray(o[k]) for k in ('normals', 'dirs', 'energy', 'wavelengths')]
+    H = d.shape[1]
+    rid = N.arange(H, dtype=N.uint64) + N.uint64(2 ** 33 + 5)
+    for i, name in enumerate(case_names(o)):
+        pre = 'o%d_' % i
+        kind, opt, extra = int(o[pre + 'kind']), list(o[pre + 'opt']), N.ascontiguousarray(o[pre + 'extra'])
+        ref_in = N.ascontiguousarray(o[pre + 'ref_in'])
+        desc = _desc(0, frame, [], extra, kind, opt)
+        out = [N.empty(2 * H) for _ in range(5)]
+        blk = N.empty(2 * H, dtype=N.int32)
+        hc.hc_shade(C.byref(desc), _p(extra), C.c_long(H), _p(d[0]), _p(d[1]), _p(d[2]), _p(e), _p(ref_in), _p(wl), _p(nrm[0]), _p(nrm[1]),
+                    _p(nrm[2]), _p(rid, C.c_uint64), C.c_uint64(987654321012), 2, *[_p(a) for a in out], _p(blk, C.c_int32))
+        blocks = optics.shade(kind, opt, extra, frame[:3, 2], d, e, ref_in, wl, nrm, 987654321012, rid, 2)
+        slots = N.concatenate([N.nonzero(blk == b)[0] for b in (0, 1)])
+        par = N.where(slots < H, slots, slots - H)
+        assert N.array_equal(par, N.hstack([b['sel'] for b in blocks])), name
+        assert N.allclose(N.vstack([a[slots] for a in out[:3]]), N.hstack([b['directions'] for b in blocks]), rtol=1e-9, atol=1e-9), name
+        assert N.allclose(out[3][slots], N.hstack([b['energy'] for b in blocks]), rtol=1e-9, atol=1e-12), name
+        assert N.allclose(out[4][slots], N.hstack([b['ref'] for b in blocks])), name
+
+
+def test_core_sources_vs_oracle(hc):
+    from oracle import sources
+    from tracer_amd import _cabi
+    s = load('sources.npz')
+    for i, name in enumerate(case_names(s)):
+        src = source_dict(s, 's%d_' % i)
+        desc = _cabi.SourceDesc()
+        desc.kind = src['kind']
+        for k in range(3):
+            desc.center[k] = src['center'][k]
+        for k in range(9):
+            desc.rot_pos[k] = src['rot_pos'].ravel()[k]
+            desc.rot_dir[k] = src['rot_dir'].ravel()[k]
+        for k in range(8):
+            desc.p[k] = src['p'][k]
+        desc.energy = src['energy']
+        for k in range(_cabi.BUIE_LEN):
+            desc.buie[k] = src['buie'][k]
+        n = 20000
+        v = N.empty((3, n)); d = N.empty((3, n))
+        hc.hc_source(C.byref(desc), C.c_long(n), C.c_uint64(31337), C.c_uint64(10 ** 12), _p(v[0]), _p(v[1]), _p(v[2]), _p(d[0]), _p(d[1]), _p(d[2]))
+        vo, do, eo, rid = sources.generate(src, n, 31337, 10 ** 12)
+        assert N.allclose(v, vo, rtol=1e-10, atol=1e-8), name
+        assert N.allclose(d, do, rtol=1e-9, atol=1e-11), name
+
+
+def test_core_kd_traversal_equals_brute_force(hc):
+    """the device traversal (front-to-back with early exit) returns the brute-force (t, surface) for every ray"""
+    from tracer_amd import scenes, _cabi
+    from tracer_amd.accel_tree import KdTree
+    from tracer_amd.scene import compile_scene
+    from oracle import sources, engine
+    plant, field, rec, src = scenes.nsttf_field()
+    cs = compile_scene(plant)
+    kd = KdTree(plant, 8 + 1.3 * N.log(cs.n_surf), min_leaf=1)
+    f = kd.flat()
+    d = _cabi.KdTreeDesc()
+    d.n_nodes, d.n_leaf_surfs, d.n_always = len(f['flag']), len(f['leaf_surfs']), len(f['always_relevant'])
+    i32 = C.POINTER(C.c_int32)
+    d.flag, d.child, d.leaf_off, d.leaf_cnt = [f[k].ctypes.data_as(i32) for k in ('flag', 'child', 'leaf_off', 'leaf_cnt')]
+    d.leaf_surfs, d.always_relevant = f['leaf_surfs'].ctypes.data_as(i32), f['always_relevant'].ctypes.data_as(i32)
+    d.split = _p(f['split'])
+    for k in range(6):
+        d.bounds[k] = f['bounds'][k]
+    n = 60000
+    b = scenes.nsttf_source(n, src, seed=5)
+    v, dr, e, rid = sources.generate(engine.source_from_desc(b.source_args()[0]), n, 5, 0)
+    # second-bounce-like rays too: from mirror height towards the tower, and horizontal rays through the field
+    rng = N.random.RandomState(2)
+    v2 = N.vstack((rng.uniform(-130, 130, n // 3), rng.uniform(50, 190, n // 3), rng.uniform(0., 9., n // 3)))
+    t2 = N.vstack((rng.uniform(-8, 8, n // 3), rng.uniform(-20, 20, n // 3), rng.uniform(0, 70., n // 3)))
+    d2 = t2 - v2
+    d2 /= N.sqrt(N.sum(d2 ** 2, axis=0))
+    v = N.ascontiguousarray(N.hstack((v, v2))); dr = N.ascontiguousarray(N.hstack((dr, d2)))
+    m = v.shape[1]
+    tb, tk = N.empty(m), N.empty(m)
+    sb, sk = N.empty(m, dtype=N.int32), N.empty(m, dtype=N.int32)
+    extra = N.zeros(1)
+    hc.hc_nearest(cs.n_surf, cs.descs, _p(extra), C.byref(d), C.c_long(m), _p(v[0]), _p(v[1]), _p(v[2]), _p(dr[0]), _p(dr[1]), _p(dr[2]),
+                  _p(tb), _p(sb, C.c_int32), _p(tk), _p(sk, C.c_int32))
+    assert (sb >= 0).sum() > 5000
+    assert N.array_equal(sb, sk)
+    assert N.array_equal(tb, tk)
+    # and the oracle agrees with the brute-force core on which surface is hit first
+    scene = engine.scene_from_compiled(cs)
+    with N.errstate(all='ignore'):
+        front, tmin = engine.intersect_ray(scene, v[:, :20000], dr[:, :20000])
+    assert N.array_equal(front, sb[:20000])
