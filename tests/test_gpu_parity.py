@@ -360,9 +360,9 @@ def test_full_size_properties(ctx):
     # energy: what a surface received is absorbed or reflected; reflected energy is received downstream or escapes
     assert N.all(a1 <= r1 * (1 + 1e-12))
     e_ray = 1000. * N.pi * src['radius'] ** 2 / n
-    # a heliostat receives source rays (e_ray each) and, when it blocks a neighbour's reflection, 0.96 e_ray rays
-    assert h1[:218].sum() * e_ray * 0.96 <= r1[:218].sum() <= h1[:218].sum() * e_ray * (1 + 1e-12)
-    assert r1[218] <= 0.96 * e_ray * h1[218] * (1 + 1e-12)                   # the receiver only sees reflected rays
+    # every ray that lands anywhere carries e_ray (straight from the source) or 0.96 e_ray (one mirror reflection):
+    # one-sided mirrors absorb everything on their back and the receiver absorbs everything
+    assert N.all(r1 >= 0.96 * e_ray * h1 * (1 - 1e-12)) and N.all(r1 <= e_ray * h1 * (1 + 1e-12))
     assert s1['segments'] == n + h1.sum()                                      # every hit spawns exactly one more segment
     assert N.isclose(f1.sum(), a1[218], rtol=1e-9)                           # all receiver hits fall on the 11 x 11 m map
     hits = rec.get_surfaces()[0].get_optics_manager().get_all_hits()
