@@ -8,6 +8,7 @@
 #include <vector>
 #include <cstring>
 #include "../../tracer_amd/csrc/trc_core.h"
+#include "../../tracer_amd/csrc/trc_bounds.h"
 
 static void pack_record(const trc_surface_desc &s, double *rec, int stride) {
     for (int i = 0; i < stride; ++i) rec[i] = 0.0;
@@ -102,6 +103,40 @@ int hc_nearest(int n_surf, const trc_surface_desc *surfs, const double *extra, c
             HostKdStack stk;
             trc_nearest_kd(view, stk, recs.data(), stride, extra, x[i], y[i], z[i], dx[i], dy[i], dz[i], &t_kd[i], &s_kd[i]);
         }
+    }
+    return 0;
+}
+
+// the single-precision conservative candidate search + exact tests (the fast engine's hot path)
+struct HostStack32 {
+    uint32_t na[64];
+    float tmax[64];
+    void push(int sp, uint32_t n, float t) { na[sp] = n; tmax[sp] = t; }
+    void pop(int sp, uint32_t *n, float *t) { *n = na[sp]; *t = tmax[sp]; }
+};
+
+int hc_nearest32(int n_surf, const trc_surface_desc *surfs, const double *extra, const trc_kdtree_desc *kd, long n, const double *x,
+                 const double *y, const double *z, const double *dx, const double *dy, const double *dz, double *t_out, int *s_out) {
+    int max_np = 0;
+    for (int i = 0; i < n_surf; ++i) { int np = trc_gm_nparams(surfs[i].gm_kind); if (np > max_np) max_np = np; }
+    int stride = TRC_REC_HDR + max_np;
+    if ((stride & 1) == 0) stride += 1;
+    std::vector<double> recs((size_t)n_surf * stride);
+    for (int i = 0; i < n_surf; ++i) pack_record(surfs[i], recs.data() + (size_t)i * stride, stride);
+    trc_accel_host H;
+    trc_accel_build_surfaces(surfs, n_surf, H);
+    if (kd && !trc_accel_build_kd(kd, H)) return -1;
+    trc_accel_view A;
+    memset(&A, 0, sizeof(A));
+    A.sbox = H.sbox.data(); A.nodes = H.nodes.data(); A.leaf_surfs = H.leaf_surfs.data();
+    A.always = kd ? kd->always_relevant : nullptr; A.n_always = kd ? kd->n_always : 0;
+    A.unbounded = H.unbounded.data(); A.n_unbounded = (int)H.unbounded.size();
+    A.n_surf = n_surf; A.has_kd = kd ? 1 : 0; A.delta = H.delta; A.dbg = 0;
+    for (int k = 0; k < 6; ++k) A.root[k] = H.root[k];
+    for (int k = 0; k < 3; ++k) { A.cen[k] = H.cen[k]; A.slo[k] = H.slo[k]; A.shi[k] = H.shi[k]; }
+    for (long i = 0; i < n; ++i) {
+        HostStack32 stk;
+        trc_nearest_accel32(A, stk, recs.data(), stride, extra, x[i], y[i], z[i], dx[i], dy[i], dz[i], kd != nullptr, &t_out[i], &s_out[i]);
     }
     return 0;
 }

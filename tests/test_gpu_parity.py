@@ -363,7 +363,7 @@ def test_full_size_properties(ctx):
     # every ray that lands anywhere carries e_ray (straight from the source) or 0.96 e_ray (one mirror reflection):
     # one-sided mirrors absorb everything on their back and the receiver absorbs everything
     assert N.all(r1 >= 0.96 * e_ray * h1 * (1 - 1e-12)) and N.all(r1 <= e_ray * h1 * (1 + 1e-12))
-    assert s1['segments'] == n + h1.sum()                                      # every hit spawns exactly one more segment
+    assert n <= s1['segments'] <= n + h1[:218].sum()                         # only mirror hits can spawn another segment
     assert N.isclose(f1.sum(), a1[218], rtol=1e-9)                           # all receiver hits fall on the 11 x 11 m map
     hits = rec.get_surfaces()[0].get_optics_manager().get_all_hits()
     assert len(hits[0]) == h1[218] and N.isclose(hits[0].sum(), a1[218], rtol=1e-9)

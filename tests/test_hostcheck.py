@@ -146,6 +146,14 @@ def test_core_kd_traversal_equals_brute_force(hc):
     assert (sb >= 0).sum() > 5000
     assert N.array_equal(sb, sk)
     assert N.array_equal(tb, tk)
+    # the single-precision conservative search (fast engine): identical (t, surface), with and without the tree
+    for use_kd in (True, False):
+        t32, s32 = N.empty(m), N.empty(m, dtype=N.int32)
+        rc = hc.hc_nearest32(cs.n_surf, cs.descs, _p(extra), C.byref(d) if use_kd else None, C.c_long(m), _p(v[0]), _p(v[1]), _p(v[2]),
+                             _p(dr[0]), _p(dr[1]), _p(dr[2]), _p(t32), _p(s32, C.c_int32))
+        assert rc == 0
+        assert N.array_equal(s32, sb), use_kd
+        assert N.array_equal(t32, tb), use_kd
     # and the oracle agrees with the brute-force core on which surface is hit first
     scene = engine.scene_from_compiled(cs)
     with N.errstate(all='ignore'):

@@ -1,0 +1,165 @@
+// trc_bounds.h -- host-side construction of the single-precision acceleration data used by
+// trc_nearest_accel32 (trc_core.h): a conservative axis-aligned box for every bounded surface, derived from
+// the surface's own geometry (never from user-declared BoundaryBoxes), the scene box and centre, the
+// inflation `delta`, and the packed Kd nodes.  Plain C++ so that the test-only host build can use it too.
+#ifndef TRC_BOUNDS_H
+#define TRC_BOUNDS_H
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+#include "trc_core.h"
+
+// Box of a surface in global coordinates.  Returns false for unbounded kinds.
+// Every point the exact test of the kind can return lies inside the box (aperture rules of trc_core.h).
+static inline bool trc_surface_bounds(const trc_surface_desc &s, double lo[3], double hi[3]) {
+    const double *g = s.gm;
+    double l[3], h[3];   // local box
+    switch (s.gm_kind) {
+    case TRC_GM_RECT: case TRC_GM_RECT_EXTRUDED: case TRC_GM_RECT_PERFORATED:
+        l[0] = -g[0]; h[0] = g[0]; l[1] = -g[1]; h[1] = g[1]; l[2] = h[2] = 0.0; break;
+    case TRC_GM_ROUND: case TRC_GM_ROUND_CUT:
+        l[0] = l[1] = -g[0]; h[0] = h[1] = g[0]; l[2] = h[2] = 0.0; break;
+    case TRC_GM_TRIANGLE:
+        for (int i = 0; i < 3; ++i) { l[i] = std::fmin(0.0, std::fmin(g[i], g[3 + i])); h[i] = std::fmax(0.0, std::fmax(g[i], g[3 + i])); }
+        break;
+    case TRC_GM_PARAB_DISH: {
+        double rx = std::sqrt(g[2] / g[0]), ry = std::sqrt(g[2] / g[1]);
+        l[0] = -rx; h[0] = rx; l[1] = -ry; h[1] = ry; l[2] = 0.0; h[2] = g[2]; break;
+    }
+    case TRC_GM_PARAB_HEX:
+        l[0] = l[1] = -g[2]; h[0] = h[1] = g[2]; l[2] = 0.0; h[2] = (g[0] + g[1]) * g[2] * g[2]; break;
+    case TRC_GM_PARAB_RECT:
+        l[0] = -g[2]; h[0] = g[2]; l[1] = -g[3]; h[1] = g[3]; l[2] = 0.0; h[2] = g[0] * g[2] * g[2] + g[1] * g[3] * g[3]; break;
+    case TRC_GM_PARAB_TROUGH: {
+        double rx = std::sqrt(g[2] / g[0]);
+        l[0] = -rx; h[0] = rx; l[1] = -g[1]; h[1] = g[1]; l[2] = 0.0; h[2] = g[2]; break;
+    }
+    case TRC_GM_SPHERE: case TRC_GM_HEMISPHERE: case TRC_GM_SPHERE_RECT:
+        for (int i = 0; i < 3; ++i) { lo[i] = s.frame[4 * i + 3] - g[0]; hi[i] = s.frame[4 * i + 3] + g[0]; }
+        return true;
+    case TRC_GM_CYL_FINITE: case TRC_GM_CYL_RECTCUT:
+        l[0] = l[1] = -g[0]; h[0] = h[1] = g[0]; l[2] = -g[1]; h[2] = g[1]; break;
+    case TRC_GM_CONE_FINITE: {
+        double r = std::fabs(g[0]) * std::fmax(std::fabs(0.0 - g[1]), std::fabs(g[2] - g[1]));
+        l[0] = l[1] = -r; h[0] = h[1] = r; l[2] = 0.0; h[2] = g[2]; break;
+    }
+    case TRC_GM_FRUSTUM: case TRC_GM_FRUSTUM_RECTCUT: {
+        double r = std::fabs(g[0]) * std::fmax(std::fabs(g[2] - g[1]), std::fabs(g[3] - g[1]));
+        l[0] = l[1] = -r; h[0] = h[1] = r; l[2] = g[2]; h[2] = g[3];
+        if (s.gm_kind == TRC_GM_FRUSTUM_RECTCUT) { l[0] = -std::fmin(r, g[4]); h[0] = -l[0]; l[1] = -std::fmin(r, g[5]); h[1] = -l[1]; }
+        break;
+    }
+    case TRC_GM_QUADRATIC_RECT: {
+        double w = g[6], hh = g[7];
+        double m = std::fabs(g[0]) * w * w + std::fabs(g[1]) * hh * hh + std::fabs(g[2]) * w * hh + std::fabs(g[3]) * w +
+                   std::fabs(g[4]) * hh + std::fabs(g[5]);
+        l[0] = -w; h[0] = w; l[1] = -hh; h[1] = hh; l[2] = -m; h[2] = m; break;
+    }
+    case TRC_GM_ELLIPSOID: case TRC_GM_ELLIPSOID_CUT:
+        for (int i = 0; i < 3; ++i) { double r = 1.0 / std::sqrt(g[i]); l[i] = -r; h[i] = r; }
+        if (s.gm_kind == TRC_GM_ELLIPSOID_CUT)
+            for (int i = 0; i < 3; ++i) { l[i] = std::fmax(l[i], g[3 + 2 * i]); h[i] = std::fmin(h[i], g[4 + 2 * i]); }
+        break;
+    default:
+        return false;   // FLAT_INF, PARABOLOID, PARAB_RECT_OFFAXIS, PARAB_CYL, CYL_INF, CONE_INF, QUADRATIC
+    }
+    for (int i = 0; i < 3; ++i) if (!(l[i] <= h[i]) || !std::isfinite(l[i]) || !std::isfinite(h[i])) return false;
+    for (int i = 0; i < 3; ++i) { lo[i] = std::numeric_limits<double>::infinity(); hi[i] = -lo[i]; }
+    for (int c = 0; c < 8; ++c) {
+        double p[3] = {(c & 1) ? h[0] : l[0], (c & 2) ? h[1] : l[1], (c & 4) ? h[2] : l[2]};
+        for (int i = 0; i < 3; ++i) {
+            double q = s.frame[4 * i] * p[0] + s.frame[4 * i + 1] * p[1] + s.frame[4 * i + 2] * p[2] + s.frame[4 * i + 3];
+            lo[i] = std::fmin(lo[i], q); hi[i] = std::fmax(hi[i], q);
+        }
+    }
+    return true;
+}
+
+static inline float trc_f32_down(double x) { float f = (float)x; return ((double)f > x) ? std::nextafterf(f, -INFINITY) : f; }
+static inline float trc_f32_up(double x) { float f = (float)x; return ((double)f < x) ? std::nextafterf(f, INFINITY) : f; }
+
+struct trc_accel_host {
+    std::vector<float> sbox;          // 6 per surface
+    std::vector<int32_t> unbounded;
+    std::vector<uint32_t> nodes;      // 2 per Kd node
+    std::vector<uint16_t> leaf_surfs;
+    float root[6];
+    float delta;
+    double cen[3], slo[3], shi[3];
+    bool any_bounded;
+    int kd_depth;
+};
+
+// surfaces -> boxes, scene box, centre, delta
+static inline void trc_accel_build_surfaces(const trc_surface_desc *surfs, int n, trc_accel_host &A) {
+    const double INF = std::numeric_limits<double>::infinity();
+    std::vector<double> lo(3 * (size_t)n), hi(3 * (size_t)n);
+    std::vector<char> bounded(n);
+    double slo[3] = {INF, INF, INF}, shi[3] = {-INF, -INF, -INF};
+    A.unbounded.clear();
+    A.any_bounded = false;
+    for (int i = 0; i < n; ++i) {
+        bounded[i] = trc_surface_bounds(surfs[i], &lo[3 * (size_t)i], &hi[3 * (size_t)i]);
+        if (bounded[i]) {
+            A.any_bounded = true;
+            for (int k = 0; k < 3; ++k) { slo[k] = std::fmin(slo[k], lo[3 * (size_t)i + k]); shi[k] = std::fmax(shi[k], hi[3 * (size_t)i + k]); }
+        } else A.unbounded.push_back(i);
+    }
+    if (!A.any_bounded) for (int k = 0; k < 3; ++k) { slo[k] = 0.0; shi[k] = 0.0; }
+    double ext = 0.0;
+    for (int k = 0; k < 3; ++k) { A.cen[k] = 0.5 * (slo[k] + shi[k]); ext = std::fmax(ext, shi[k] - slo[k]); }
+    // float32 spacing at the largest relative coordinate is ~ext * 6e-8: delta is >= 400 such steps
+    double delta = std::fmax(1e-3, 2.5e-5 * ext);
+    A.delta = (float)delta;
+    for (int k = 0; k < 3; ++k) { A.slo[k] = slo[k] - 2.0 * delta; A.shi[k] = shi[k] + 2.0 * delta; }
+    A.sbox.assign(6 * (size_t)n, 0.0f);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            if (bounded[i]) {
+                A.sbox[6 * (size_t)i + k] = trc_f32_down(lo[3 * (size_t)i + k] - A.cen[k] - delta);
+                A.sbox[6 * (size_t)i + 3 + k] = trc_f32_up(hi[3 * (size_t)i + k] - A.cen[k] + delta);
+            } else {
+                A.sbox[6 * (size_t)i + k] = -INFINITY;
+                A.sbox[6 * (size_t)i + 3 + k] = INFINITY;
+            }
+        }
+}
+
+// Kd-tree -> packed nodes relative to the centre (call after trc_accel_build_surfaces). Returns false when the
+// tree cannot use the packed form (surface index or node count too large).
+static inline bool trc_accel_build_kd(const trc_kdtree_desc *kd, trc_accel_host &A) {
+    if (kd->n_nodes >= (1 << 28)) return false;
+    A.nodes.assign(2 * (size_t)kd->n_nodes, 0u);
+    A.leaf_surfs.assign((size_t)kd->n_leaf_surfs, 0);
+    for (int i = 0; i < kd->n_leaf_surfs; ++i) {
+        if (kd->leaf_surfs[i] > 65535) return false;
+        A.leaf_surfs[i] = (uint16_t)kd->leaf_surfs[i];
+    }
+    std::vector<int> depth(kd->n_nodes, 0);
+    A.kd_depth = 0;
+    for (int i = 0; i < kd->n_nodes; ++i) {
+        int f = kd->flag[i];
+        if (f == 3) {
+            A.nodes[2 * (size_t)i] = (uint32_t)kd->leaf_off[i];
+            A.nodes[2 * (size_t)i + 1] = ((uint32_t)kd->leaf_cnt[i] << 2) | 3u;
+        } else {
+            float sp = (float)(kd->split[i] - A.cen[f]);
+            uint32_t w;
+            std::memcpy(&w, &sp, 4);
+            A.nodes[2 * (size_t)i] = w;
+            A.nodes[2 * (size_t)i + 1] = ((uint32_t)kd->child[i] << 2) | (uint32_t)f;
+            int c = kd->child[i];
+            depth[c] = depth[c + 1] = depth[i] + 1;
+            if (depth[c] > A.kd_depth) A.kd_depth = depth[c];
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        A.root[k] = trc_f32_down(kd->bounds[k] - A.cen[k] - A.delta);
+        A.root[3 + k] = trc_f32_up(kd->bounds[3 + k] - A.cen[k] + A.delta);
+    }
+    return true;
+}
+
+#endif  // TRC_BOUNDS_H

@@ -563,6 +563,173 @@ TRC_HD void trc_nearest_kd(const trc_kd_view &kd, Stack &stk, const double *recs
 }
 
 // ---------------------------------------------------------------------------------------------
+// K2 (fast form) -- single-precision CONSERVATIVE candidate search + exact float64 tests.
+//
+// Only the *choice of candidates* is done in float32; every candidate that survives is tested with the
+// exact float64 trc_intersect above, and the winner is the lowest surface index among the minimal t, so
+// the result equals brute force over all surfaces (= the reference) as long as no true hit is ever
+// discarded.  That is guaranteed by construction:
+//   * every bounded surface carries an axis-aligned box derived from its own geometry (not from the
+//     user's BoundaryBox), inflated by `delta` >> float32 rounding of any coordinate in the scene;
+//     unbounded surfaces (infinite plane, paraboloid, cylinder, cone ...) are always tested exactly;
+//   * the ray is first advanced (in float64) to where it enters the scene box, so float32 coordinates are
+//     bounded by the scene size, and all coordinates are taken relative to the scene centre;
+//   * Kd split planes are treated as slabs of half-width delta: a child is skipped only if the ray's
+//     interval lies entirely beyond the slab; when the origin is within delta of a plane both children are
+//     visited; the walk stops early only when the best exact hit is nearer than the entry of everything
+//     left on the stack by more than the margin.
+// ---------------------------------------------------------------------------------------------
+struct trc_accel_view {
+    const float *sbox;         // n_surf * 6: lo xyz, hi xyz relative to cen, inflated; unbounded: -inf / +inf
+    const uint32_t *nodes;     // 2 words per node: interior {float split (rel), child<<2|axis}; leaf {leaf_off, cnt<<2|3}
+    const uint16_t *leaf_surfs;
+    const int32_t *always;     // Kd always_relevant surfaces
+    const int32_t *unbounded;  // surfaces without a box (tested exactly for every ray)
+    int32_t n_always, n_unbounded, n_surf, has_kd;
+    int32_t dbg;               // timing experiments: 1 = skip leaf lists, 2 = skip exact tests (results are wrong)
+    float root[6];             // Kd root box, relative, inflated
+    float delta;
+    double cen[3];
+    double slo[3], shi[3];     // scene box (absolute, inflated): union of all finite surface boxes
+};
+
+struct trc_ray32 {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz;
+};
+
+// does the ray (t' >= 0) cross the inflated box?  NaNs (0 * inf) are ignored by fminf/fmaxf: conservative
+TRC_HD bool trc_box_hit32(const float *b, const trc_ray32 &r) {
+    float ax = (b[0] - r.ox) * r.ix, bx = (b[3] - r.ox) * r.ix;
+    float ay = (b[1] - r.oy) * r.iy, by = (b[4] - r.oy) * r.iy;
+    float az = (b[2] - r.oz) * r.iz, bz = (b[5] - r.oz) * r.iz;
+    float lo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    // parametric rounding: 1e-4 relative on the far end is far above float32 error and far below delta's effect
+    return hi * 1.0001f + 1e-6f >= lo;
+}
+
+#define TRC_TEST_EXACT(S)                                                                                   \
+    do {                                                                                                    \
+        int _s = (S);                                                                                       \
+        double _t = trc_intersect(recs + (size_t)_s * stride, extra, vx, vy, vz, dx, dy, dz);               \
+        if (_t != 0.0 && (_t < tb || (_t == tb && _s < sb))) { tb = _t; sb = _s; }                          \
+    } while (0)
+
+// Stack: push(sp, node_and_axis, tmax) / pop(sp, &node_and_axis, &tmax)
+template <class Stack>
+TRC_HD void trc_nearest_accel32(const trc_accel_view &A, Stack &stk, const double *recs, int stride,
+                                const double *extra, double vx, double vy, double vz, double dx, double dy,
+                                double dz, bool use_kd, double *t_best, int *s_best) {
+    double tb = TRC_INF;
+    int sb = -1;
+    for (int k = 0; k < A.n_unbounded; ++k) TRC_TEST_EXACT(A.unbounded[k]);
+    // scene box in float64: where does the ray enter the region that holds every bounded surface?
+    double t0 = 0.0, t1 = TRC_INF;
+    {
+        const double v[3] = {vx, vy, vz}, d[3] = {dx, dy, dz};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double inv = 1.0 / d[i];
+            double a = (A.slo[i] - v[i]) * inv, b = (A.shi[i] - v[i]) * inv;
+            t0 = fmax(t0, fmin(a, b));
+            t1 = fmin(t1, fmax(a, b));
+        }
+    }
+    if (t1 >= t0) {
+        trc_ray32 r;
+        r.ox = (float)(vx + t0 * dx - A.cen[0]);
+        r.oy = (float)(vy + t0 * dy - A.cen[1]);
+        r.oz = (float)(vz + t0 * dz - A.cen[2]);
+        r.dx = (float)dx; r.dy = (float)dy; r.dz = (float)dz;
+        r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+        if (!use_kd) {
+            for (int s = 0; s < A.n_surf; ++s) {
+                const float *b = A.sbox + 6 * (size_t)s;
+                if (b[3] == TRC_INF && b[0] == -TRC_INF) continue;     // unbounded: already tested
+                if (trc_box_hit32(b, r)) TRC_TEST_EXACT(s);
+            }
+        } else {
+            for (int k = 0; k < A.n_always; ++k) {
+                int s = A.always[k];
+                const float *b = A.sbox + 6 * (size_t)s;
+                if (b[3] == TRC_INF && b[0] == -TRC_INF) continue;
+                if (trc_box_hit32(b, r)) TRC_TEST_EXACT(s);
+            }
+            // root slab
+            float ax = (A.root[0] - r.ox) * r.ix, bx = (A.root[3] - r.ox) * r.ix;
+            float ay = (A.root[1] - r.oy) * r.iy, by = (A.root[4] - r.oy) * r.iy;
+            float az = (A.root[2] - r.oz) * r.iz, bz = (A.root[5] - r.oz) * r.iz;
+            float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+            float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            tmax = tmax * 1.0001f + 1e-6f;
+            if (tmax >= tmin) {
+                const float delta = A.delta;
+                uint32_t node = 0;
+                int sp = 0;
+                for (;;) {
+                    uint32_t w0 = A.nodes[2 * node], w1 = A.nodes[2 * node + 1];
+                    uint32_t axis = w1 & 3u;
+                    if (axis != 3u) {
+                        float split = __builtin_bit_cast(float, w0);
+                        float o = axis == 0 ? r.ox : (axis == 1 ? r.oy : r.oz);
+                        float iv = axis == 0 ? r.ix : (axis == 1 ? r.iy : r.iz);
+                        float diff = split - o;
+                        uint32_t left = w1 >> 2, right = left + 1;
+                        if (fabsf(diff) <= delta) {
+                            // origin on the plane within tolerance: both children, full interval
+                            stk.push(sp, (right << 2) | 3u, tmax); ++sp;     // axis code 3: do not tighten on pop
+                            node = left;
+                        } else {
+                            uint32_t nearc = diff > 0.0f ? left : right, farc = diff > 0.0f ? right : left;
+                            float tp = diff * iv;
+                            float dt = delta * fabsf(iv);
+                            if (!(tp - dt <= tmax) || tp + dt < 0.0f) node = nearc;      // slab beyond the interval / behind
+                            else if (tp + dt < tmin) node = farc;                         // interval starts after the slab
+                            else {
+                                stk.push(sp, (farc << 2) | axis, tmax); ++sp;
+                                node = nearc;
+                                tmax = fminf(tmax, tp + dt);
+                            }
+                        }
+                    } else {
+                        uint32_t off = w0, cnt = w1 >> 2;
+                        if (A.dbg == 1) cnt = 0;
+                        for (uint32_t k = 0; k < cnt; ++k) {
+                            int s = A.leaf_surfs[off + k];
+                            if (trc_box_hit32(A.sbox + 6 * (size_t)s, r)) {
+                                if (A.dbg == 2) { if (tb > 1e300) { tb = 1e299; sb = -1; } }
+                                else TRC_TEST_EXACT(s);
+                            }
+                        }
+                        if (sp == 0) break;
+                        --sp;
+                        uint32_t na;
+                        float tmax_far;
+                        stk.pop(sp, &na, &tmax_far);
+                        uint32_t pax = na & 3u;
+                        node = na >> 2;
+                        // entry of the far child: the near subtree ended at (plane + dt); the far one starts at (plane - dt)
+                        if (pax != 3u) {
+                            float iv = pax == 0 ? r.ix : (pax == 1 ? r.iy : r.iz);
+                            tmin = fmaxf(0.0f, tmax - 2.0f * delta * fabsf(iv) - 1e-5f * fabsf(tmax));
+                        } else {
+                            tmin = 0.0f;
+                        }
+                        tmax = tmax_far;
+                        if (sb >= 0) {
+                            float tbr = (float)(tb - t0);
+                            if (tbr < tmin - (1e-3f + 1e-5f * fabsf(tbr))) break;   // everything left starts behind the best hit
+                        }
+                    }
+                }
+            }
+        }
+    }
+    *t_best = tb;
+    *s_best = sb;
+}
+
+// ---------------------------------------------------------------------------------------------
 // O1..O6 -- optics.  One interaction of one ray; at most two outgoing rays.
 // ---------------------------------------------------------------------------------------------
 struct trc_ray_out {

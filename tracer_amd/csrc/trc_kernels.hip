@@ -26,6 +26,7 @@
 #include <new>
 
 #include "trc_core.h"
+#include "trc_bounds.h"
 
 // ================================================================================================
 // error handling
@@ -88,6 +89,15 @@ struct DScene {
     const double *kd_split;
     int32_t kd_nodes, kd_nleaf, kd_nalways, kd_pad;
     double kd_bmin[3], kd_bmax[3];
+    // single-precision acceleration data (trc_bounds.h)
+    const float *a_sbox;
+    const uint32_t *a_nodes;
+    const uint16_t *a_leaf;
+    const int32_t *a_unbounded;
+    int32_t a_n_unbounded, a_kd_depth, a_ok, a_kd_ok;
+    float a_root[6];
+    float a_delta, a_pad;
+    double a_cen[3], a_slo[3], a_shi[3];
     // tallies: [absorbed S | received S | count S | segments, hits | flux bins ...]
     double *tally;
     // flux maps
@@ -116,6 +126,12 @@ struct trc_scene {
     int32_t kd_nodes, kd_nleaf, kd_nalways;
     double kd_bounds[6];
     bool has_kd;
+    trc_accel_host accel;
+    bool accel_ok, accel_kd_ok;
+    float *d_a_sbox;
+    uint32_t *d_a_nodes;
+    uint16_t *d_a_leaf;
+    int32_t *d_a_unbounded;
     double *d_tally;
     int64_t tally_n;
     std::vector<FluxMapDev> fms_h;
@@ -266,24 +282,326 @@ struct FastParams {
     int capture;      // some surface captures hits
 };
 
-// LDS layout (doubles): [recs S*stride][kd_split nodes][buie 639][tally 3S+2] then int32: [kd_a][kd_b][leaf][always]
-__global__ __launch_bounds__(256) void k_trace_fast(FastParams P) {
+// per-wave traversal stack of the single-precision search, in LDS: entry (sp, lane) at base[sp * 64 + lane]
+struct LdsStack32 {
+    uint2 *base;
+    unsigned lane;
+    __device__ __forceinline__ void push(int sp, uint32_t n, float t) { base[sp * 64 + lane] = make_uint2(n, __float_as_uint(t)); }
+    __device__ __forceinline__ void pop(int sp, uint32_t *n, float *t) {
+        uint2 v = base[sp * 64 + lane];
+        *n = v.x;
+        *t = __uint_as_float(v.y);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Wave-cooperative form of trc_nearest_accel32 (same candidates, same exact tests, same winner).
+//
+// Per ray the Kd walk touches ~7 nodes and ~10 candidate boxes, but the slowest of 64 lanes touches ~32 and ~90,
+// and an exact float64 test executed by one lane stalls the other 63.  So the wave separates the three kinds of
+// work and load-balances the last two across lanes through LDS queues:
+//   1. each lane walks the tree for its own ray (single precision, LDS stack) and only RECORDS (lane, surface)
+//      candidates of the leaves it crosses;
+//   2. all 64 lanes drain the candidate queue together, one (ray, box) test per lane per round;
+//   3. survivors go to a second queue; all lanes drain it with the exact float64 test of trc_core.h and combine
+//      results per ray with LDS atomics: minimal t, then lowest surface index among equal t.
+// Every lane of the wave must call it (inactive lanes pass active=false).
+// ------------------------------------------------------------------------------------------------
+#define COOP_Q 256           // candidate queue entries per wave
+#define COOP_E 128           // exact-test queue entries per wave
+#define COOP_MAX_NODES 16384 // stack entries are 4 bytes: node (14 bits) | axis code (2 bits) | interval end (16 bits)
+#define COOP_MAX_DEPTH 24
+#define COOP_FIXED_BYTES (6 * 64 * 4 + 6 * 64 * 8 + COOP_Q * 4 + COOP_E * 4 + COOP_E * 8 + 64 * 8 + 64 * 4 + 64 * 4)
+#define COOP_WAVE_BYTES(DEPTH) ((size_t)(DEPTH) * 64 * 4 + COOP_FIXED_BYTES)
+
+struct CoopLds {
+    uint32_t *stack;              // [depth][64]
+    double *rd;                   // [6][64]  ray origin / direction, float64
+    double *exq_t;                // [COOP_E]
+    unsigned long long *best_t;   // [64]
+    float *rf;                    // [6][64]  relative origin / inverse direction, float32
+    uint32_t *candq;              // [COOP_Q]
+    uint32_t *exq;                // [COOP_E]
+    int *best_s;                  // [64]
+    int *dirty;                   // [64]
+};
+
+__device__ __forceinline__ CoopLds coop_carve(char *base, int depth) {
+    CoopLds W;
+    W.rd = (double *)base; base += 6 * 64 * 8;
+    W.exq_t = (double *)base; base += COOP_E * 8;
+    W.best_t = (unsigned long long *)base; base += 64 * 8;
+    W.rf = (float *)base; base += 6 * 64 * 4;
+    W.candq = (uint32_t *)base; base += COOP_Q * 4;
+    W.exq = (uint32_t *)base; base += COOP_E * 4;
+    W.best_s = (int *)base; base += 64 * 4;
+    W.dirty = (int *)base; base += 64 * 4;
+    W.stack = (uint32_t *)base;
+    (void)depth;
+    return W;
+}
+
+// LDS traffic between lanes of one wave: order it for the compiler and the hardware
+#define WAVE_SYNC()                                              \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
+
+// drain the exact-test queue (wave-uniform call)
+__device__ __forceinline__ void coop_drain_exact(const CoopLds &W, int ecount, const double *recs, int stride,
+                                                 const double *extra, unsigned lane) {
+    WAVE_SYNC();
+    for (int base = 0; base < ecount; base += 64) {
+        int i = base + (int)lane;
+        if (i < ecount) {
+            uint32_t en = W.exq[i];
+            int L = (int)(en >> 16), sidx = (int)(en & 0xFFFFu);
+            double t = trc_intersect(recs + (size_t)sidx * stride, extra, W.rd[L], W.rd[64 + L], W.rd[128 + L], W.rd[192 + L],
+                                     W.rd[256 + L], W.rd[320 + L]);
+            if (!(t > 0.0) || !(t < TRC_INF)) t = TRC_INF;    // t == 0 is not a hit (tracer_engine.py:58)
+            W.exq_t[i] = t;
+            if (t < TRC_INF) {
+                unsigned long long bits = (unsigned long long)__double_as_longlong(t);   // t > 0: bit order = numeric order
+                unsigned long long old = atomicMin(&W.best_t[L], bits);
+                if (bits < old) W.dirty[L] = 1;
+            }
+        }
+    }
+    WAVE_SYNC();
+    if (W.dirty[lane]) { W.best_s[lane] = 0x7FFFFFFF; W.dirty[lane] = 0; }   // a strictly nearer hit: forget the old surface
+    WAVE_SYNC();
+    for (int base = 0; base < ecount; base += 64) {
+        int i = base + (int)lane;
+        if (i < ecount) {
+            double t = W.exq_t[i];
+            if (t < TRC_INF) {
+                uint32_t en = W.exq[i];
+                int L = (int)(en >> 16), sidx = (int)(en & 0xFFFFu);
+                if ((unsigned long long)__double_as_longlong(t) == W.best_t[L]) atomicMin(&W.best_s[L], sidx);   // lowest index wins ties
+            }
+        }
+    }
+    WAVE_SYNC();
+}
+
+// append (lane, surface) to the exact queue for the lanes whose `want` is set (wave-uniform call); drains when full
+__device__ __forceinline__ void coop_push_exact(const CoopLds &W, int &ecount, bool want, uint32_t entry, const double *recs,
+                                                int stride, const double *extra, unsigned lane) {
+    unsigned long long m = __ballot(want);
+    if (!m) return;
+    int add = __popcll(m);
+    if (ecount + add > COOP_E) { coop_drain_exact(W, ecount, recs, stride, extra, lane); ecount = 0; }
+    if (want) W.exq[ecount + __popcll(m & ((1ull << lane) - 1ull))] = entry;
+    ecount += add;
+}
+
+// drain the candidate queue: one (ray, box) test per lane per round (wave-uniform call)
+__device__ __forceinline__ void coop_drain_cand(const trc_accel_view &A, const CoopLds &W, int qcount, int &ecount,
+                                                const double *recs, int stride, const double *extra, unsigned lane) {
+    WAVE_SYNC();
+    for (int base = 0; base < qcount; base += 64) {
+        int i = base + (int)lane;
+        bool hit = false;
+        uint32_t en = 0;
+        if (i < qcount) {
+            en = W.candq[i];
+            int L = (int)(en >> 16), sidx = (int)(en & 0xFFFFu);
+            trc_ray32 r;
+            r.ox = W.rf[L]; r.oy = W.rf[64 + L]; r.oz = W.rf[128 + L];
+            r.ix = W.rf[192 + L]; r.iy = W.rf[256 + L]; r.iz = W.rf[320 + L];
+            r.dx = r.dy = r.dz = 0.0f;
+            hit = trc_box_hit32(A.sbox + 6 * (size_t)sidx, r);
+        }
+        coop_push_exact(W, ecount, hit, en, recs, stride, extra, lane);
+    }
+}
+
+__device__ __forceinline__ void nearest_coop32(const trc_accel_view &A, const CoopLds &W, const double *recs, int stride,
+                                               const double *extra, bool active, double vx, double vy, double vz, double dx,
+                                               double dy, double dz, double *t_best, int *s_best) {
+    const unsigned lane = lane_id();
+    double tb = TRC_INF;
+    int sb = -1;
+    // surfaces without a box: every active ray tests them (uniform loop, no divergence between active lanes)
+    if (active)
+        for (int k = 0; k < A.n_unbounded; ++k) TRC_TEST_EXACT(A.unbounded[k]);
+    W.best_t[lane] = (unsigned long long)__double_as_longlong(TRC_INF);
+    W.best_s[lane] = 0x7FFFFFFF;
+    W.dirty[lane] = 0;
+    W.rd[lane] = vx; W.rd[64 + lane] = vy; W.rd[128 + lane] = vz;
+    W.rd[192 + lane] = dx; W.rd[256 + lane] = dy; W.rd[320 + lane] = dz;
+    // scene box (float64): entry point of the region holding every bounded surface
+    double t0 = 0.0, t1 = TRC_INF;
+    {
+        const double v[3] = {vx, vy, vz}, d[3] = {dx, dy, dz};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double inv = 1.0 / d[i];
+            double a = (A.slo[i] - v[i]) * inv, b = (A.shi[i] - v[i]) * inv;
+            t0 = fmax(t0, fmin(a, b));
+            t1 = fmin(t1, fmax(a, b));
+        }
+    }
+    const bool in = active && (t1 >= t0);
+    trc_ray32 r;
+    r.ox = (float)(vx + t0 * dx - A.cen[0]);
+    r.oy = (float)(vy + t0 * dy - A.cen[1]);
+    r.oz = (float)(vz + t0 * dz - A.cen[2]);
+    r.dx = (float)dx; r.dy = (float)dy; r.dz = (float)dz;
+    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+    W.rf[lane] = r.ox; W.rf[64 + lane] = r.oy; W.rf[128 + lane] = r.oz;
+    W.rf[192 + lane] = r.ix; W.rf[256 + lane] = r.iy; W.rf[320 + lane] = r.iz;
+    int ecount = 0;   // wave-uniform
+    int qcount = 0;   // wave-uniform
+    const uint32_t me = (uint32_t)lane << 16;
+    if (!A.has_kd) {
+        // brute force over the boxes: same surface for all lanes at a time, survivors queued for the exact test
+        for (int sidx = 0; sidx < A.n_surf; ++sidx) {
+            const float *b = A.sbox + 6 * (size_t)sidx;
+            bool bounded = !(b[3] == TRC_INF && b[0] == -TRC_INF);
+            bool hit = in && bounded && trc_box_hit32(b, r);
+            coop_push_exact(W, ecount, hit, me | (uint32_t)sidx, recs, stride, extra, lane);
+        }
+    } else {
+        for (int k = 0; k < A.n_always; ++k) {
+            int sidx = A.always[k];
+            const float *b = A.sbox + 6 * (size_t)sidx;
+            bool bounded = !(b[3] == TRC_INF && b[0] == -TRC_INF);
+            bool hit = in && bounded && trc_box_hit32(b, r);
+            coop_push_exact(W, ecount, hit, me | (uint32_t)sidx, recs, stride, extra, lane);
+        }
+        // root slab
+        float ax = (A.root[0] - r.ox) * r.ix, bx = (A.root[3] - r.ox) * r.ix;
+        float ay = (A.root[1] - r.oy) * r.iy, by = (A.root[4] - r.oy) * r.iy;
+        float az = (A.root[2] - r.oz) * r.iz, bz = (A.root[5] - r.oz) * r.iz;
+        float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+        float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        tmax = tmax * 1.0001f + 1e-6f;
+        bool walking = in && (tmax >= tmin);
+        const float delta = A.delta;
+        uint32_t node = 0;
+        int sp = 0;
+        uint32_t leaf_off = 0, leaf_rem = 0;   // surfaces of the current leaf still to be recorded
+        // stack entry: (node << 18) | (axis code << 16) | interval end as the upper half of a float32, rounded UP
+        // (the interval only ever grows: conservative)
+#define COOP_PUSH(NA, T)                                                                                   \
+    do {                                                                                                   \
+        uint32_t _b = __float_as_uint(T);                                                                  \
+        uint32_t _h = (_b >> 16) + ((_b & 0xFFFFu) ? 1u : 0u);                                             \
+        W.stack[sp * 64 + lane] = ((NA) << 16) | (_h & 0xFFFFu);                                           \
+        ++sp;                                                                                              \
+    } while (0)
+        while (__ballot(walking)) {
+            if (walking && leaf_rem == 0) {
+                uint32_t w0 = A.nodes[2 * node], w1 = A.nodes[2 * node + 1];
+                uint32_t axis = w1 & 3u;
+                if (axis != 3u) {
+                    float split = __uint_as_float(w0);
+                    float o = axis == 0 ? r.ox : (axis == 1 ? r.oy : r.oz);
+                    float iv = axis == 0 ? r.ix : (axis == 1 ? r.iy : r.iz);
+                    float diff = split - o;
+                    uint32_t left = w1 >> 2, right = left + 1;
+                    if (fabsf(diff) <= delta) {
+                        // origin on the plane within tolerance: both children with the full interval
+                        COOP_PUSH((right << 2) | 3u, tmax);
+                        node = left;
+                    } else {
+                        uint32_t nearc = diff > 0.0f ? left : right, farc = diff > 0.0f ? right : left;
+                        float tp = diff * iv;
+                        float dt = delta * fabsf(iv);
+                        if (!(tp - dt <= tmax) || tp + dt < 0.0f) node = nearc;        // slab beyond the interval / behind
+                        else if (tp + dt < tmin) node = farc;                           // interval starts after the slab
+                        else {
+                            COOP_PUSH((farc << 2) | axis, tmax);                        // far child keeps the interval end
+                            node = nearc;
+                            tmax = fminf(tmax, tp + dt);
+                        }
+                    }
+                } else {
+                    leaf_off = w0;
+                    leaf_rem = w1 >> 2;
+                    if (leaf_rem == 0) leaf_rem = 0xFFFFFFFFu;   // empty leaf: go straight to the pop below
+                }
+            }
+            // ---- record the surfaces of the leaves reached in this step (wave-uniform section) ----
+            const bool at_leaf = walking && leaf_rem != 0;
+            if (__ballot(at_leaf)) {
+                uint32_t c = (at_leaf && leaf_rem != 0xFFFFFFFFu) ? (leaf_rem < 16u ? leaf_rem : 16u) : 0u;
+                // total <= 64 * 16 entries would overflow a 256-entry queue: record in slices of 4 per lane
+                for (uint32_t k0 = 0; __ballot(c > k0); k0 += 4) {
+                    unsigned long long m0 = __ballot(c > k0), m1 = __ballot(c > k0 + 1), m2 = __ballot(c > k0 + 2), m3 = __ballot(c > k0 + 3);
+                    int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+                    if (qcount + n0 + n1 + n2 + n3 > COOP_Q) { coop_drain_cand(A, W, qcount, ecount, recs, stride, extra, lane); qcount = 0; }
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+                    if (c > k0) W.candq[qcount + __popcll(m0 & lt)] = me | A.leaf_surfs[leaf_off + k0];
+                    if (c > k0 + 1) W.candq[qcount + n0 + __popcll(m1 & lt)] = me | A.leaf_surfs[leaf_off + k0 + 1];
+                    if (c > k0 + 2) W.candq[qcount + n0 + n1 + __popcll(m2 & lt)] = me | A.leaf_surfs[leaf_off + k0 + 2];
+                    if (c > k0 + 3) W.candq[qcount + n0 + n1 + n2 + __popcll(m3 & lt)] = me | A.leaf_surfs[leaf_off + k0 + 3];
+                    qcount += n0 + n1 + n2 + n3;
+                }
+                if (at_leaf) {
+                    if (leaf_rem == 0xFFFFFFFFu) leaf_rem = 0;
+                    else { leaf_off += c; leaf_rem -= c; }
+                    if (leaf_rem == 0) {
+                        // leaf finished: next subtree from the stack
+                        if (sp == 0) walking = false;
+                        else {
+                            --sp;
+                            uint32_t en = W.stack[sp * 64 + lane];
+                            uint32_t na = en >> 16;
+                            float tmax_far = __uint_as_float(en << 16);
+                            uint32_t pax = na & 3u;
+                            node = na >> 2;
+                            if (pax != 3u) {
+                                float iv = pax == 0 ? r.ix : (pax == 1 ? r.iy : r.iz);
+                                tmin = fmaxf(0.0f, tmax - 2.0f * delta * fabsf(iv) - 1e-5f * fabsf(tmax));
+                            } else tmin = 0.0f;
+                            tmax = tmax_far;
+                        }
+                    }
+                }
+            }
+        }
+        coop_drain_cand(A, W, qcount, ecount, recs, stride, extra, lane);
+    }
+    coop_drain_exact(W, ecount, recs, stride, extra, lane);
+    // merge the queued results of this lane's ray with the inline ones (unbounded surfaces)
+    unsigned long long bt = W.best_t[lane];
+    double tq = __longlong_as_double((long long)bt);
+    int sq = W.best_s[lane];
+    if (tq < TRC_INF && (tq < tb || (tq == tb && sq < sb))) { tb = tq; sb = sq; }
+    WAVE_SYNC();
+    *t_best = tb;
+    *s_best = sb;
+}
+
+// M32 = false: generic float64 traversal; scene records (+ Kd arrays) staged in LDS when they fit.
+//   LDS (doubles): [recs S*stride][kd_split nodes][buie 639][tally 3S+2] then int32: [kd_a][kd_b][leaf][always]
+// M32 = true: single-precision conservative candidate search (trc_nearest_accel32), exact tests read the records
+//   from global memory (they are rare).
+//   LDS: doubles [buie 639][tally 3S+2] | float [sbox 6S] | u32 [nodes 2n] | i32 [always][unbounded] | u16 [leaf] |
+//        8-byte aligned stacks: waves x depth x 64 x 8 B
+template <int THREADS, bool M32>
+__global__ __launch_bounds__(THREADS) void k_trace_fast(FastParams P) {
     extern __shared__ double lds[];
     const DScene &sc = P.sc;
     const int S = sc.n_surf;
     const int tid = threadIdx.x;
+    const unsigned lane = lane_id();
 
     const double *recs = sc.recs;
     const double *kd_split = sc.kd_split;
     const int32_t *kd_a = sc.kd_a, *kd_b = sc.kd_b, *kd_leaf = sc.kd_leaf, *kd_always = sc.kd_always;
     double *cursor = lds;
-    if (P.lds_scene) {
+    if (!M32 && P.lds_scene) {
         double *l_recs = cursor; cursor += (size_t)S * sc.stride;
-        for (int i = tid; i < S * sc.stride; i += blockDim.x) l_recs[i] = sc.recs[i];
+        for (int i = tid; i < S * sc.stride; i += THREADS) l_recs[i] = sc.recs[i];
         recs = l_recs;
         if (sc.has_kd) {
             double *l_split = cursor; cursor += sc.kd_nodes;
-            for (int i = tid; i < sc.kd_nodes; i += blockDim.x) l_split[i] = sc.kd_split[i];
+            for (int i = tid; i < sc.kd_nodes; i += THREADS) l_split[i] = sc.kd_split[i];
             kd_split = l_split;
         }
     }
@@ -292,23 +610,53 @@ __global__ __launch_bounds__(256) void k_trace_fast(FastParams P) {
         const int NB = 3 * (TRC_BUIE_NELEM + 1) + 6;
         double *l_buie = cursor; cursor += NB;
         if (P.src->kind == TRC_SRC_BUIE_DISK || P.src->kind == TRC_SRC_BUIE_RECT)
-            for (int i = tid; i < NB; i += blockDim.x) l_buie[i] = P.src->buie[i];
+            for (int i = tid; i < NB; i += THREADS) l_buie[i] = P.src->buie[i];
         buie = l_buie;
     }
     double *l_tally = cursor;
     if (P.lds_tally) {
         cursor += 3 * S + 2;
-        for (int i = tid; i < 3 * S + 2; i += blockDim.x) l_tally[i] = 0.0;
+        for (int i = tid; i < 3 * S + 2; i += THREADS) l_tally[i] = 0.0;
     }
-    if (P.lds_scene && sc.has_kd) {
+    trc_accel_view A;
+    A.dbg = 0;
+    CoopLds coopW;
+    if (M32) {
+        const bool kd32 = sc.a_kd_ok && (P.flags & TRC_TRACE_ACCEL);
+        float *l_sbox = (float *)cursor;
+        for (int i = tid; i < 6 * S; i += THREADS) l_sbox[i] = sc.a_sbox[i];
+        uint32_t *l_nodes = (uint32_t *)(l_sbox + 6 * S);
+        const int nn = kd32 ? sc.kd_nodes : 0;
+        for (int i = tid; i < 2 * nn; i += THREADS) l_nodes[i] = sc.a_nodes[i];
+        int32_t *l_alw = (int32_t *)(l_nodes + 2 * nn);
+        const int na = kd32 ? sc.kd_nalways : 0;
+        for (int i = tid; i < na; i += THREADS) l_alw[i] = sc.kd_always[i];
+        int32_t *l_unb = l_alw + na;
+        for (int i = tid; i < sc.a_n_unbounded; i += THREADS) l_unb[i] = sc.a_unbounded[i];
+        uint16_t *l_leaf = (uint16_t *)(l_unb + sc.a_n_unbounded);
+        const int nl = kd32 ? sc.kd_nleaf : 0;
+        for (int i = tid; i < nl; i += THREADS) l_leaf[i] = sc.a_leaf[i];
+        size_t off = (size_t)((char *)(l_leaf + nl) - (char *)lds);
+        off = (off + 15) & ~(size_t)15;
+        const int depth = kd32 ? (sc.a_kd_depth > 0 ? sc.a_kd_depth : 1) : 1;
+        coopW = coop_carve((char *)lds + off + (size_t)(tid >> 6) * COOP_WAVE_BYTES(depth), depth);
+        A.sbox = l_sbox; A.nodes = l_nodes; A.leaf_surfs = l_leaf; A.always = l_alw; A.unbounded = l_unb;
+        A.n_always = na; A.n_unbounded = sc.a_n_unbounded; A.n_surf = S; A.has_kd = kd32 ? 1 : 0;
+        A.dbg = (P.flags >> 8) & 3;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) A.root[i] = sc.a_root[i];
+        A.delta = sc.a_delta;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { A.cen[i] = sc.a_cen[i]; A.slo[i] = sc.a_slo[i]; A.shi[i] = sc.a_shi[i]; }
+    } else if (P.lds_scene && sc.has_kd) {
         int32_t *ic = (int32_t *)cursor;
         int32_t *l_a = ic; ic += sc.kd_nodes;
         int32_t *l_b = ic; ic += sc.kd_nodes;
         int32_t *l_leaf = ic; ic += sc.kd_nleaf;
         int32_t *l_alw = ic;
-        for (int i = tid; i < sc.kd_nodes; i += blockDim.x) { l_a[i] = sc.kd_a[i]; l_b[i] = sc.kd_b[i]; }
-        for (int i = tid; i < sc.kd_nleaf; i += blockDim.x) l_leaf[i] = sc.kd_leaf[i];
-        for (int i = tid; i < sc.kd_nalways; i += blockDim.x) l_alw[i] = sc.kd_always[i];
+        for (int i = tid; i < sc.kd_nodes; i += THREADS) { l_a[i] = sc.kd_a[i]; l_b[i] = sc.kd_b[i]; }
+        for (int i = tid; i < sc.kd_nleaf; i += THREADS) l_leaf[i] = sc.kd_leaf[i];
+        for (int i = tid; i < sc.kd_nalways; i += THREADS) l_alw[i] = sc.kd_always[i];
         kd_a = l_a; kd_b = l_b; kd_leaf = l_leaf; kd_always = l_alw;
     }
     __syncthreads();
@@ -317,9 +665,8 @@ __global__ __launch_bounds__(256) void k_trace_fast(FastParams P) {
     trc_kd_view kd = make_kd_view(sc, kd_a, kd_b, kd_split, kd_leaf, kd_always);
 
     // this wave's slice of the ray-id range
-    const unsigned lane = lane_id();
-    const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
-    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (tid >> 6);
+    const long long n_waves = (long long)gridDim.x * (THREADS >> 6);
+    const long long wave = (long long)blockIdx.x * (THREADS >> 6) + (tid >> 6);
     const long long chunk = (P.n + n_waves - 1) / n_waves;
     long long next = wave * chunk;
     long long end = next + chunk;
@@ -356,13 +703,18 @@ __global__ __launch_bounds__(256) void k_trace_fast(FastParams P) {
             next += __popcll(need);
         }
         if (!__ballot(alive)) break;
-        if (!alive) continue;
 
         // ---- one segment ----
-        nseg += 1.0;
         double t;
         int s;
-        if (accel) {
+        if (M32) {
+            // wave-cooperative: every lane takes part, dead lanes only help draining the queues
+            nearest_coop32(A, coopW, recs, sc.stride, sc.extra, alive, px, py, pz, dx, dy, dz, &t, &s);
+            if (!alive) continue;
+            nseg += 1.0;
+        } else if (!alive) {
+            continue;
+        } else if ((nseg += 1.0), accel) {
             LocalKdStack stk;
             trc_nearest_kd(kd, stk, recs, sc.stride, sc.extra, px, py, pz, dx, dy, dz, &t, &s);
         } else {
@@ -407,7 +759,7 @@ __global__ __launch_bounds__(256) void k_trace_fast(FastParams P) {
     if (P.lds_tally) {
         if (lane == 0) { atomicAdd(&l_tally[3 * S], nseg); atomicAdd(&l_tally[3 * S + 1], nhit); }
         __syncthreads();
-        for (int i = tid; i < 3 * S + 2; i += blockDim.x) {
+        for (int i = tid; i < 3 * S + 2; i += THREADS) {
             double v = l_tally[i];
             if (v != 0.0) atomicAdd(&sc.tally[i], v);
         }
@@ -803,6 +1155,16 @@ static int scene_upload_surfaces(trc_scene *sc) {
     HIP_TRY(hipMemcpy(sc->d_recs, recs.data(), recs.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(sc->d_opt, opt.data(), opt.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(sc->d_sflags, flags.data(), flags.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    // conservative single-precision boxes of the bounded surfaces (fast engine)
+    trc_accel_build_surfaces(sc->surfs.data(), sc->n_surf, sc->accel);
+    dev_free(sc->d_a_sbox); dev_free(sc->d_a_unbounded);
+    TRC_TRY(dev_alloc(&sc->d_a_sbox, sc->accel.sbox.size()));
+    TRC_TRY(dev_alloc(&sc->d_a_unbounded, sc->accel.unbounded.size()));
+    HIP_TRY(hipMemcpy(sc->d_a_sbox, sc->accel.sbox.data(), sc->accel.sbox.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!sc->accel.unbounded.empty())
+        HIP_TRY(hipMemcpy(sc->d_a_unbounded, sc->accel.unbounded.data(), sc->accel.unbounded.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    sc->accel_ok = true;
+    sc->accel_kd_ok = false;   // packed Kd nodes are relative to the scene centre: rebuilt by trc_scene_set_kdtree
     return TRC_OK;
 }
 
@@ -872,6 +1234,7 @@ extern "C" int trc_scene_destroy(trc_scene *sc) {
     (void)hipStreamSynchronize(sc->ctx->stream);
     dev_free(sc->d_recs); dev_free(sc->d_opt); dev_free(sc->d_extra); dev_free(sc->d_sflags);
     dev_free(sc->d_kd_a); dev_free(sc->d_kd_b); dev_free(sc->d_kd_leaf); dev_free(sc->d_kd_always);
+    dev_free(sc->d_a_sbox); dev_free(sc->d_a_nodes); dev_free(sc->d_a_leaf); dev_free(sc->d_a_unbounded);
     dev_free(sc->d_kd_split); dev_free(sc->d_tally); dev_free(sc->d_fm_of_surf); dev_free(sc->d_fms);
     dev_free(sc->d_fm_edges); dev_free(sc->d_counters); dev_free(sc->d_energy_left); dev_free(sc->d_h_surf);
     for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
@@ -893,6 +1256,7 @@ extern "C" int trc_scene_set_kdtree(trc_scene *sc, const trc_kdtree_desc *kd) {
     HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
     dev_free(sc->d_kd_a); dev_free(sc->d_kd_b); dev_free(sc->d_kd_leaf); dev_free(sc->d_kd_always); dev_free(sc->d_kd_split);
     sc->has_kd = false;
+    sc->accel_kd_ok = false;
     if (!kd) return TRC_OK;
     if (kd->n_nodes <= 0 || !kd->flag || !kd->split || !kd->child || !kd->leaf_off || !kd->leaf_cnt)
         return trc_fail(TRC_ERR_INVALID, "trc_scene_set_kdtree: incomplete tree");
@@ -936,6 +1300,16 @@ extern "C" int trc_scene_set_kdtree(trc_scene *sc, const trc_kdtree_desc *kd) {
     sc->kd_nodes = kd->n_nodes; sc->kd_nleaf = kd->n_leaf_surfs; sc->kd_nalways = kd->n_always;
     memcpy(sc->kd_bounds, kd->bounds, sizeof(sc->kd_bounds));
     sc->has_kd = true;
+    dev_free(sc->d_a_nodes); dev_free(sc->d_a_leaf);
+    sc->accel_kd_ok = false;
+    if (sc->accel_ok && trc_accel_build_kd(kd, sc->accel)) {
+        TRC_TRY(dev_alloc(&sc->d_a_nodes, sc->accel.nodes.size()));
+        TRC_TRY(dev_alloc(&sc->d_a_leaf, sc->accel.leaf_surfs.size()));
+        HIP_TRY(hipMemcpy(sc->d_a_nodes, sc->accel.nodes.data(), sc->accel.nodes.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!sc->accel.leaf_surfs.empty())
+            HIP_TRY(hipMemcpy(sc->d_a_leaf, sc->accel.leaf_surfs.data(), sc->accel.leaf_surfs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        sc->accel_kd_ok = true;
+    }
     return TRC_OK;
 }
 
@@ -1077,6 +1451,12 @@ static DScene make_dscene(trc_scene *sc) {
     d.kd_split = sc->d_kd_split;
     d.kd_nodes = sc->kd_nodes; d.kd_nleaf = sc->kd_nleaf; d.kd_nalways = sc->kd_nalways;
     for (int i = 0; i < 3; ++i) { d.kd_bmin[i] = sc->kd_bounds[i]; d.kd_bmax[i] = sc->kd_bounds[3 + i]; }
+    d.a_sbox = sc->d_a_sbox; d.a_nodes = sc->d_a_nodes; d.a_leaf = sc->d_a_leaf; d.a_unbounded = sc->d_a_unbounded;
+    d.a_n_unbounded = (int32_t)sc->accel.unbounded.size(); d.a_kd_depth = sc->accel.kd_depth;
+    d.a_ok = sc->accel_ok ? 1 : 0; d.a_kd_ok = sc->accel_kd_ok ? 1 : 0;
+    for (int i = 0; i < 6; ++i) d.a_root[i] = sc->accel.root[i];
+    d.a_delta = sc->accel.delta;
+    for (int i = 0; i < 3; ++i) { d.a_cen[i] = sc->accel.cen[i]; d.a_slo[i] = sc->accel.slo[i]; d.a_shi[i] = sc->accel.shi[i]; }
     d.tally = sc->d_tally;
     d.fm_of_surf = sc->d_fm_of_surf; d.fms = sc->d_fms; d.fm_edges = sc->d_fm_edges;
     d.counters = sc->d_counters; d.energy_left = sc->d_energy_left;
@@ -1198,32 +1578,62 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         if (sc->hit_cap > 0)
             for (int i = 0; i < S; ++i) if (sc->surfs[i].flags & TRC_SURF_CAPTURE_HITS) P.capture = 1;
 
-        // LDS budget: stage the scene (and the Kd-tree) when it fits in 64 KiB together with the rest
         const bool accel = sc->has_kd && (flags & TRC_TRACE_ACCEL);
         size_t b_buie = src ? (size_t)(3 * (TRC_BUIE_NELEM + 1) + 6) * 8 : 0;
         size_t b_tally = (size_t)(3 * S + 2) * 8;
-        size_t b_scene = (size_t)S * sc->stride * 8;
-        if (sc->has_kd) b_scene += (size_t)sc->kd_nodes * 8 + ((size_t)sc->kd_nodes * 2 + sc->kd_nleaf + sc->kd_nalways) * 4 + 8;
-        const size_t LDS_MAX = 64 * 1024;
-        size_t lds = b_buie;
-        P.lds_tally = (lds + b_tally <= LDS_MAX) ? 1 : 0;
-        if (P.lds_tally) lds += b_tally;
-        P.lds_scene = (lds + b_scene <= LDS_MAX) ? 1 : 0;
-        if (P.lds_scene) lds += b_scene;
-        (void)accel;
+        static int threads_env = -1, mode_env = -1;
+        if (threads_env < 0) { const char *ev = getenv("TRC_FAST_THREADS"); threads_env = ev ? atoi(ev) : 0; }
+        if (mode_env < 0) { const char *ev = getenv("TRC_FAST_GENERIC"); mode_env = (ev && atoi(ev)) ? 1 : 0; }
+        { const char *ev = getenv("TRC_DEBUG_SKIP"); if (ev) P.flags |= (atoi(ev) & 3) << 8; }
+        // preferred: single-precision conservative search with everything it needs in LDS (up to 160 KiB per CU)
+        bool m32 = sc->accel_ok && !mode_env && S <= 65535 &&
+                   (!accel || (sc->accel_kd_ok && sc->kd_nodes <= COOP_MAX_NODES && sc->accel.kd_depth <= COOP_MAX_DEPTH));
+        int threads = 512;
+        if (threads_env == 256 || threads_env == 512 || threads_env == 1024) threads = threads_env;
+        size_t lds = 0;
+        if (m32) {
+            size_t b_acc = (size_t)6 * S * 4 + (accel ? ((size_t)2 * sc->kd_nodes * 4 + (size_t)sc->kd_nalways * 4 + (size_t)sc->kd_nleaf * 2) : 0) +
+                           sc->accel.unbounded.size() * 4 + 32;
+            for (;;) {
+                lds = b_buie + b_tally + b_acc + (size_t)(threads / 64) * COOP_WAVE_BYTES(accel ? (sc->accel.kd_depth > 0 ? sc->accel.kd_depth : 1) : 1);
+                if (lds <= 160 * 1024 - 512 || threads == 256) break;
+                threads /= 2;
+            }
+            if (lds > 160 * 1024 - 512) m32 = false;
+            P.lds_tally = 1;
+            P.lds_scene = 0;
+        }
+        if (!m32) {
+            threads = 256;
+            size_t b_scene = (size_t)S * sc->stride * 8;
+            if (sc->has_kd) b_scene += (size_t)sc->kd_nodes * 8 + ((size_t)sc->kd_nodes * 2 + sc->kd_nleaf + sc->kd_nalways) * 4 + 8;
+            const size_t LDS_MAX = 64 * 1024;
+            lds = b_buie;
+            P.lds_tally = (lds + b_tally <= LDS_MAX) ? 1 : 0;
+            if (P.lds_tally) lds += b_tally;
+            P.lds_scene = (lds + b_scene <= LDS_MAX) ? 1 : 0;
+            if (P.lds_scene) lds += b_scene;
+        }
+        void (*kern)(FastParams) = nullptr;
+        if (m32) kern = threads == 1024 ? k_trace_fast<1024, true> : (threads == 512 ? k_trace_fast<512, true> : k_trace_fast<256, true>);
+        else kern = k_trace_fast<256, false>;
+        if (lds > 64 * 1024) {
+            hipError_t ae = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ae != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(ae)); break; }
+        }
 
         // persistent grid: as many workgroups as are resident at once, never more waves than rays/64
         int blocks_per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_trace_fast, 256, lds) != hipSuccess || blocks_per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void *)kern, threads, lds) != hipSuccess || blocks_per_cu < 1)
             blocks_per_cu = 1;
         if (blocks_per_cu > 8) blocks_per_cu = 8;
         long long grid = (long long)ctx->n_cu * blocks_per_cu;
-        long long max_grid = (n + 255) / 256;
+        long long max_grid = (n + threads - 1) / threads;
         if (grid > max_grid) grid = max_grid;
         if (grid < 1) grid = 1;
         if (n > 0) {
             if (hipEventRecord(ctx->ev0, ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "event record failed"); break; }
-            hipLaunchKernelGGL(k_trace_fast, dim3((unsigned)grid), dim3(256), lds, ctx->stream, P);
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, ctx->stream, P);
             hipError_t le = hipGetLastError();
             if (le != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "k_trace_fast launch failed: %s", hipGetErrorString(le)); break; }
             if (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "event record failed"); break; }
