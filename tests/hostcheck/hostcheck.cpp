@@ -131,7 +131,7 @@ int hc_nearest32(int n_surf, const trc_surface_desc *surfs, const double *extra,
     A.sbox = H.sbox.data(); A.nodes = H.nodes.data(); A.leaf_surfs = H.leaf_surfs.data();
     A.always = kd ? kd->always_relevant : nullptr; A.n_always = kd ? kd->n_always : 0;
     A.unbounded = H.unbounded.data(); A.n_unbounded = (int)H.unbounded.size();
-    A.n_surf = n_surf; A.has_kd = kd ? 1 : 0; A.delta = H.delta; A.dbg = 0;
+    A.n_surf = n_surf; A.has_kd = kd ? 1 : 0; A.delta = H.delta;
     for (int k = 0; k < 6; ++k) A.root[k] = H.root[k];
     for (int k = 0; k < 3; ++k) { A.cen[k] = H.cen[k]; A.slo[k] = H.slo[k]; A.shi[k] = H.shi[k]; }
     for (long i = 0; i < n; ++i) {

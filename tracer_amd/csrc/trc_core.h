@@ -586,7 +586,6 @@ struct trc_accel_view {
     const int32_t *always;     // Kd always_relevant surfaces
     const int32_t *unbounded;  // surfaces without a box (tested exactly for every ray)
     int32_t n_always, n_unbounded, n_surf, has_kd;
-    int32_t dbg;               // timing experiments: 1 = skip leaf lists, 2 = skip exact tests (results are wrong)
     float root[6];             // Kd root box, relative, inflated
     float delta;
     double cen[3];
@@ -608,6 +607,72 @@ TRC_HD bool trc_box_hit32(const float *b, const trc_ray32 &r) {
     return hi * 1.0001f + 1e-6f >= lo;
 }
 
+// One interior-node step of the conservative single-precision walk (used by trc_nearest_accel32 below and by the
+// wave-cooperative kernel).  w0/w1: the packed node.  Returns the node to continue with; when *push is set the
+// caller must push (*push_na = other child << 2 | axis code, *push_t = interval end of that child) and the
+// interval of the continued child has been shortened.  Axis code 3 on the stack means "both children with the
+// full interval" (origin within delta of the plane).
+TRC_HD uint32_t trc_kd32_step(uint32_t w0, uint32_t w1, const trc_ray32 &r, float delta, float tmin, float *tmax,
+                              bool *push, uint32_t *push_na, float *push_t) {
+    uint32_t axis = w1 & 3u;
+    float split = __builtin_bit_cast(float, w0);
+    float o = axis == 0 ? r.ox : (axis == 1 ? r.oy : r.oz);
+    float iv = axis == 0 ? r.ix : (axis == 1 ? r.iy : r.iz);
+    float diff = split - o;
+    uint32_t left = w1 >> 2, right = left + 1;
+    *push = false;
+    if (fabsf(diff) <= delta) {
+        *push = true; *push_na = (right << 2) | 3u; *push_t = *tmax;
+        return left;
+    }
+    uint32_t nearc = diff > 0.0f ? left : right, farc = diff > 0.0f ? right : left;
+    float tp = diff * iv;
+    float dt = delta * fabsf(iv);
+    if (!(tp - dt <= *tmax) || tp + dt < 0.0f) return nearc;      // slab beyond the interval / behind the origin
+    if (tp + dt < tmin) return farc;                              // interval starts after the slab
+    *push = true; *push_na = (farc << 2) | axis; *push_t = *tmax;  // far child keeps the interval end
+    *tmax = fminf(*tmax, tp + dt);
+    return nearc;
+}
+
+// interval start of a popped child: the near subtree ended at (plane + dt), the far one starts at (plane - dt)
+TRC_HD float trc_kd32_pop_tmin(uint32_t axis_code, const trc_ray32 &r, float delta, float tmax_now) {
+    if (axis_code == 3u) return 0.0f;
+    float iv = axis_code == 0 ? r.ix : (axis_code == 1 ? r.iy : r.iz);
+    return fmaxf(0.0f, tmax_now - 2.0f * delta * fabsf(iv) - 1e-5f * fabsf(tmax_now));
+}
+
+// root interval of the walk
+TRC_HD bool trc_kd32_root(const float *root, const trc_ray32 &r, float *tmin, float *tmax) {
+    float ax = (root[0] - r.ox) * r.ix, bx = (root[3] - r.ox) * r.ix;
+    float ay = (root[1] - r.oy) * r.iy, by = (root[4] - r.oy) * r.iy;
+    float az = (root[2] - r.oz) * r.iz, bz = (root[5] - r.oz) * r.iz;
+    *tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    *tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0001f + 1e-6f;
+    return *tmax >= *tmin;
+}
+
+// float64 entry into the scene box and the relative single-precision ray from there
+TRC_HD bool trc_ray32_prepare(const double *slo, const double *shi, const double *cen, double vx, double vy, double vz,
+                              double dx, double dy, double dz, trc_ray32 *r, double *t_entry) {
+    double t0 = 0.0, t1 = TRC_INF;
+    const double v[3] = {vx, vy, vz}, d[3] = {dx, dy, dz};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double inv = 1.0 / d[i];
+        double a = (slo[i] - v[i]) * inv, b = (shi[i] - v[i]) * inv;
+        t0 = fmax(t0, fmin(a, b));
+        t1 = fmin(t1, fmax(a, b));
+    }
+    r->ox = (float)(vx + t0 * dx - cen[0]);
+    r->oy = (float)(vy + t0 * dy - cen[1]);
+    r->oz = (float)(vz + t0 * dz - cen[2]);
+    r->dx = (float)dx; r->dy = (float)dy; r->dz = (float)dz;
+    r->ix = 1.0f / r->dx; r->iy = 1.0f / r->dy; r->iz = 1.0f / r->dz;
+    *t_entry = t0;
+    return t1 >= t0;
+}
+
 #define TRC_TEST_EXACT(S)                                                                                   \
     do {                                                                                                    \
         int _s = (S);                                                                                       \
@@ -623,25 +688,9 @@ TRC_HD void trc_nearest_accel32(const trc_accel_view &A, Stack &stk, const doubl
     double tb = TRC_INF;
     int sb = -1;
     for (int k = 0; k < A.n_unbounded; ++k) TRC_TEST_EXACT(A.unbounded[k]);
-    // scene box in float64: where does the ray enter the region that holds every bounded surface?
-    double t0 = 0.0, t1 = TRC_INF;
-    {
-        const double v[3] = {vx, vy, vz}, d[3] = {dx, dy, dz};
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            double inv = 1.0 / d[i];
-            double a = (A.slo[i] - v[i]) * inv, b = (A.shi[i] - v[i]) * inv;
-            t0 = fmax(t0, fmin(a, b));
-            t1 = fmin(t1, fmax(a, b));
-        }
-    }
-    if (t1 >= t0) {
-        trc_ray32 r;
-        r.ox = (float)(vx + t0 * dx - A.cen[0]);
-        r.oy = (float)(vy + t0 * dy - A.cen[1]);
-        r.oz = (float)(vz + t0 * dz - A.cen[2]);
-        r.dx = (float)dx; r.dy = (float)dy; r.dz = (float)dz;
-        r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+    trc_ray32 r;
+    double t0;
+    if (trc_ray32_prepare(A.slo, A.shi, A.cen, vx, vy, vz, dx, dy, dz, &r, &t0)) {
         if (!use_kd) {
             for (int s = 0; s < A.n_surf; ++s) {
                 const float *b = A.sbox + 6 * (size_t)s;
@@ -655,66 +704,31 @@ TRC_HD void trc_nearest_accel32(const trc_accel_view &A, Stack &stk, const doubl
                 if (b[3] == TRC_INF && b[0] == -TRC_INF) continue;
                 if (trc_box_hit32(b, r)) TRC_TEST_EXACT(s);
             }
-            // root slab
-            float ax = (A.root[0] - r.ox) * r.ix, bx = (A.root[3] - r.ox) * r.ix;
-            float ay = (A.root[1] - r.oy) * r.iy, by = (A.root[4] - r.oy) * r.iy;
-            float az = (A.root[2] - r.oz) * r.iz, bz = (A.root[5] - r.oz) * r.iz;
-            float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-            float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-            tmax = tmax * 1.0001f + 1e-6f;
-            if (tmax >= tmin) {
-                const float delta = A.delta;
+            float tmin, tmax;
+            if (trc_kd32_root(A.root, r, &tmin, &tmax)) {
                 uint32_t node = 0;
                 int sp = 0;
                 for (;;) {
                     uint32_t w0 = A.nodes[2 * node], w1 = A.nodes[2 * node + 1];
-                    uint32_t axis = w1 & 3u;
-                    if (axis != 3u) {
-                        float split = __builtin_bit_cast(float, w0);
-                        float o = axis == 0 ? r.ox : (axis == 1 ? r.oy : r.oz);
-                        float iv = axis == 0 ? r.ix : (axis == 1 ? r.iy : r.iz);
-                        float diff = split - o;
-                        uint32_t left = w1 >> 2, right = left + 1;
-                        if (fabsf(diff) <= delta) {
-                            // origin on the plane within tolerance: both children, full interval
-                            stk.push(sp, (right << 2) | 3u, tmax); ++sp;     // axis code 3: do not tighten on pop
-                            node = left;
-                        } else {
-                            uint32_t nearc = diff > 0.0f ? left : right, farc = diff > 0.0f ? right : left;
-                            float tp = diff * iv;
-                            float dt = delta * fabsf(iv);
-                            if (!(tp - dt <= tmax) || tp + dt < 0.0f) node = nearc;      // slab beyond the interval / behind
-                            else if (tp + dt < tmin) node = farc;                         // interval starts after the slab
-                            else {
-                                stk.push(sp, (farc << 2) | axis, tmax); ++sp;
-                                node = nearc;
-                                tmax = fminf(tmax, tp + dt);
-                            }
-                        }
+                    if ((w1 & 3u) != 3u) {
+                        bool push;
+                        uint32_t na;
+                        float pt;
+                        node = trc_kd32_step(w0, w1, r, A.delta, tmin, &tmax, &push, &na, &pt);
+                        if (push) { stk.push(sp, na, pt); ++sp; }
                     } else {
                         uint32_t off = w0, cnt = w1 >> 2;
-                        if (A.dbg == 1) cnt = 0;
                         for (uint32_t k = 0; k < cnt; ++k) {
                             int s = A.leaf_surfs[off + k];
-                            if (trc_box_hit32(A.sbox + 6 * (size_t)s, r)) {
-                                if (A.dbg == 2) { if (tb > 1e300) { tb = 1e299; sb = -1; } }
-                                else TRC_TEST_EXACT(s);
-                            }
+                            if (trc_box_hit32(A.sbox + 6 * (size_t)s, r)) TRC_TEST_EXACT(s);
                         }
                         if (sp == 0) break;
                         --sp;
                         uint32_t na;
                         float tmax_far;
                         stk.pop(sp, &na, &tmax_far);
-                        uint32_t pax = na & 3u;
                         node = na >> 2;
-                        // entry of the far child: the near subtree ended at (plane + dt); the far one starts at (plane - dt)
-                        if (pax != 3u) {
-                            float iv = pax == 0 ? r.ix : (pax == 1 ? r.iy : r.iz);
-                            tmin = fmaxf(0.0f, tmax - 2.0f * delta * fabsf(iv) - 1e-5f * fabsf(tmax));
-                        } else {
-                            tmin = 0.0f;
-                        }
+                        tmin = trc_kd32_pop_tmin(na & 3u, r, A.delta, tmax);
                         tmax = tmax_far;
                         if (sb >= 0) {
                             float tbr = (float)(tb - t0);

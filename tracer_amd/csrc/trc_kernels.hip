@@ -282,62 +282,51 @@ struct FastParams {
     int capture;      // some surface captures hits
 };
 
-// per-wave traversal stack of the single-precision search, in LDS: entry (sp, lane) at base[sp * 64 + lane]
-struct LdsStack32 {
-    uint2 *base;
-    unsigned lane;
-    __device__ __forceinline__ void push(int sp, uint32_t n, float t) { base[sp * 64 + lane] = make_uint2(n, __float_as_uint(t)); }
-    __device__ __forceinline__ void pop(int sp, uint32_t *n, float *t) {
-        uint2 v = base[sp * 64 + lane];
-        *n = v.x;
-        *t = __uint_as_float(v.y);
-    }
-};
-
 // ------------------------------------------------------------------------------------------------
-// Wave-cooperative form of trc_nearest_accel32 (same candidates, same exact tests, same winner).
-//
-// Per ray the Kd walk touches ~7 nodes and ~10 candidate boxes, but the slowest of 64 lanes touches ~32 and ~90,
-// and an exact float64 test executed by one lane stalls the other 63.  So the wave separates the three kinds of
-// work and load-balances the last two across lanes through LDS queues:
-//   1. each lane walks the tree for its own ray (single precision, LDS stack) and only RECORDS (lane, surface)
-//      candidates of the leaves it crosses;
-//   2. all 64 lanes drain the candidate queue together, one (ray, box) test per lane per round;
-//   3. survivors go to a second queue; all lanes drain it with the exact float64 test of trc_core.h and combine
-//      results per ray with LDS atomics: minimal t, then lowest surface index among equal t.
-// Every lane of the wave must call it (inactive lanes pass active=false).
+// Wave-cooperative fast path (k_trace_coop).  Same candidates, same exact float64 tests and the same winner as
+// trc_nearest_accel32 / brute force -- the work is only distributed differently over the 64 lanes:
+//   refill   dead lanes take fresh rays; a ray with no candidate at all (misses the Kd root box and the boxes of
+//            the always-relevant surfaces) is finished on the spot and its lane refilled again, up to 3 passes,
+//            so that the lanes entering the walk are (almost) all doing useful work;
+//   walk     each lane walks the tree for its own ray (single precision, packed 4-byte LDS stack) and only lists
+//            the leaves it crosses;
+//   boxes    all lanes drain the leaf lists together: one (ray, leaf) item per lane per round (prefix sum +
+//            binary search), box test of every surface of the leaf;
+//   exact    survivors are queued; all lanes drain that queue with trc_intersect (float64) and combine per ray
+//            with LDS atomics: minimal t, then the lowest surface index among equal t (tracer_engine.py:58-63).
 // ------------------------------------------------------------------------------------------------
-#define COOP_Q 256           // candidate queue entries per wave
+#define COOP_LEAFCAP 16      // leaves listed per lane between two drains
 #define COOP_E 128           // exact-test queue entries per wave
 #define COOP_MAX_NODES 16384 // stack entries are 4 bytes: node (14 bits) | axis code (2 bits) | interval end (16 bits)
 #define COOP_MAX_DEPTH 24
-#define COOP_FIXED_BYTES (6 * 64 * 4 + 6 * 64 * 8 + COOP_Q * 4 + COOP_E * 4 + COOP_E * 8 + 64 * 8 + 64 * 4 + 64 * 4)
+#define COOP_FIXED_BYTES (6 * 64 * 8 + COOP_E * 8 + 64 * 8 + 6 * 64 * 4 + COOP_E * 4 + 64 * 4 + 64 * 4 + 64 * 4 + COOP_LEAFCAP * 64 * 2)
 #define COOP_WAVE_BYTES(DEPTH) ((size_t)(DEPTH) * 64 * 4 + COOP_FIXED_BYTES)
 
 struct CoopLds {
-    uint32_t *stack;              // [depth][64]
     double *rd;                   // [6][64]  ray origin / direction, float64
     double *exq_t;                // [COOP_E]
     unsigned long long *best_t;   // [64]
     float *rf;                    // [6][64]  relative origin / inverse direction, float32
-    uint32_t *candq;              // [COOP_Q]
     uint32_t *exq;                // [COOP_E]
     int *best_s;                  // [64]
     int *dirty;                   // [64]
+    uint32_t *pre;                // [64] inclusive prefix of the leaf-list lengths
+    uint16_t *lst;                // [COOP_LEAFCAP][64] leaves crossed by each lane's ray
+    uint32_t *stack;              // [depth][64]
 };
 
-__device__ __forceinline__ CoopLds coop_carve(char *base, int depth) {
+__device__ __forceinline__ CoopLds coop_carve(char *base) {
     CoopLds W;
     W.rd = (double *)base; base += 6 * 64 * 8;
     W.exq_t = (double *)base; base += COOP_E * 8;
     W.best_t = (unsigned long long *)base; base += 64 * 8;
     W.rf = (float *)base; base += 6 * 64 * 4;
-    W.candq = (uint32_t *)base; base += COOP_Q * 4;
     W.exq = (uint32_t *)base; base += COOP_E * 4;
     W.best_s = (int *)base; base += 64 * 4;
     W.dirty = (int *)base; base += 64 * 4;
+    W.pre = (uint32_t *)base; base += 64 * 4;
+    W.lst = (uint16_t *)base; base += COOP_LEAFCAP * 64 * 2;
     W.stack = (uint32_t *)base;
-    (void)depth;
     return W;
 }
 
@@ -352,6 +341,7 @@ __device__ __forceinline__ CoopLds coop_carve(char *base, int depth) {
 // drain the exact-test queue (wave-uniform call)
 __device__ __forceinline__ void coop_drain_exact(const CoopLds &W, int ecount, const double *recs, int stride,
                                                  const double *extra, unsigned lane) {
+    if (ecount == 0) return;
     WAVE_SYNC();
     for (int base = 0; base < ecount; base += 64) {
         int i = base + (int)lane;
@@ -386,7 +376,7 @@ __device__ __forceinline__ void coop_drain_exact(const CoopLds &W, int ecount, c
     WAVE_SYNC();
 }
 
-// append (lane, surface) to the exact queue for the lanes whose `want` is set (wave-uniform call); drains when full
+// append (ray lane, surface) to the exact queue for the lanes whose `want` is set (wave-uniform call)
 __device__ __forceinline__ void coop_push_exact(const CoopLds &W, int &ecount, bool want, uint32_t entry, const double *recs,
                                                 int stride, const double *extra, unsigned lane) {
     unsigned long long m = __ballot(want);
@@ -397,193 +387,112 @@ __device__ __forceinline__ void coop_push_exact(const CoopLds &W, int &ecount, b
     ecount += add;
 }
 
-// drain the candidate queue: one (ray, box) test per lane per round (wave-uniform call)
-__device__ __forceinline__ void coop_drain_cand(const trc_accel_view &A, const CoopLds &W, int qcount, int &ecount,
-                                                const double *recs, int stride, const double *extra, unsigned lane) {
+// drain the per-lane leaf lists: items (ray lane, leaf) are dealt to the 64 lanes round by round (wave-uniform call)
+__device__ __forceinline__ void coop_drain_leaves(const trc_accel_view &A, const CoopLds &W, unsigned cnt, int &ecount,
+                                                  const double *recs, int stride, const double *extra, unsigned lane) {
+    // inclusive prefix sum of the list lengths
+    unsigned incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned o = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += o;
+    }
+    const unsigned total = __shfl(incl, 63, 64);
+    if (total == 0) return;
+    W.pre[lane] = incl;
     WAVE_SYNC();
-    for (int base = 0; base < qcount; base += 64) {
-        int i = base + (int)lane;
-        bool hit = false;
-        uint32_t en = 0;
-        if (i < qcount) {
-            en = W.candq[i];
-            int L = (int)(en >> 16), sidx = (int)(en & 0xFFFFu);
-            trc_ray32 r;
+    for (unsigned base = 0; base < total; base += 64) {
+        const unsigned e = base + lane;
+        const bool valid = e < total;
+        unsigned lc = 0, off = 0, L = 0;
+        trc_ray32 r;
+        r.ox = r.oy = r.oz = r.ix = r.iy = r.iz = r.dx = r.dy = r.dz = 0.0f;
+        if (valid) {
+            // first lane whose inclusive prefix exceeds e
+            unsigned lo = 0, hi = 63;
+            while (lo < hi) {
+                unsigned mid = (lo + hi) >> 1;
+                if (W.pre[mid] > e) hi = mid; else lo = mid + 1;
+            }
+            L = lo;
+            unsigned j = e - (L ? W.pre[L - 1] : 0u);
+            unsigned node = W.lst[j * 64 + L];
+            off = A.nodes[2 * node];
+            lc = A.nodes[2 * node + 1] >> 2;
             r.ox = W.rf[L]; r.oy = W.rf[64 + L]; r.oz = W.rf[128 + L];
             r.ix = W.rf[192 + L]; r.iy = W.rf[256 + L]; r.iz = W.rf[320 + L];
-            r.dx = r.dy = r.dz = 0.0f;
-            hit = trc_box_hit32(A.sbox + 6 * (size_t)sidx, r);
         }
-        coop_push_exact(W, ecount, hit, en, recs, stride, extra, lane);
-    }
-}
-
-__device__ __forceinline__ void nearest_coop32(const trc_accel_view &A, const CoopLds &W, const double *recs, int stride,
-                                               const double *extra, bool active, double vx, double vy, double vz, double dx,
-                                               double dy, double dz, double *t_best, int *s_best) {
-    const unsigned lane = lane_id();
-    double tb = TRC_INF;
-    int sb = -1;
-    // surfaces without a box: every active ray tests them (uniform loop, no divergence between active lanes)
-    if (active)
-        for (int k = 0; k < A.n_unbounded; ++k) TRC_TEST_EXACT(A.unbounded[k]);
-    W.best_t[lane] = (unsigned long long)__double_as_longlong(TRC_INF);
-    W.best_s[lane] = 0x7FFFFFFF;
-    W.dirty[lane] = 0;
-    W.rd[lane] = vx; W.rd[64 + lane] = vy; W.rd[128 + lane] = vz;
-    W.rd[192 + lane] = dx; W.rd[256 + lane] = dy; W.rd[320 + lane] = dz;
-    // scene box (float64): entry point of the region holding every bounded surface
-    double t0 = 0.0, t1 = TRC_INF;
-    {
-        const double v[3] = {vx, vy, vz}, d[3] = {dx, dy, dz};
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            double inv = 1.0 / d[i];
-            double a = (A.slo[i] - v[i]) * inv, b = (A.shi[i] - v[i]) * inv;
-            t0 = fmax(t0, fmin(a, b));
-            t1 = fmin(t1, fmax(a, b));
-        }
-    }
-    const bool in = active && (t1 >= t0);
-    trc_ray32 r;
-    r.ox = (float)(vx + t0 * dx - A.cen[0]);
-    r.oy = (float)(vy + t0 * dy - A.cen[1]);
-    r.oz = (float)(vz + t0 * dz - A.cen[2]);
-    r.dx = (float)dx; r.dy = (float)dy; r.dz = (float)dz;
-    r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
-    W.rf[lane] = r.ox; W.rf[64 + lane] = r.oy; W.rf[128 + lane] = r.oz;
-    W.rf[192 + lane] = r.ix; W.rf[256 + lane] = r.iy; W.rf[320 + lane] = r.iz;
-    int ecount = 0;   // wave-uniform
-    int qcount = 0;   // wave-uniform
-    const uint32_t me = (uint32_t)lane << 16;
-    if (!A.has_kd) {
-        // brute force over the boxes: same surface for all lanes at a time, survivors queued for the exact test
-        for (int sidx = 0; sidx < A.n_surf; ++sidx) {
-            const float *b = A.sbox + 6 * (size_t)sidx;
-            bool bounded = !(b[3] == TRC_INF && b[0] == -TRC_INF);
-            bool hit = in && bounded && trc_box_hit32(b, r);
-            coop_push_exact(W, ecount, hit, me | (uint32_t)sidx, recs, stride, extra, lane);
-        }
-    } else {
-        for (int k = 0; k < A.n_always; ++k) {
-            int sidx = A.always[k];
-            const float *b = A.sbox + 6 * (size_t)sidx;
-            bool bounded = !(b[3] == TRC_INF && b[0] == -TRC_INF);
-            bool hit = in && bounded && trc_box_hit32(b, r);
-            coop_push_exact(W, ecount, hit, me | (uint32_t)sidx, recs, stride, extra, lane);
-        }
-        // root slab
-        float ax = (A.root[0] - r.ox) * r.ix, bx = (A.root[3] - r.ox) * r.ix;
-        float ay = (A.root[1] - r.oy) * r.iy, by = (A.root[4] - r.oy) * r.iy;
-        float az = (A.root[2] - r.oz) * r.iz, bz = (A.root[5] - r.oz) * r.iz;
-        float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-        float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-        tmax = tmax * 1.0001f + 1e-6f;
-        bool walking = in && (tmax >= tmin);
-        const float delta = A.delta;
-        uint32_t node = 0;
-        int sp = 0;
-        uint32_t leaf_off = 0, leaf_rem = 0;   // surfaces of the current leaf still to be recorded
-        // stack entry: (node << 18) | (axis code << 16) | interval end as the upper half of a float32, rounded UP
-        // (the interval only ever grows: conservative)
-#define COOP_PUSH(NA, T)                                                                                   \
-    do {                                                                                                   \
-        uint32_t _b = __float_as_uint(T);                                                                  \
-        uint32_t _h = (_b >> 16) + ((_b & 0xFFFFu) ? 1u : 0u);                                             \
-        W.stack[sp * 64 + lane] = ((NA) << 16) | (_h & 0xFFFFu);                                           \
-        ++sp;                                                                                              \
-    } while (0)
-        while (__ballot(walking)) {
-            if (walking && leaf_rem == 0) {
-                uint32_t w0 = A.nodes[2 * node], w1 = A.nodes[2 * node + 1];
-                uint32_t axis = w1 & 3u;
-                if (axis != 3u) {
-                    float split = __uint_as_float(w0);
-                    float o = axis == 0 ? r.ox : (axis == 1 ? r.oy : r.oz);
-                    float iv = axis == 0 ? r.ix : (axis == 1 ? r.iy : r.iz);
-                    float diff = split - o;
-                    uint32_t left = w1 >> 2, right = left + 1;
-                    if (fabsf(diff) <= delta) {
-                        // origin on the plane within tolerance: both children with the full interval
-                        COOP_PUSH((right << 2) | 3u, tmax);
-                        node = left;
-                    } else {
-                        uint32_t nearc = diff > 0.0f ? left : right, farc = diff > 0.0f ? right : left;
-                        float tp = diff * iv;
-                        float dt = delta * fabsf(iv);
-                        if (!(tp - dt <= tmax) || tp + dt < 0.0f) node = nearc;        // slab beyond the interval / behind
-                        else if (tp + dt < tmin) node = farc;                           // interval starts after the slab
-                        else {
-                            COOP_PUSH((farc << 2) | axis, tmax);                        // far child keeps the interval end
-                            node = nearc;
-                            tmax = fminf(tmax, tp + dt);
-                        }
-                    }
-                } else {
-                    leaf_off = w0;
-                    leaf_rem = w1 >> 2;
-                    if (leaf_rem == 0) leaf_rem = 0xFFFFFFFFu;   // empty leaf: go straight to the pop below
-                }
+        for (unsigned k = 0; __ballot(k < lc); ++k) {
+            bool hit = false;
+            unsigned sidx = 0;
+            if (k < lc) {
+                sidx = A.leaf_surfs[off + k];
+                hit = trc_box_hit32(A.sbox + 6 * (size_t)sidx, r);
             }
-            // ---- record the surfaces of the leaves reached in this step (wave-uniform section) ----
-            const bool at_leaf = walking && leaf_rem != 0;
-            if (__ballot(at_leaf)) {
-                uint32_t c = (at_leaf && leaf_rem != 0xFFFFFFFFu) ? (leaf_rem < 16u ? leaf_rem : 16u) : 0u;
-                // total <= 64 * 16 entries would overflow a 256-entry queue: record in slices of 4 per lane
-                for (uint32_t k0 = 0; __ballot(c > k0); k0 += 4) {
-                    unsigned long long m0 = __ballot(c > k0), m1 = __ballot(c > k0 + 1), m2 = __ballot(c > k0 + 2), m3 = __ballot(c > k0 + 3);
-                    int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-                    if (qcount + n0 + n1 + n2 + n3 > COOP_Q) { coop_drain_cand(A, W, qcount, ecount, recs, stride, extra, lane); qcount = 0; }
-                    const unsigned long long lt = (1ull << lane) - 1ull;
-                    if (c > k0) W.candq[qcount + __popcll(m0 & lt)] = me | A.leaf_surfs[leaf_off + k0];
-                    if (c > k0 + 1) W.candq[qcount + n0 + __popcll(m1 & lt)] = me | A.leaf_surfs[leaf_off + k0 + 1];
-                    if (c > k0 + 2) W.candq[qcount + n0 + n1 + __popcll(m2 & lt)] = me | A.leaf_surfs[leaf_off + k0 + 2];
-                    if (c > k0 + 3) W.candq[qcount + n0 + n1 + n2 + __popcll(m3 & lt)] = me | A.leaf_surfs[leaf_off + k0 + 3];
-                    qcount += n0 + n1 + n2 + n3;
-                }
-                if (at_leaf) {
-                    if (leaf_rem == 0xFFFFFFFFu) leaf_rem = 0;
-                    else { leaf_off += c; leaf_rem -= c; }
-                    if (leaf_rem == 0) {
-                        // leaf finished: next subtree from the stack
-                        if (sp == 0) walking = false;
-                        else {
-                            --sp;
-                            uint32_t en = W.stack[sp * 64 + lane];
-                            uint32_t na = en >> 16;
-                            float tmax_far = __uint_as_float(en << 16);
-                            uint32_t pax = na & 3u;
-                            node = na >> 2;
-                            if (pax != 3u) {
-                                float iv = pax == 0 ? r.ix : (pax == 1 ? r.iy : r.iz);
-                                tmin = fmaxf(0.0f, tmax - 2.0f * delta * fabsf(iv) - 1e-5f * fabsf(tmax));
-                            } else tmin = 0.0f;
-                            tmax = tmax_far;
-                        }
-                    }
-                }
-            }
+            coop_push_exact(W, ecount, hit, (L << 16) | sidx, recs, stride, extra, lane);
         }
-        coop_drain_cand(A, W, qcount, ecount, recs, stride, extra, lane);
     }
-    coop_drain_exact(W, ecount, recs, stride, extra, lane);
-    // merge the queued results of this lane's ray with the inline ones (unbounded surfaces)
-    unsigned long long bt = W.best_t[lane];
-    double tq = __longlong_as_double((long long)bt);
-    int sq = W.best_s[lane];
-    if (tq < TRC_INF && (tq < tb || (tq == tb && sq < sb))) { tb = tq; sb = sq; }
     WAVE_SYNC();
-    *t_best = tb;
-    *s_best = sb;
 }
 
-// M32 = false: generic float64 traversal; scene records (+ Kd arrays) staged in LDS when they fit.
+// shading + bookkeeping of one hit, shared by the two fast kernels.  Returns false when the ray stops here.
+template <bool LDS_TALLY>
+__device__ __forceinline__ bool fast_shade(const FastParams &P, const double *recs, double *l_tally, double t, int s, double &px,
+                                           double &py, double &pz, double &dx, double &dy, double &dz, double &e, double &ref,
+                                           double wl, unsigned long long rid, int &bounce) {
+    const DScene &sc = P.sc;
+    bounce += 1;
+    const double *rec = recs + (size_t)s * sc.stride;
+    double hx = px + t * dx, hy = py + t * dy, hz = pz + t * dz;
+    double nx, ny, nz;
+    trc_normal(rec, hx, hy, hz, dx, dy, dz, &nx, &ny, &nz);
+    trc_ray_out out[2];
+    int n_out = trc_shade(trc_rec_opt_kind(rec), sc.opt + (size_t)s * 8, sc.extra, trc_rec_extra_off(rec), trc_rec_extra_len(rec),
+                          rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, nx, ny, nz, P.seed, rid, (uint32_t)bounce, out);
+    (void)n_out;  // scenes whose optics split rays are routed to the ordered engine by the host
+    double e_abs = e - out[0].e;
+    record_hit<LDS_TALLY>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0);
+    px = hx; py = hy; pz = hz;
+    dx = out[0].dx; dy = out[0].dy; dz = out[0].dz;
+    e = out[0].e; ref = out[0].ref;
+    if (e <= P.min_energy) return false;                      // tracer_engine.py:242
+    if (bounce >= P.reps) {                                   // still alive after the last iteration
+        atomicAdd(&sc.counters[3], 1ull);
+        atomicAdd(sc.energy_left, e);
+        if (P.flags & TRC_TRACE_KEEP_LAST) {
+            unsigned long long slot = atomicAdd(&sc.counters[2], 1ull);
+            if ((long long)slot < P.last_cap) {
+                P.lx[slot] = px; P.ly[slot] = py; P.lz[slot] = pz;
+                P.ldx[slot] = dx; P.ldy[slot] = dy; P.ldz[slot] = dz; P.le[slot] = e;
+            }
+        }
+        return false;
+    }
+    return true;
+}
+
+// fresh ray for a lane: from the source descriptor or from the given bundle
+__device__ __forceinline__ void fast_new_ray(const FastParams &P, const double *buie, long long id, double &px, double &py,
+                                             double &pz, double &dx, double &dy, double &dz, double &e, double &ref, double &wl,
+                                             unsigned long long &rid) {
+    rid = P.rid ? P.rid[id] : (P.ray_offset + (unsigned long long)id);
+    if (P.src) {
+        trc_source_ray(P.src, buie, P.seed, rid, &px, &py, &pz, &dx, &dy, &dz);
+        e = P.src->energy; ref = 1.0; wl = 0.0;
+    } else {
+        px = P.x[id]; py = P.y[id]; pz = P.z[id];
+        dx = P.dx[id]; dy = P.dy[id]; dz = P.dz[id];
+        e = P.e[id];
+        ref = P.ref ? P.ref[id] : 1.0;
+        wl = P.wl ? P.wl[id] : 0.0;
+    }
+}
+
+// Generic fast kernel: float64 Kd traversal / brute force straight from trc_core.h; scene records (+ Kd arrays)
+// staged in LDS when they fit in 64 KiB, read from global memory otherwise.  Used when the single-precision data
+// cannot be built or do not fit (very large scenes), and as a cross-check of the cooperative kernel.
 //   LDS (doubles): [recs S*stride][kd_split nodes][buie 639][tally 3S+2] then int32: [kd_a][kd_b][leaf][always]
-// M32 = true: single-precision conservative candidate search (trc_nearest_accel32), exact tests read the records
-//   from global memory (they are rare).
-//   LDS: doubles [buie 639][tally 3S+2] | float [sbox 6S] | u32 [nodes 2n] | i32 [always][unbounded] | u16 [leaf] |
-//        8-byte aligned stacks: waves x depth x 64 x 8 B
-template <int THREADS, bool M32>
+template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_trace_fast(FastParams P) {
     extern __shared__ double lds[];
     const DScene &sc = P.sc;
@@ -595,7 +504,7 @@ __global__ __launch_bounds__(THREADS) void k_trace_fast(FastParams P) {
     const double *kd_split = sc.kd_split;
     const int32_t *kd_a = sc.kd_a, *kd_b = sc.kd_b, *kd_leaf = sc.kd_leaf, *kd_always = sc.kd_always;
     double *cursor = lds;
-    if (!M32 && P.lds_scene) {
+    if (P.lds_scene) {
         double *l_recs = cursor; cursor += (size_t)S * sc.stride;
         for (int i = tid; i < S * sc.stride; i += THREADS) l_recs[i] = sc.recs[i];
         recs = l_recs;
@@ -618,37 +527,7 @@ __global__ __launch_bounds__(THREADS) void k_trace_fast(FastParams P) {
         cursor += 3 * S + 2;
         for (int i = tid; i < 3 * S + 2; i += THREADS) l_tally[i] = 0.0;
     }
-    trc_accel_view A;
-    A.dbg = 0;
-    CoopLds coopW;
-    if (M32) {
-        const bool kd32 = sc.a_kd_ok && (P.flags & TRC_TRACE_ACCEL);
-        float *l_sbox = (float *)cursor;
-        for (int i = tid; i < 6 * S; i += THREADS) l_sbox[i] = sc.a_sbox[i];
-        uint32_t *l_nodes = (uint32_t *)(l_sbox + 6 * S);
-        const int nn = kd32 ? sc.kd_nodes : 0;
-        for (int i = tid; i < 2 * nn; i += THREADS) l_nodes[i] = sc.a_nodes[i];
-        int32_t *l_alw = (int32_t *)(l_nodes + 2 * nn);
-        const int na = kd32 ? sc.kd_nalways : 0;
-        for (int i = tid; i < na; i += THREADS) l_alw[i] = sc.kd_always[i];
-        int32_t *l_unb = l_alw + na;
-        for (int i = tid; i < sc.a_n_unbounded; i += THREADS) l_unb[i] = sc.a_unbounded[i];
-        uint16_t *l_leaf = (uint16_t *)(l_unb + sc.a_n_unbounded);
-        const int nl = kd32 ? sc.kd_nleaf : 0;
-        for (int i = tid; i < nl; i += THREADS) l_leaf[i] = sc.a_leaf[i];
-        size_t off = (size_t)((char *)(l_leaf + nl) - (char *)lds);
-        off = (off + 15) & ~(size_t)15;
-        const int depth = kd32 ? (sc.a_kd_depth > 0 ? sc.a_kd_depth : 1) : 1;
-        coopW = coop_carve((char *)lds + off + (size_t)(tid >> 6) * COOP_WAVE_BYTES(depth), depth);
-        A.sbox = l_sbox; A.nodes = l_nodes; A.leaf_surfs = l_leaf; A.always = l_alw; A.unbounded = l_unb;
-        A.n_always = na; A.n_unbounded = sc.a_n_unbounded; A.n_surf = S; A.has_kd = kd32 ? 1 : 0;
-        A.dbg = (P.flags >> 8) & 3;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) A.root[i] = sc.a_root[i];
-        A.delta = sc.a_delta;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { A.cen[i] = sc.a_cen[i]; A.slo[i] = sc.a_slo[i]; A.shi[i] = sc.a_shi[i]; }
-    } else if (P.lds_scene && sc.has_kd) {
+    if (P.lds_scene && sc.has_kd) {
         int32_t *ic = (int32_t *)cursor;
         int32_t *l_a = ic; ic += sc.kd_nodes;
         int32_t *l_b = ic; ic += sc.kd_nodes;
@@ -686,35 +565,20 @@ __global__ __launch_bounds__(THREADS) void k_trace_fast(FastParams P) {
         if (next < end && need) {
             long long id = next + __popcll(need & lt_mask);
             if (!alive && id < end) {
-                rid = P.rid ? P.rid[id] : (P.ray_offset + (unsigned long long)id);
-                if (P.src) {
-                    trc_source_ray(P.src, buie, P.seed, rid, &px, &py, &pz, &dx, &dy, &dz);
-                    e = P.src->energy; ref = 1.0; wl = 0.0;
-                } else {
-                    px = P.x[id]; py = P.y[id]; pz = P.z[id];
-                    dx = P.dx[id]; dy = P.dy[id]; dz = P.dz[id];
-                    e = P.e[id];
-                    ref = P.ref ? P.ref[id] : 1.0;
-                    wl = P.wl ? P.wl[id] : 0.0;
-                }
+                fast_new_ray(P, buie, id, px, py, pz, dx, dy, dz, e, ref, wl, rid);
                 bounce = 0;
                 alive = true;
             }
             next += __popcll(need);
         }
         if (!__ballot(alive)) break;
+        if (!alive) continue;
 
         // ---- one segment ----
+        nseg += 1.0;
         double t;
         int s;
-        if (M32) {
-            // wave-cooperative: every lane takes part, dead lanes only help draining the queues
-            nearest_coop32(A, coopW, recs, sc.stride, sc.extra, alive, px, py, pz, dx, dy, dz, &t, &s);
-            if (!alive) continue;
-            nseg += 1.0;
-        } else if (!alive) {
-            continue;
-        } else if ((nseg += 1.0), accel) {
+        if (accel) {
             LocalKdStack stk;
             trc_nearest_kd(kd, stk, recs, sc.stride, sc.extra, px, py, pz, dx, dy, dz, &t, &s);
         } else {
@@ -722,35 +586,8 @@ __global__ __launch_bounds__(THREADS) void k_trace_fast(FastParams P) {
         }
         if (s < 0) { alive = false; continue; }
         nhit += 1.0;
-        bounce += 1;
-        const double *rec = recs + (size_t)s * sc.stride;
-        double hx = px + t * dx, hy = py + t * dy, hz = pz + t * dz;
-        double nx, ny, nz;
-        trc_normal(rec, hx, hy, hz, dx, dy, dz, &nx, &ny, &nz);
-        trc_ray_out out[2];
-        int n_out = trc_shade(trc_rec_opt_kind(rec), sc.opt + (size_t)s * 8, sc.extra, trc_rec_extra_off(rec),
-                              trc_rec_extra_len(rec), rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, nx, ny,
-                              nz, P.seed, rid, (uint32_t)bounce, out);
-        (void)n_out;  // scenes whose optics split rays are routed to the ordered engine by the host
-        double e_abs = e - out[0].e;
-        if (P.lds_tally) record_hit<true>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0);
-        else record_hit<false>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0);
-        px = hx; py = hy; pz = hz;
-        dx = out[0].dx; dy = out[0].dy; dz = out[0].dz;
-        e = out[0].e; ref = out[0].ref;
-        if (e <= P.min_energy) { alive = false; continue; }      // tracer_engine.py:242
-        if (bounce >= P.reps) {                                   // still alive after the last iteration
-            alive = false;
-            atomicAdd(&sc.counters[3], 1ull);
-            atomicAdd(sc.energy_left, e);
-            if (P.flags & TRC_TRACE_KEEP_LAST) {
-                unsigned long long slot = atomicAdd(&sc.counters[2], 1ull);
-                if ((long long)slot < P.last_cap) {
-                    P.lx[slot] = px; P.ly[slot] = py; P.lz[slot] = pz;
-                    P.ldx[slot] = dx; P.ldy[slot] = dy; P.ldz[slot] = dz; P.le[slot] = e;
-                }
-            }
-        }
+        if (P.lds_tally) alive = fast_shade<true>(P, recs, l_tally, t, s, px, py, pz, dx, dy, dz, e, ref, wl, rid, bounce);
+        else alive = fast_shade<false>(P, recs, l_tally, t, s, px, py, pz, dx, dy, dz, e, ref, wl, rid, bounce);
     }
 
     // ---- flush ----
@@ -766,6 +603,238 @@ __global__ __launch_bounds__(THREADS) void k_trace_fast(FastParams P) {
     } else if (lane == 0) {
         atomicAdd(&sc.tally[3 * S], nseg);
         atomicAdd(&sc.tally[3 * S + 1], nhit);
+    }
+}
+
+// Cooperative fast kernel (see the block comment above).  Exact tests read the surface records from global
+// memory (they are rare); everything the candidate search touches lives in LDS:
+//   doubles [buie 639][tally 3S+2] | float [sbox 6S] | u32 [nodes 2n] | i32 [always][unbounded] | u16 [leaf] |
+//   16-byte aligned per-wave regions of COOP_WAVE_BYTES(depth)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
+    extern __shared__ double lds[];
+    const DScene &sc = P.sc;
+    const int S = sc.n_surf;
+    const int tid = threadIdx.x;
+    const unsigned lane = lane_id();
+    const double *recs = sc.recs;
+
+    double *cursor = lds;
+    const double *buie = nullptr;
+    if (P.src) {
+        const int NB = 3 * (TRC_BUIE_NELEM + 1) + 6;
+        double *l_buie = cursor; cursor += NB;
+        if (P.src->kind == TRC_SRC_BUIE_DISK || P.src->kind == TRC_SRC_BUIE_RECT)
+            for (int i = tid; i < NB; i += THREADS) l_buie[i] = P.src->buie[i];
+        buie = l_buie;
+    }
+    double *l_tally = cursor;
+    cursor += 3 * S + 2;
+    for (int i = tid; i < 3 * S + 2; i += THREADS) l_tally[i] = 0.0;
+
+    const bool kd32 = sc.a_kd_ok && (P.flags & TRC_TRACE_ACCEL);
+    trc_accel_view A;
+    CoopLds W;
+    {
+        float *l_sbox = (float *)cursor;
+        for (int i = tid; i < 6 * S; i += THREADS) l_sbox[i] = sc.a_sbox[i];
+        uint32_t *l_nodes = (uint32_t *)(l_sbox + 6 * S);
+        const int nn = kd32 ? sc.kd_nodes : 0;
+        for (int i = tid; i < 2 * nn; i += THREADS) l_nodes[i] = sc.a_nodes[i];
+        int32_t *l_alw = (int32_t *)(l_nodes + 2 * nn);
+        const int na = kd32 ? sc.kd_nalways : 0;
+        for (int i = tid; i < na; i += THREADS) l_alw[i] = sc.kd_always[i];
+        int32_t *l_unb = l_alw + na;
+        for (int i = tid; i < sc.a_n_unbounded; i += THREADS) l_unb[i] = sc.a_unbounded[i];
+        uint16_t *l_leaf = (uint16_t *)(l_unb + sc.a_n_unbounded);
+        const int nl = kd32 ? sc.kd_nleaf : 0;
+        for (int i = tid; i < nl; i += THREADS) l_leaf[i] = sc.a_leaf[i];
+        size_t off = (size_t)((char *)(l_leaf + nl) - (char *)lds);
+        off = (off + 15) & ~(size_t)15;
+        const int depth = kd32 ? (sc.a_kd_depth > 0 ? sc.a_kd_depth : 1) : 1;
+        W = coop_carve((char *)lds + off + (size_t)(tid >> 6) * COOP_WAVE_BYTES(depth));
+        A.sbox = l_sbox; A.nodes = l_nodes; A.leaf_surfs = l_leaf; A.always = l_alw; A.unbounded = l_unb;
+        A.n_always = na; A.n_unbounded = sc.a_n_unbounded; A.n_surf = S; A.has_kd = kd32 ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) A.root[i] = sc.a_root[i];
+        A.delta = sc.a_delta;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { A.cen[i] = sc.a_cen[i]; A.slo[i] = sc.a_slo[i]; A.shi[i] = sc.a_shi[i]; }
+    }
+    __syncthreads();
+
+    // this wave's slice of the ray-id range
+    const long long n_waves = (long long)gridDim.x * (THREADS >> 6);
+    const long long wave = (long long)blockIdx.x * (THREADS >> 6) + (tid >> 6);
+    const long long chunk = (P.n + n_waves - 1) / n_waves;
+    long long next = wave * chunk;
+    long long end = next + chunk;
+    if (end > P.n) end = P.n;
+    if (next > end) next = end;
+
+    bool alive = false;       // the lane holds a ray that still needs its segment
+    bool prepared = false;    // ... and the ray has candidates: it takes part in the search below
+    double px = 0, py = 0, pz = 0, dx = 0, dy = 0, dz = 0, e = 0, ref = 1.0, wl = 0.0;
+    unsigned long long rid = 0;
+    int bounce = 0;
+    double nseg = 0.0, nhit = 0.0;
+    double tb = TRC_INF;      // best hit among the surfaces tested inline (unbounded ones)
+    int sb = -1;
+    bool in = false, walking = false;
+    float tmin = 0.0f, tmax = 0.0f;
+    unsigned alw_mask = 0;    // always-relevant surfaces whose box the ray crosses (first 32 of them; the rest always pass)
+    trc_ray32 r;
+    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int stride = sc.stride;
+    const double *extra = sc.extra;
+
+    for (;;) {
+        // ================= refill + prepare: up to 3 passes =================
+        for (int pass = 0; pass < 3; ++pass) {
+            unsigned long long need = __ballot(!alive);
+            if (next < end && need) {
+                long long id = next + __popcll(need & lt_mask);
+                if (!alive && id < end) {
+                    fast_new_ray(P, buie, id, px, py, pz, dx, dy, dz, e, ref, wl, rid);
+                    bounce = 0;
+                    alive = true;
+                    prepared = false;
+                }
+                next += __popcll(need);
+            }
+            if (!__ballot(alive && !prepared)) break;
+            if (alive && !prepared) {
+                tb = TRC_INF;
+                sb = -1;
+                const double vx = px, vy = py, vz = pz;   // names used by TRC_TEST_EXACT
+                for (int k = 0; k < A.n_unbounded; ++k) TRC_TEST_EXACT(A.unbounded[k]);
+                double t0;
+                in = trc_ray32_prepare(A.slo, A.shi, A.cen, px, py, pz, dx, dy, dz, &r, &t0);
+                walking = false;
+                alw_mask = 0;
+                bool cand = false;
+                if (in) {
+                    if (kd32) {
+                        walking = trc_kd32_root(A.root, r, &tmin, &tmax);
+                        for (int k = 0; k < A.n_always; ++k) {
+                            const float *b = A.sbox + 6 * (size_t)A.always[k];
+                            bool bounded = !(b[3] == TRC_INF && b[0] == -TRC_INF);
+                            if (bounded && (k >= 32 || trc_box_hit32(b, r))) { if (k < 32) alw_mask |= 1u << k; cand = true; }
+                        }
+                        cand = cand || walking;
+                    } else {
+                        cand = true;    // brute force over the boxes happens in the search
+                    }
+                }
+                if (cand || sb >= 0) {
+                    prepared = true;
+                } else {
+                    nseg += 1.0;        // the segment hits nothing: finished, the lane can be refilled in the next pass
+                    alive = false;
+                }
+            }
+        }
+        if (!__ballot(alive)) {
+            if (next >= end) break;
+            continue;
+        }
+
+        // ================= search (wave-cooperative; every lane takes part) =================
+        W.best_t[lane] = (unsigned long long)__double_as_longlong(TRC_INF);
+        W.best_s[lane] = 0x7FFFFFFF;
+        W.dirty[lane] = 0;
+        W.rd[lane] = px; W.rd[64 + lane] = py; W.rd[128 + lane] = pz;
+        W.rd[192 + lane] = dx; W.rd[256 + lane] = dy; W.rd[320 + lane] = dz;
+        W.rf[lane] = r.ox; W.rf[64 + lane] = r.oy; W.rf[128 + lane] = r.oz;
+        W.rf[192 + lane] = r.ix; W.rf[256 + lane] = r.iy; W.rf[320 + lane] = r.iz;
+        int ecount = 0;   // wave-uniform
+        const uint32_t me = (uint32_t)lane << 16;
+        const bool searching = alive && prepared && in;
+        if (!kd32) {
+            for (int sidx = 0; sidx < S; ++sidx) {
+                const float *b = A.sbox + 6 * (size_t)sidx;
+                bool bounded = !(b[3] == TRC_INF && b[0] == -TRC_INF);
+                bool hit = searching && bounded && trc_box_hit32(b, r);
+                coop_push_exact(W, ecount, hit, me | (uint32_t)sidx, recs, stride, extra, lane);
+            }
+        } else {
+            for (int k = 0; k < A.n_always; ++k) {
+                bool hit = searching && (k >= 32 ? true : ((alw_mask >> k) & 1u) != 0);
+                if (k >= 32) {
+                    const float *b = A.sbox + 6 * (size_t)A.always[k];
+                    hit = hit && !(b[3] == TRC_INF && b[0] == -TRC_INF) && trc_box_hit32(b, r);
+                }
+                coop_push_exact(W, ecount, hit, me | (uint32_t)A.always[k], recs, stride, extra, lane);
+            }
+            bool walk = searching && walking;
+            uint32_t node = 0;
+            int sp = 0;
+            unsigned cnt = 0;     // leaves listed since the last drain
+            while (__ballot(walk)) {
+                if (walk) {
+                    uint32_t w0 = A.nodes[2 * node], w1 = A.nodes[2 * node + 1];
+                    if ((w1 & 3u) != 3u) {
+                        bool push;
+                        uint32_t na;
+                        float pt;
+                        node = trc_kd32_step(w0, w1, r, A.delta, tmin, &tmax, &push, &na, &pt);
+                        if (push) {
+                            // stack entry: (node << 18) | (axis code << 16) | interval end as the upper half of a float32
+                            // rounded UP (the interval only ever grows: conservative)
+                            uint32_t bts = __float_as_uint(pt);
+                            uint32_t hb = (bts >> 16) + ((bts & 0xFFFFu) ? 1u : 0u);
+                            W.stack[sp * 64 + lane] = (na << 16) | (hb & 0xFFFFu);
+                            ++sp;
+                        }
+                    } else {
+                        if ((w1 >> 2) != 0u) { W.lst[cnt * 64 + lane] = (uint16_t)node; ++cnt; }
+                        if (sp == 0) walk = false;
+                        else {
+                            --sp;
+                            uint32_t en = W.stack[sp * 64 + lane];
+                            uint32_t na = en >> 16;
+                            node = na >> 2;
+                            tmin = trc_kd32_pop_tmin(na & 3u, r, A.delta, tmax);
+                            tmax = __uint_as_float(en << 16);
+                        }
+                    }
+                }
+                if (__ballot(cnt >= COOP_LEAFCAP)) {    // some lane's list is full: everybody drains
+                    coop_drain_leaves(A, W, cnt, ecount, recs, stride, extra, lane);
+                    cnt = 0;
+                }
+            }
+            coop_drain_leaves(A, W, cnt, ecount, recs, stride, extra, lane);
+        }
+        coop_drain_exact(W, ecount, recs, stride, extra, lane);
+
+        // ================= per lane: result of the segment, shading =================
+        if (alive) {
+            double t = tb;
+            int s = sb;
+            double tq = __longlong_as_double((long long)W.best_t[lane]);
+            int sq = W.best_s[lane];
+            if (tq < TRC_INF && (tq < t || (tq == t && sq < s))) { t = tq; s = sq; }
+            nseg += 1.0;
+            prepared = false;
+            if (s < 0) alive = false;
+            else {
+                nhit += 1.0;
+                alive = fast_shade<true>(P, recs, l_tally, t, s, px, py, pz, dx, dy, dz, e, ref, wl, rid, bounce);
+            }
+        }
+        WAVE_SYNC();
+    }
+
+    // ---- flush ----
+    nseg = wave_sum(nseg);
+    nhit = wave_sum(nhit);
+    if (lane == 0) { atomicAdd(&l_tally[3 * S], nseg); atomicAdd(&l_tally[3 * S + 1], nhit); }
+    __syncthreads();
+    for (int i = tid; i < 3 * S + 2; i += THREADS) {
+        double v = l_tally[i];
+        if (v != 0.0) atomicAdd(&sc.tally[i], v);
     }
 }
 
@@ -1615,8 +1684,8 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
             if (P.lds_scene) lds += b_scene;
         }
         void (*kern)(FastParams) = nullptr;
-        if (m32) kern = threads == 1024 ? k_trace_fast<1024, true> : (threads == 512 ? k_trace_fast<512, true> : k_trace_fast<256, true>);
-        else kern = k_trace_fast<256, false>;
+        if (m32) kern = threads == 1024 ? k_trace_coop<1024> : (threads == 512 ? k_trace_coop<512> : k_trace_coop<256>);
+        else kern = k_trace_fast<256>;
         if (lds > 64 * 1024) {
             hipError_t ae = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (ae != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(ae)); break; }
