@@ -85,6 +85,9 @@ struct trc_accel_host {
     std::vector<int32_t> unbounded;
     std::vector<uint32_t> nodes;      // 2 per Kd node
     std::vector<uint16_t> leaf_surfs;
+    std::vector<uint16_t> brute_leaf;  // all bounded surfaces: the single leaf used when no Kd-tree is given
+    uint32_t brute_nodes[2];
+    float brute_root[6];
     float root[6];
     float delta;
     double cen[3], slo[3], shi[3];
@@ -114,6 +117,14 @@ static inline void trc_accel_build_surfaces(const trc_surface_desc *surfs, int n
     double delta = std::fmax(1e-3, 2.5e-5 * ext);
     A.delta = (float)delta;
     for (int k = 0; k < 3; ++k) { A.slo[k] = slo[k] - 2.0 * delta; A.shi[k] = shi[k] + 2.0 * delta; }
+    A.brute_leaf.clear();
+    for (int i = 0; i < n && i < 65536; ++i) if (bounded[i]) A.brute_leaf.push_back((uint16_t)i);
+    A.brute_nodes[0] = 0u;
+    A.brute_nodes[1] = ((uint32_t)A.brute_leaf.size() << 2) | 3u;
+    for (int k = 0; k < 3; ++k) {
+        A.brute_root[k] = trc_f32_down(A.slo[k] - A.cen[k]);
+        A.brute_root[3 + k] = trc_f32_up(A.shi[k] - A.cen[k]);
+    }
     A.sbox.assign(6 * (size_t)n, 0.0f);
     for (int i = 0; i < n; ++i)
         for (int k = 0; k < 3; ++k) {

@@ -94,7 +94,11 @@ struct DScene {
     const uint32_t *a_nodes;
     const uint16_t *a_leaf;
     const int32_t *a_unbounded;
+    const uint16_t *a_bleaf;
     int32_t a_n_unbounded, a_kd_depth, a_ok, a_kd_ok;
+    int32_t a_n_bleaf, a_pad2;
+    uint32_t a_bnodes[2];
+    float a_broot[6];
     float a_root[6];
     float a_delta, a_pad;
     double a_cen[3], a_slo[3], a_shi[3];
@@ -132,6 +136,7 @@ struct trc_scene {
     uint32_t *d_a_nodes;
     uint16_t *d_a_leaf;
     int32_t *d_a_unbounded;
+    uint16_t *d_a_bleaf;
     double *d_tally;
     int64_t tally_n;
     std::vector<FluxMapDev> fms_h;
@@ -422,14 +427,27 @@ __device__ __forceinline__ void coop_drain_leaves(const trc_accel_view &A, const
             r.ox = W.rf[L]; r.oy = W.rf[64 + L]; r.oz = W.rf[128 + L];
             r.ix = W.rf[192 + L]; r.iy = W.rf[256 + L]; r.iz = W.rf[320 + L];
         }
-        for (unsigned k = 0; __ballot(k < lc); ++k) {
-            bool hit = false;
-            unsigned sidx = 0;
-            if (k < lc) {
-                sidx = A.leaf_surfs[off + k];
-                hit = trc_box_hit32(A.sbox + 6 * (size_t)sidx, r);
+        // box tests of the leaf's surfaces, four at a time (independent LDS loads in flight), hits kept as a bit mask;
+        // the wave-level queue append happens once per round, for the (rare) set bits
+        for (unsigned kb = 0; __ballot(kb < lc); kb += 32) {        // the hit mask holds 32 surfaces at a time
+            unsigned hits = 0;
+            for (unsigned k0 = kb; k0 < kb + 32 && __ballot(k0 < lc); k0 += 4) {
+                unsigned sid[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sid[q] = (k0 + q < lc) ? (unsigned)A.leaf_surfs[off + k0 + q] : 0u;
+                bool h[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h[q] = trc_box_hit32(A.sbox + 6 * (size_t)sid[q], r);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (h[q] && k0 + q < lc) hits |= 1u << (k0 + q - kb);
             }
-            coop_push_exact(W, ecount, hit, (L << 16) | sidx, recs, stride, extra, lane);
+            while (__ballot(hits != 0)) {
+                bool want = hits != 0;
+                unsigned k = want ? kb + (unsigned)__ffs((int)hits) - 1u : 0u;
+                unsigned sidx = want ? (unsigned)A.leaf_surfs[off + k] : 0u;
+                coop_push_exact(W, ecount, want, (L << 16) | sidx, recs, stride, extra, lane);
+                hits &= hits - 1u;
+            }
         }
     }
     WAVE_SYNC();
@@ -639,24 +657,24 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
         float *l_sbox = (float *)cursor;
         for (int i = tid; i < 6 * S; i += THREADS) l_sbox[i] = sc.a_sbox[i];
         uint32_t *l_nodes = (uint32_t *)(l_sbox + 6 * S);
-        const int nn = kd32 ? sc.kd_nodes : 0;
-        for (int i = tid; i < 2 * nn; i += THREADS) l_nodes[i] = sc.a_nodes[i];
+        const int nn = kd32 ? sc.kd_nodes : 1;          // without a Kd-tree: one leaf holding every bounded surface
+        for (int i = tid; i < 2 * nn; i += THREADS) l_nodes[i] = kd32 ? sc.a_nodes[i] : sc.a_bnodes[i];
         int32_t *l_alw = (int32_t *)(l_nodes + 2 * nn);
         const int na = kd32 ? sc.kd_nalways : 0;
         for (int i = tid; i < na; i += THREADS) l_alw[i] = sc.kd_always[i];
         int32_t *l_unb = l_alw + na;
         for (int i = tid; i < sc.a_n_unbounded; i += THREADS) l_unb[i] = sc.a_unbounded[i];
         uint16_t *l_leaf = (uint16_t *)(l_unb + sc.a_n_unbounded);
-        const int nl = kd32 ? sc.kd_nleaf : 0;
-        for (int i = tid; i < nl; i += THREADS) l_leaf[i] = sc.a_leaf[i];
+        const int nl = kd32 ? sc.kd_nleaf : sc.a_n_bleaf;
+        for (int i = tid; i < nl; i += THREADS) l_leaf[i] = kd32 ? sc.a_leaf[i] : sc.a_bleaf[i];
         size_t off = (size_t)((char *)(l_leaf + nl) - (char *)lds);
         off = (off + 15) & ~(size_t)15;
         const int depth = kd32 ? (sc.a_kd_depth > 0 ? sc.a_kd_depth : 1) : 1;
         W = coop_carve((char *)lds + off + (size_t)(tid >> 6) * COOP_WAVE_BYTES(depth));
         A.sbox = l_sbox; A.nodes = l_nodes; A.leaf_surfs = l_leaf; A.always = l_alw; A.unbounded = l_unb;
-        A.n_always = na; A.n_unbounded = sc.a_n_unbounded; A.n_surf = S; A.has_kd = kd32 ? 1 : 0;
+        A.n_always = na; A.n_unbounded = sc.a_n_unbounded; A.n_surf = S; A.has_kd = 1;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) A.root[i] = sc.a_root[i];
+        for (int i = 0; i < 6; ++i) A.root[i] = kd32 ? sc.a_root[i] : sc.a_broot[i];
         A.delta = sc.a_delta;
 #pragma unroll
         for (int i = 0; i < 3; ++i) { A.cen[i] = sc.a_cen[i]; A.slo[i] = sc.a_slo[i]; A.shi[i] = sc.a_shi[i]; }
@@ -715,17 +733,13 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
                 alw_mask = 0;
                 bool cand = false;
                 if (in) {
-                    if (kd32) {
-                        walking = trc_kd32_root(A.root, r, &tmin, &tmax);
-                        for (int k = 0; k < A.n_always; ++k) {
-                            const float *b = A.sbox + 6 * (size_t)A.always[k];
-                            bool bounded = !(b[3] == TRC_INF && b[0] == -TRC_INF);
-                            if (bounded && (k >= 32 || trc_box_hit32(b, r))) { if (k < 32) alw_mask |= 1u << k; cand = true; }
-                        }
-                        cand = cand || walking;
-                    } else {
-                        cand = true;    // brute force over the boxes happens in the search
+                    walking = trc_kd32_root(A.root, r, &tmin, &tmax);
+                    for (int k = 0; k < A.n_always; ++k) {
+                        const float *b = A.sbox + 6 * (size_t)A.always[k];
+                        bool bounded = !(b[3] == TRC_INF && b[0] == -TRC_INF);
+                        if (bounded && (k >= 32 || trc_box_hit32(b, r))) { if (k < 32) alw_mask |= 1u << k; cand = true; }
                     }
+                    cand = cand || walking;
                 }
                 if (cand || sb >= 0) {
                     prepared = true;
@@ -751,14 +765,7 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
         int ecount = 0;   // wave-uniform
         const uint32_t me = (uint32_t)lane << 16;
         const bool searching = alive && prepared && in;
-        if (!kd32) {
-            for (int sidx = 0; sidx < S; ++sidx) {
-                const float *b = A.sbox + 6 * (size_t)sidx;
-                bool bounded = !(b[3] == TRC_INF && b[0] == -TRC_INF);
-                bool hit = searching && bounded && trc_box_hit32(b, r);
-                coop_push_exact(W, ecount, hit, me | (uint32_t)sidx, recs, stride, extra, lane);
-            }
-        } else {
+        {
             for (int k = 0; k < A.n_always; ++k) {
                 bool hit = searching && (k >= 32 ? true : ((alw_mask >> k) & 1u) != 0);
                 if (k >= 32) {
@@ -1226,7 +1233,10 @@ static int scene_upload_surfaces(trc_scene *sc) {
     HIP_TRY(hipMemcpy(sc->d_sflags, flags.data(), flags.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     // conservative single-precision boxes of the bounded surfaces (fast engine)
     trc_accel_build_surfaces(sc->surfs.data(), sc->n_surf, sc->accel);
-    dev_free(sc->d_a_sbox); dev_free(sc->d_a_unbounded);
+    dev_free(sc->d_a_sbox); dev_free(sc->d_a_unbounded); dev_free(sc->d_a_bleaf);
+    TRC_TRY(dev_alloc(&sc->d_a_bleaf, sc->accel.brute_leaf.size()));
+    if (!sc->accel.brute_leaf.empty())
+        HIP_TRY(hipMemcpy(sc->d_a_bleaf, sc->accel.brute_leaf.data(), sc->accel.brute_leaf.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     TRC_TRY(dev_alloc(&sc->d_a_sbox, sc->accel.sbox.size()));
     TRC_TRY(dev_alloc(&sc->d_a_unbounded, sc->accel.unbounded.size()));
     HIP_TRY(hipMemcpy(sc->d_a_sbox, sc->accel.sbox.data(), sc->accel.sbox.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1303,7 +1313,7 @@ extern "C" int trc_scene_destroy(trc_scene *sc) {
     (void)hipStreamSynchronize(sc->ctx->stream);
     dev_free(sc->d_recs); dev_free(sc->d_opt); dev_free(sc->d_extra); dev_free(sc->d_sflags);
     dev_free(sc->d_kd_a); dev_free(sc->d_kd_b); dev_free(sc->d_kd_leaf); dev_free(sc->d_kd_always);
-    dev_free(sc->d_a_sbox); dev_free(sc->d_a_nodes); dev_free(sc->d_a_leaf); dev_free(sc->d_a_unbounded);
+    dev_free(sc->d_a_sbox); dev_free(sc->d_a_nodes); dev_free(sc->d_a_leaf); dev_free(sc->d_a_unbounded); dev_free(sc->d_a_bleaf);
     dev_free(sc->d_kd_split); dev_free(sc->d_tally); dev_free(sc->d_fm_of_surf); dev_free(sc->d_fms);
     dev_free(sc->d_fm_edges); dev_free(sc->d_counters); dev_free(sc->d_energy_left); dev_free(sc->d_h_surf);
     for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
@@ -1522,6 +1532,9 @@ static DScene make_dscene(trc_scene *sc) {
     for (int i = 0; i < 3; ++i) { d.kd_bmin[i] = sc->kd_bounds[i]; d.kd_bmax[i] = sc->kd_bounds[3 + i]; }
     d.a_sbox = sc->d_a_sbox; d.a_nodes = sc->d_a_nodes; d.a_leaf = sc->d_a_leaf; d.a_unbounded = sc->d_a_unbounded;
     d.a_n_unbounded = (int32_t)sc->accel.unbounded.size(); d.a_kd_depth = sc->accel.kd_depth;
+    d.a_bleaf = sc->d_a_bleaf; d.a_n_bleaf = (int32_t)sc->accel.brute_leaf.size();
+    d.a_bnodes[0] = sc->accel.brute_nodes[0]; d.a_bnodes[1] = sc->accel.brute_nodes[1];
+    for (int i = 0; i < 6; ++i) d.a_broot[i] = sc->accel.brute_root[i];
     d.a_ok = sc->accel_ok ? 1 : 0; d.a_kd_ok = sc->accel_kd_ok ? 1 : 0;
     for (int i = 0; i < 6; ++i) d.a_root[i] = sc->accel.root[i];
     d.a_delta = sc->accel.delta;
@@ -1661,7 +1674,8 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         if (threads_env == 256 || threads_env == 512 || threads_env == 1024) threads = threads_env;
         size_t lds = 0;
         if (m32) {
-            size_t b_acc = (size_t)6 * S * 4 + (accel ? ((size_t)2 * sc->kd_nodes * 4 + (size_t)sc->kd_nalways * 4 + (size_t)sc->kd_nleaf * 2) : 0) +
+            size_t b_acc = (size_t)6 * S * 4 + (accel ? ((size_t)2 * sc->kd_nodes * 4 + (size_t)sc->kd_nalways * 4 + (size_t)sc->kd_nleaf * 2)
+                                                      : (8 + sc->accel.brute_leaf.size() * 2)) +
                            sc->accel.unbounded.size() * 4 + 32;
             for (;;) {
                 lds = b_buie + b_tally + b_acc + (size_t)(threads / 64) * COOP_WAVE_BYTES(accel ? (sc->accel.kd_depth > 0 ? sc->accel.kd_depth : 1) : 1);
