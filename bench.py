@@ -74,14 +74,21 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # TRC_BENCH_BACKEND=gloo rehearses the multi-rank logic on a box with fewer GPUs than ranks (ranks share GPUs)
+    backend = os.environ.get('TRC_BENCH_BACKEND', 'nccl')
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend=backend)
 
     import numpy as N
     from tracer_amd import _cabi, scenes
     from tracer_amd.accel_tree import KdTree
     from tracer_amd.scene import compile_scene, DeviceScene
+    from tracer_amd.distributed import reduce_scene_tallies, all_reduce_sum
 
     _cabi.set_default_device(local)
     ctx = _cabi.get_context(local)
@@ -94,8 +101,6 @@ def main():
     ue, ve = scenes.nsttf_fluxmap_edges()
     dev.set_fluxmap(218, ue, ve)
     dev.set_hit_capacity(int(0.08 * n * (args.steps + args.warmup)) + 4096)   # receiver hits ~6.4 % of the source rays
-
-    tally = torch.zeros(dev.tally_size(), dtype=torch.float64, device='cuda')
 
     def barrier():
         if world > 1:
@@ -112,7 +117,7 @@ def main():
     for k in range(args.warmup):
         step(k)
     if world > 1:
-        dist.all_reduce(torch.zeros(8, dtype=torch.float64, device='cuda'))   # communicator set-up outside the timed region
+        reduce_scene_tallies(dev)      # communicator set-up outside the timed region
     dev.reset_tallies()
     dev.lib.trc_scene_clear_hits(dev.handle)
 
@@ -125,20 +130,14 @@ def main():
         seg += st.segments
         kms += st.kernel_ms
     # the single exchange of the job: sum the tally buffers of all ranks (per-surface energies, counts, flux map)
-    dev.export_tallies(out=tally.data_ptr())
-    if world > 1:
-        dist.all_reduce(tally)
-        dev.import_tallies(tally.data_ptr())
+    reduce_scene_tallies(dev)
     barrier()
     dt = time.time() - t0
 
-    seg_t = torch.tensor([float(seg), dt, kms], dtype=torch.float64, device='cuda')
     if world > 1:
-        tot = seg_t.clone()
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        mx = seg_t.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        total_segments, dt_max = float(tot[0]), float(mx[1])
+        total_segments = float(all_reduce_sum(N.array([float(seg)]))[0])
+        times = all_reduce_sum(N.eye(world)[rank] * dt)        # every rank's time; the job takes the slowest
+        dt_max = float(times.max())
     else:
         total_segments, dt_max = float(seg), dt
 
@@ -153,7 +152,10 @@ def main():
         tf = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get('hbm_bytes_per_launch')
+                tj = json.load(open(tf))
+                # the PMC passes were taken on the default workload (1e8 rays per launch, Kd-tree)
+                if int(tj.get('rays_per_launch', 0)) == n and accel:
+                    traffic = tj.get('hbm_bytes_per_launch')
             except Exception:
                 traffic = None
         out = {
@@ -170,7 +172,7 @@ def main():
                        'rays_per_step_per_gpu': n, 'segments_per_step_per_gpu': seg / args.steps, 'accel': accel,
                        'parallelism': 'rays sharded by stream id over %d GPU(s), one all-reduce of tallies at the end' % world},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'k_trace_fast', 'kernel_ms_per_launch': kms / args.steps,
+                         'traffic': traffic, 'kernel': 'k_trace_coop<512>', 'kernel_ms_per_launch': kms / args.steps,
                          'algorithmic_bytes_per_launch': seg / args.steps * B_SEG},
             'check': {'receiver_kW': receiver_kw, 'receiver_hits_per_ray': h[218] / total_rays,
                       'heliostat_hits_per_ray': float(h[:218].sum()) / total_rays,

@@ -1,0 +1,265 @@
+"""
+GPU tests of the Python plugin API (run with -m gpu): the reference's own unit tests restated against tracer_amd's
+classes -- same inputs, same expected values (file:line of the reference test in each docstring).  They exercise
+the per-surface protocol kernels, the three engines through TracerEngine, the accountants and the compat aliases.
+"""
+import math
+
+import numpy as N
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tracer_amd.ray_bundle import RayBundle
+from tracer_amd.surface import Surface
+from tracer_amd.object import AssembledObject
+from tracer_amd.assembly import Assembly
+from tracer_amd.flat_surface import FlatGeometryManager, RectPlateGM, RoundPlateGM
+from tracer_amd.triangular_face import TriangularFace
+from tracer_amd.paraboloid import Paraboloid, ParabolicDishGM
+from tracer_amd.sphere_surface import HemisphereGM, SphericalGM
+from tracer_amd.cylinder import InfiniteCylinder, FiniteCylinder
+from tracer_amd.spatial_geometry import generate_transform, rotx, translate, general_axis_rotation
+from tracer_amd.tracer_engine import TracerEngine
+from tracer_amd import optics_callables as opt
+from tracer_amd import optics, sources
+
+
+def _bundle45():
+    """the four rays at 45 degrees of tests/test_flat_geometry_manager.py:12-22"""
+    dir = N.array([[1, 1, -1], [-1, 1, -1], [-1, -1, -1], [1, -1, -1]]).T / math.sqrt(3)
+    position = N.c_[[0, 0, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]]
+    return RayBundle(position, dir)
+
+
+def test_flat_gm_known_answers():
+    """tests/test_flat_geometry_manager.py:10-53 (t = sqrt(3), normals, hit points), :56-80 (plane tilted by 45 deg),
+    :139-152 (back-side hit flips the normal)"""
+    gm = FlatGeometryManager()
+    b = _bundle45()
+    t = gm.find_intersections(N.eye(4), b)
+    assert t.shape == (4,) and N.allclose(t, N.sqrt(3))
+    gm.select_rays(N.arange(4))
+    assert N.array_equal(gm.get_normals(), N.tile(N.c_[[0, 0, 1]], (1, 4)))
+    correct = N.zeros((3, 4)); correct[:2, 0] = 1
+    assert N.allclose(gm.get_intersection_points_global(), correct, atol=1e-15)
+    gm.select_rays(N.r_[1, 3])
+    assert N.array_equal(gm.get_normals(), N.tile(N.c_[[0, 0, 1]], (1, 2)))
+    gm.done()
+    s2 = math.sqrt(2)
+    dir = N.c_[[1, 0, -s2], [-1, 0, -s2], [-1, -s2, 0], [1, -s2, 0]] / math.sqrt(3)
+    position = N.c_[[0, 1 / s2, 1 / s2], [1, 0, s2], [1, s2, 0], [-1, s2, 0]]
+    frame = generate_transform(N.r_[1., 0, 0], -N.pi / 4., N.zeros((3, 1)))
+    t = gm.find_intersections(frame, RayBundle(position, dir))
+    assert t.shape == (4,) and N.allclose(t, math.sqrt(3))
+    gm.select_rays(N.arange(4))
+    assert N.allclose(gm.get_normals(), N.tile(N.c_[[0, 1 / s2, 1 / s2]], (1, 4)))
+    gm.done()
+    up = RayBundle(N.c_[[0., 0., -1.]], N.c_[[0., 0., 1.]])           # from below: the normal opposes the ray
+    t = gm.find_intersections(N.eye(4), up)
+    gm.select_rays(N.r_[0])
+    assert N.allclose(t, 1.) and N.allclose(gm.get_normals(), N.c_[[0., 0., -1.]])
+
+
+def test_rect_round_triangle_apertures():
+    """tests/test_rect_plate.py:13-27, test_round_plate.py, test_triangular_face.py:11-38"""
+    pos = N.zeros((3, 4)); pos[0] = N.r_[0, 0.5, 2, -2]; pos[2] = 1.
+    bund = RayBundle(pos, N.tile(N.c_[[0, 0, -1]], (1, 4)).astype(float))
+    surf = Surface(RectPlateGM(1, 0.25), opt.perfect_mirror)
+    assert N.array_equal(N.isinf(surf.register_incoming(bund)), N.r_[False, False, True, True])
+    with pytest.raises(ValueError):
+        RectPlateGM(-1, 7)
+    with pytest.raises(ValueError):
+        RectPlateGM(1, -7)
+    pos = N.zeros((3, 4)); pos[0] = N.r_[0., 0.4, 0.9, 1.1]; pos[2] = 1.
+    down = RayBundle(pos, N.tile(N.c_[[0., 0., -1.]], (1, 4)))
+    assert N.array_equal(N.isfinite(RoundPlateGM(1.).find_intersections(N.eye(4), down)), [True, True, True, False])
+    assert N.array_equal(N.isfinite(RoundPlateGM(1., 0.5).find_intersections(N.eye(4), down)), [False, False, True, False])
+    tri = TriangularFace(N.array([[1., 0.], [0., 1.], [0., 0.]]))
+    p2 = N.c_[[0.2, 0.2, 1.], [0.8, 0.8, 1.], [-0.1, 0.2, 1.], [0.5, 0.5, 1.]]
+    t = tri.find_intersections(N.eye(4), RayBundle(p2, N.tile(N.c_[[0., 0., -1.]], (1, 4))))
+    assert N.array_equal(N.isfinite(t), [True, False, False, True]) and N.allclose(t[[0, 3]], 1.)
+
+
+def test_paraboloid_and_dish():
+    """tests/test_paraboloid_gm.py:9-41: ten rays on the unit circle, Paraboloid(a=5, b=5): t = 0.96, z = 0.04, normals
+    pointing to the axis; ParabolicDishGM: rays outside the aperture miss"""
+    n = 10
+    theta = N.linspace(0, 2 * N.pi, n, endpoint=False)
+    position = N.vstack((N.cos(theta), N.sin(theta), N.ones(n)))
+    b = RayBundle(position, N.tile(N.c_[[0., 0., -1.]], (1, n)))
+    gm = Paraboloid(a=5., b=5.)
+    t = gm.find_intersections(N.eye(4), b)
+    assert t.shape == (n,) and N.allclose(t, 0.96)
+    gm.select_rays(N.arange(n))
+    nrm = gm.get_normals()
+    assert N.allclose(nrm[-1, 0], nrm[-1, 1:])
+    assert N.allclose(position[:2], -nrm[:2] / N.sqrt((nrm[:2] ** 2).sum(axis=0)))
+    pts = gm.get_intersection_points_global()
+    assert N.allclose(pts[:2], position[:2]) and N.allclose(pts[2], 0.04)
+    dish = ParabolicDishGM(1., 1.)        # aperture radius 0.5: the unit-circle rays miss, inner ones hit
+    assert N.all(N.isinf(dish.find_intersections(N.eye(4), b)))
+    inner = RayBundle(position * N.c_[[0.3, 0.3, 1.]], N.tile(N.c_[[0., 0., -1.]], (1, n)))
+    assert N.all(N.isfinite(dish.find_intersections(N.eye(4), inner)))
+
+
+def test_hemisphere_and_cylinder():
+    """tests/test_hemisphere_gm.py (t = 1 + 2 sin 60 deg), tests/test_cylinder.py:66-99 (rotated frame, finite height)"""
+    gm = HemisphereGM(2.)
+    pos = N.c_[[0., 0., 1.], [1., 0., 1.]]
+    b = RayBundle(pos, N.tile(N.c_[[0., 0., -1.]], (1, 2)))
+    t = gm.find_intersections(N.eye(4), b)
+    assert N.allclose(t, [3., 1. + 2. * math.sin(math.pi / 3.)])
+    cyl = InfiniteCylinder(diameter=1.)
+    pos = N.c_[[-2., 0., 0.], [-2., 0.3, 5.]]
+    b = RayBundle(pos, N.tile(N.c_[[1., 0., 0.]], (1, 2)))
+    t = cyl.find_intersections(N.eye(4), b)
+    assert N.allclose(t, [1.5, 2. - math.sqrt(0.25 - 0.09)])
+    fin = FiniteCylinder(diameter=1., height=2.)
+    assert N.array_equal(N.isfinite(fin.find_intersections(N.eye(4), b)), [True, False])
+    frame = N.eye(4); frame[:3, :3] = rotx(N.pi / 2.)[:3, :3]          # axis along global y
+    t = fin.find_intersections(frame, RayBundle(N.c_[[-2., 0.5, 0.]], N.c_[[1., 0., 0.]]))
+    assert N.allclose(t, 1.5)
+    with pytest.raises(ValueError):
+        SphericalGM(-1.)
+
+
+def test_optics_laws():
+    """tests/test_optics.py:63-130: Fresnel R = 0.04 at normal incidence (n 1 -> 1.5), Snell incl. TIR, mirror law"""
+    d = N.c_[[0., 0., -1.], [math.sin(0.5), 0., -math.cos(0.5)]]
+    n = N.c_[[0., 0., 1.]]
+    R = optics.fresnel(d, n, 1., 1.5)
+    assert N.isclose(R[0], 0.04)
+    assert N.allclose(optics.reflections(d, n), d * N.c_[[1., 1., -1.]])
+    refr, dirs = optics.refractions(1., 1.5, d, n)
+    assert refr.all() and N.allclose(dirs[:, 0], [0., 0., -1.])
+    assert N.isclose(dirs[0, 1] * 1.5, math.sin(0.5))                     # Snell
+    steep = N.c_[[math.sin(1.2), 0., -math.cos(1.2)]]
+    refr, dirs = optics.refractions(1.5, 1., steep, n)                    # beyond the critical angle
+    assert not refr.any() and dirs.shape == (3, 0)
+    assert N.allclose(optics.fresnel(steep, n, 1.5, 1.), 1.)
+
+
+def test_optics_callables_and_accountants():
+    """tests/test_opt_callable.py:20-61 (energies, parents, accumulation across calls), :92-109 (TIR), :139-189 (Lambertian)"""
+    b = _bundle45()
+    b.set_energy(N.ones(4))
+    gm = FlatGeometryManager()
+    gm.find_intersections(N.eye(4), b)
+    sel = N.r_[0, 1, 3]
+    gm.select_rays(sel)
+    out = opt.Reflective(0.1)(gm, b, sel)
+    assert N.allclose(out.get_energy(), 0.9) and N.array_equal(out.get_parents(), sel)
+    assert N.allclose(out.get_directions(), b.get_directions()[:, sel] * N.c_[[1., 1., -1.]])
+    assert N.allclose(out.get_vertices(), gm.get_intersection_points_global())
+    rec = opt.ReflectiveReceiver(1.)
+    rec(gm, b, sel); rec(gm, b, sel)
+    absorbed, hits = rec.get_all_hits()
+    assert absorbed.shape == (6,) and N.allclose(absorbed, 1.) and hits.shape == (3, 6)
+    rec.reset()
+    assert rec.get_all_hits()[0].shape == (0,)
+    lam = opt.Lambertian(0.2)(gm, b, sel)
+    assert N.allclose(lam.get_energy(), 0.8) and N.all(lam.get_directions()[2] >= 0.) and N.allclose(N.sum(lam.get_directions() ** 2, axis=0), 1.)
+    # refraction out of glass beyond the critical angle: all reflected, index unchanged
+    b2 = RayBundle(N.c_[[0., 0., 1.]], N.c_[[math.sin(1.2), 0., -math.cos(1.2)]], energy=N.r_[1.], ref_index=N.r_[1.5])
+    gm.done(); gm.find_intersections(N.eye(4), b2); gm.select_rays(N.r_[0])
+    out = opt.RefractiveHomogenous(1., 1.5, single_ray=False)(gm, b2, N.r_[0])
+    assert out.get_num_rays() == 1 and N.allclose(out.get_energy(), 1.) and N.allclose(out.get_ref_index(), 1.5)
+
+
+def test_engine_two_planes_and_depletion():
+    """tests/test_tracer_engine.py TestTraceProtocol1 (:21-60): two perpendicular mirrors send the rays back; 'bundle depleted'"""
+    s1 = Surface(FlatGeometryManager(), opt.perfect_mirror)
+    s2 = Surface(FlatGeometryManager(), opt.Reflective(0.), rotation=general_axis_rotation(N.r_[1., 0., 0.], N.pi / 2.))
+    asm = Assembly(objects=[AssembledObject(surfs=[s1]), AssembledObject(surfs=[s2], location=N.r_[0., 1., 0.])])
+    d = N.array([[0., 0., 0., 0.], [1., 1., 1., 1.], [-1., -1., -1., -1.]]) / math.sqrt(2.)
+    p = N.c_[[0., -0.5, 1.], [0.2, -0.3, 1.], [-0.2, -0.7, 1.], [0.5, -1., 1.]]
+    eng = TracerEngine(asm)
+    for engine in ('ordered', 'protocol'):
+        b = RayBundle(p.copy(), d.copy(), energy=N.ones(4))
+        v, dd = eng.ray_tracer(b, reps=10, min_energy=0.05, tree=True, engine=engine)
+        assert eng.tree.num_bunds() == 3 and v.shape == (3, 0)             # two bounces, then every ray escapes
+        assert N.allclose(eng.tree[2].get_directions(), -d)                # retro-reflection
+        assert N.array_equal(eng.tree[1].get_parents(), N.arange(4))
+    b = RayBundle(p.copy(), d.copy(), energy=N.ones(4))
+    v, dd = eng.ray_tracer(b, reps=1, min_energy=0.05, tree=True)
+    assert v.shape == (3, 4) and N.allclose(v[2], 0.)                      # reps exhausted: live rays returned
+
+
+def test_tree_ordering_culled_rays_to_back():
+    """tests/test_tracer_tree.py:106-153: surface-major order; rays under min_energy recorded after the live ones"""
+    absorber = Surface(RectPlateGM(1., 1.), opt.Reflective(0.99), location=N.r_[-1., 0., 0.])
+    mirror = Surface(RectPlateGM(1., 1.), opt.Reflective(0.), location=N.r_[1., 0., 0.])
+    asm = Assembly(objects=[AssembledObject(surfs=[mirror]), AssembledObject(surfs=[absorber])])
+    p = N.c_[[-1., 0., 1.], [1., 0.2, 1.], [-1.2, 0.1, 1.], [1.1, -0.2, 1.]]
+    b = RayBundle(p, N.tile(N.c_[[0., 0., -1.]], (1, 4)), energy=N.ones(4))
+    eng = TracerEngine(asm)
+    eng.ray_tracer(b, reps=2, min_energy=0.05, tree=True)
+    lvl = eng.tree[1]
+    assert N.array_equal(lvl.get_parents(), [1, 3, 0, 2])                  # mirror (surface 0) first, culled absorber rays last
+    assert N.allclose(lvl.get_energy(), [1., 1., 0.01, 0.01])
+
+
+def test_models_and_compat_script():
+    """tests/models/test_one_sided_mirror.py (energies front/back) and a scene script written against `tracer.*` names"""
+    import tracer_amd.compat as compat
+    compat.install(force=True)
+    from tracer.models.one_sided_mirror import rect_one_sided_mirror
+    from tracer.assembly import Assembly as TAssembly
+    from tracer.ray_bundle import RayBundle as TBundle
+    from tracer.tracer_engine import TracerEngine as TEngine
+    m = rect_one_sided_mirror(2., 2., absorptivity=0.1)
+    asm = TAssembly(objects=[m])
+    p = N.c_[[0., 0., 1.], [0.5, 0.5, -1.]]
+    d = N.c_[[0., 0., -1.], [0., 0., 1.]]
+    eng = TEngine(asm)
+    eng.ray_tracer(TBundle(p, d, energy=N.ones(2)), reps=1, min_energy=-1., tree=True)
+    assert N.allclose(eng.tree[1].get_energy(), [0.9, 0.])                # front reflects 90 %, back absorbs everything
+    det = m.get_surfaces()[0].get_optics_manager().get_all_hits()
+    assert N.allclose(det[0], [0.1, 1.]) and det[1].shape == (3, 2) and det[2].shape == (3, 2)
+
+
+def test_protocol_engine_with_python_plugin():
+    """a user-defined optics callable (pure Python) in the scene: engine='auto' falls back to the protocol loop, native
+    geometry still runs on the GPU, results equal the all-native scene"""
+    class HalfMirror(object):
+        def __call__(self, geometry, rays, selector):
+            return rays.inherit(selector, vertices=geometry.get_intersection_points_global(),
+                                direction=optics.reflections(rays.get_directions(selector), geometry.get_normals()),
+                                energy=rays.get_energy(selector) * 0.5, parents=selector)
+
+    def build(o1):
+        s1 = Surface(RectPlateGM(4., 4.), o1)
+        s2 = Surface(RoundPlateGM(3.), opt.ReflectiveReceiver(1.), location=N.r_[0., 0., 2.], rotation=rotx(N.pi)[:3, :3])
+        return Assembly(objects=[AssembledObject(surfs=[s1]), AssembledObject(surfs=[s2])]), s2
+    rng = N.random.RandomState(3)
+    p = N.vstack((rng.uniform(-1., 1., (2, 50)), N.ones(50)))
+    d = N.vstack((rng.normal(scale=0.2, size=(2, 50)), -N.ones(50)))
+    d /= N.sqrt(N.sum(d ** 2, axis=0))
+    res = []
+    for o1 in (HalfMirror(), opt.Reflective(0.5)):
+        asm, rec = build(o1)
+        eng = TracerEngine(asm)
+        eng.ray_tracer(RayBundle(p.copy(), d.copy(), energy=N.ones(50)), reps=5, min_energy=1e-6, tree=True)
+        e, h = rec.get_optics_manager().get_all_hits()
+        res.append((eng.tree.num_bunds(), e.copy(), h.copy()))
+    assert res[0][0] == res[1][0] and N.allclose(res[0][1], res[1][1]) and N.allclose(res[0][2], res[1][2])
+    assert len(res[0][1]) > 10
+
+
+def test_sources_statistics():
+    """tests/test_ray_bundle.py:102-183: directions inside the cone, uniform azimuth (KS), total energy"""
+    from scipy import stats
+    n = 20000
+    b = sources.disk_bundle(n, N.c_[[0., 0., 0.]], N.r_[0., 0., 1.], 1., 0.05, flux=2., seed=11)
+    d, v, e = b.get_directions(), b.get_vertices(), b.get_energy()
+    assert N.all(N.arccos(d[2]) <= 0.05 + 1e-12) and N.all(N.sum(v[:2] ** 2, axis=0) <= 1. + 1e-12)
+    assert N.isclose(e.sum(), 2. * N.pi)
+    az = N.arctan2(d[1], d[0]) % (2. * N.pi)
+    assert stats.kstest(az / (2. * N.pi), 'uniform').pvalue > 1e-3
+    assert stats.kstest(N.sum(v[:2] ** 2, axis=0), 'uniform').pvalue > 1e-3      # r^2 uniform on the disc
+    b2 = sources.disk_bundle(n, N.c_[[0., 0., 0.]], N.r_[0., 0., 1.], 1., 0.05, flux=2., seed=11)
+    assert N.array_equal(b2.get_vertices(), v)                                     # same seed, same rays
+    b3 = sources.buie_sunshape(n, N.c_[[0., 0., 6.]], N.r_[0., 0., -1.], 2.5, 0.05, flux=1000., seed=5)
+    th = N.arccos(-b3.get_directions()[2])
+    assert th.max() <= 43.6e-3 + 1e-9 and 0.9 < N.mean(th < 4.65e-3) < 0.99
