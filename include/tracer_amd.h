@@ -84,8 +84,13 @@ typedef enum trc_optics_kind {
     TRC_OPT_LAMBERTIAN = 5,             /* Lambertian              :143-176   opt: absorptivity,ang_range */
     TRC_OPT_LAMBERTIAN_SPECULAR = 6,    /* LambertianSpecular      :553-585   opt: absorptivity,specularity */
     TRC_OPT_REFRACTIVE_HOMOGENOUS = 7,  /* RefractiveHomogenous    :1186-1296 opt: n1,n2,single_ray,sigma(<0:none) */
-    TRC_OPT_REFLECTIVE_SPECTRAL = 8,    /* Reflective_spectral     :178-193   extra: n*(lambda,absorptance) */
-    TRC_OPT_KIND_COUNT = 9
+    TRC_OPT_REFLECTIVE_SPECTRAL = 8,    /* Reflective_spectral     :178-193   extra: lambda[n] | absorptance[n] */
+    TRC_OPT_LAMBERTIAN_DIRECTIONAL = 9, /* Lambertian_directional_axisymmetric_piecewise :331-361
+                                           extra: theta[n] | absorptance[n] */
+    TRC_OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL = 10, /* ..._piecewise_spectral :363-391
+                                           extra: n_theta, n_lambda, theta[], lambda[], absorptance[n_theta][n_lambda] */
+    TRC_OPT_FRESNEL_CONDUCTOR = 11,     /* FresnelConductorHomogenous :1523-1558  opt: n1 ; extra: lambda[n] | n[n] | k[n] */
+    TRC_OPT_KIND_COUNT = 12
 } trc_optics_kind;
 
 /* surface flags */
@@ -134,7 +139,8 @@ typedef enum trc_source_kind {
     TRC_SRC_PILLBOX_DISK = 0,  /* disk_bundle    sources.py:175-239  p: radius,radius_in,span0,span1,ang_range */
     TRC_SRC_PILLBOX_RECT = 1,  /* rect_bundle    sources.py:241-264  p: x,y,ang_range,swap_xy */
     TRC_SRC_BUIE_DISK = 2,     /* buie_sunshape  sources.py:412-464  p: radius ; tables */
-    TRC_SRC_BUIE_RECT = 3      /* rect_buie_sunshape sources.py:466-515 p: width,height ; tables */
+    TRC_SRC_BUIE_RECT = 3,     /* rect_buie_sunshape sources.py:466-515 p: width,height ; tables */
+    TRC_SRC_PILLBOX_TRIANGLE = 4 /* triangular_bundle sources.py:544-597  center = A, rot_pos columns 0,1 = AB, AC ; p: ang_range */
 } trc_source_kind;
 
 #define TRC_BUIE_NELEM 210  /* sources.py:338 */

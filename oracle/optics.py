@@ -157,6 +157,34 @@ def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event):
         ns = ~specular
         dirs[:, ns] = lambertian_directions(nrm[:, ns], 2. * N.pi * u1[ns], u2[ns], N.pi / 2.)
         return [dict(sel=allsel, directions=dirs, energy=e * (1. - opt[0]), ref=ref.copy(), rid=rid)]
+    if opt_kind in (OPT_LAMBERTIAN_DIRECTIONAL, OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL):   # :340-361, :373-391
+        vertical = N.sum(d * nrm, axis=0) * nrm
+        thetas_in = N.arccos(N.sqrt(N.sum(vertical ** 2, axis=0)))
+        if opt_kind == OPT_LAMBERTIAN_DIRECTIONAL:
+            k = len(extra) // 2
+            ang_abss = N.interp(thetas_in, extra[:k], extra[k:])
+        else:
+            from scipy.interpolate import RegularGridInterpolator
+            nt, nl = int(extra[0]), int(extra[1])
+            ts, ls = extra[2:2 + nt], extra[2 + nt:2 + nt + nl]
+            grid = N.reshape(extra[2 + nt + nl:], (nt, nl))
+            pts = N.array([N.clip(thetas_in, ts[0], ts[-1]), N.clip(wl, ls[0], ls[-1])]).T
+            ang_abss = RegularGridInterpolator((ts, ls), grid)(pts)
+        u0, u1 = philox.uniform_pair(seed, rid, event, 0)
+        dirs = lambertian_directions(nrm, 2. * N.pi * u0, u1, N.pi / 2.)
+        return [dict(sel=allsel, directions=dirs, energy=e * (1. - ang_abss), ref=ref.copy(), rid=rid)]
+    if opt_kind == OPT_FRESNEL_CONDUCTOR:                        # :1536-1558 with optics.py:41-81
+        k = len(extra) // 3
+        m2 = N.interp(wl, extra[:k], extra[k:2 * k]) + 1j * N.interp(wl, extra[:k], extra[2 * k:])
+        theta1 = N.arccos(N.abs((nrm * d).sum(axis=0)))
+        n1 = opt[0]
+        b = (m2.real ** 2 - m2.imag ** 2 - (n1 * N.sin(theta1)) ** 2)
+        a = N.sqrt(b ** 2 + 4. * (m2.real * m2.imag) ** 2)
+        p = N.sqrt(0.5 * (a + b))
+        q = N.sqrt(0.5 * (a - b))
+        R_s = ((n1 * N.cos(theta1) - p) ** 2 + q ** 2) / ((n1 * N.cos(theta1) + p) ** 2 + q ** 2)
+        R_p = ((p - n1 * N.sin(theta1) * N.tan(theta1)) ** 2 + q ** 2) / ((p + n1 * N.sin(theta1) * N.tan(theta1)) ** 2 + q ** 2) * R_s
+        return [dict(sel=allsel, directions=reflections(d, nrm), energy=e * (R_p + R_s) / 2., ref=ref.copy(), rid=rid)]
     if opt_kind == OPT_REFRACTIVE_HOMOGENOUS:                    # :1226-1296 on :836-858
         na, nb, single, sigma = opt[0], opt[1], opt[2] != 0., opt[3]
         u0, u1 = philox.uniform_pair(seed, rid, event, 0)

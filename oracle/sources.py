@@ -101,6 +101,10 @@ def generate(src, n, seed, offset, uniforms=None):
         if p[3] != 0.:
             xs, ys = ys, xs
         loc = N.vstack((ys, xs, N.zeros(n)))
+    elif kind == SRC_PILLBOX_TRIANGLE:  # sources.py:559-568
+        sq = N.sqrt(u0)
+        loc = N.vstack((sq * (1. - u1), u1 * sq, N.zeros(n)))
+        a = pillbox_directions(2. * N.pi * u2, u3, p[0])
     else:
         tab = table_from_desc_buie(src['buie'])
         if kind == SRC_BUIE_DISK:       # sources.py:431-434

@@ -286,6 +286,21 @@ def make_optics(ref, amd, out):
     ab = N.array([0.1, 0.2, 0.15, 0.4, 0.9, 0.5, 0.3, 0.2, 0.25])
     run('reflective_spectral', oc.Reflective_spectral(ab, lam), A.Reflective_spectral(ab, lam), wavelengths=wl)
 
+    ths = N.linspace(0., N.pi / 2., 7)
+    abth = N.array([0.9, 0.88, 0.85, 0.8, 0.7, 0.5, 0.1])
+    run('lambertian_directional', oc.Lambertian_directional_axisymmetric_piecewise(ths, abth), A.Lambertian_directional_axisymmetric_piecewise(ths, abth),
+        draws=lambda: dict(xi1=N.random.uniform(low=0., high=2. * N.pi, size=H), xi2=N.random.uniform(size=H)))
+    wls = N.linspace(0.25e-6, 2.6e-6, 5)
+    grid = 0.2 + 0.7 * N.outer(N.cos(ths) ** 0.5, 1. / (1. + (wls * 1e6 - 1.) ** 2))
+    run('lambertian_directional_spectral', oc.Lambertian_directional_axisymmetric_piecewise_spectral(ths, grid, wls),
+        A.Lambertian_directional_axisymmetric_piecewise_spectral(ths, grid, wls), wavelengths=wl,
+        draws=lambda: dict(xi1=N.random.uniform(low=0., high=2. * N.pi, size=H), xi2=N.random.uniform(size=H)))
+    mlam = N.linspace(0.2e-6, 3e-6, 8)
+    mn = N.array([0.1, 0.13, 0.2, 0.4, 0.9, 1.5, 2.4, 3.6])
+    mk = N.array([2.0, 3.5, 5.0, 7.0, 9.5, 13., 18., 24.])
+    mat = A.TabulatedMaterial(mlam, mn, mk)
+    run('fresnel_conductor', oc.FresnelConductorHomogenous(1., mat), A.FresnelConductorHomogenous(1., mat), wavelengths=wl)
+
     out['n_cases'] = N.int32(len(cases))
     out['names'] = N.array(cases)
     out['frame'] = frame
@@ -379,6 +394,21 @@ def make_sources(ref, amd, out):
     r1 = N.random.uniform(size=n); th = N.random.uniform(low=0., high=2. * N.pi, size=n)
     store('disk_bundle_lambertian_noflux', b, A.disk_bundle(n, N.c_[[0., 0., 0.]], N.r_[0., 0., 1.], 1., N.pi / 2., seed=1),
           (xi1 / (2. * N.pi), xi2, r1, th / (2. * N.pi)))
+    N.random.seed(18)
+    TA, TB, TC = N.r_[0., 0., 1.], N.r_[2., 0.5, 1.2], N.r_[0.3, 1.5, 0.7]
+    b = S.triangular_bundle(n, TA, TB, TC, ang_range=0.3, flux=500.)
+    N.random.seed(18)
+    r1 = N.random.uniform(size=n); r2 = N.random.uniform(size=n)
+    xi1 = N.random.uniform(low=0., high=2. * N.pi, size=n); xi2 = N.random.uniform(size=n)
+    store('triangular_bundle', b, A.triangular_bundle(n, TA, TB, TC, ang_range=0.3, flux=500., seed=1), (r1, r2, xi1 / (2. * N.pi), xi2))
+    N.random.seed(19)
+    sd = N.r_[0., N.sin(0.2), -N.cos(0.2)]; rd = N.r_[N.sin(0.1), 0., -N.cos(0.1)]
+    b = S.oblique_solar_rect_bundle(n, N.c_[[1., 0., 8.]], sd, rd, 3., 2., 4.65e-3, flux=1000.)
+    N.random.seed(19)
+    xi1 = N.random.uniform(low=0., high=2. * N.pi, size=n); xi2 = N.random.uniform(size=n)
+    xs = N.random.uniform(low=-1.5, high=1.5, size=n); ys = N.random.uniform(low=-1., high=1., size=n)
+    store('oblique_solar_rect_bundle', b, A.oblique_solar_rect_bundle(n, N.c_[[1., 0., 8.]], sd, rd, 3., 2., 4.65e-3, flux=1000., seed=1),
+          (xi1 / (2. * N.pi), xi2, (xs + 1.5) / 3., (ys + 1.) / 2.))
     out['n_cases'] = N.int32(len(cases))
     out['names'] = N.array(cases)
     print('sources: %d cases' % len(cases))

@@ -145,7 +145,7 @@ def test_optics_vs_reference_and_oracle(ctx):
         kind, opt, extra, ref_in = int(o[pre + 'kind']), list(o[pre + 'opt']), o[pre + 'extra'], o[pre + 'ref_in']
         dirs, en, par, ref, rid = optics_apply(ctx, kind, opt, extra, frame, d, e, ref_in, wl, nrm, pts, 4242, 3)
         if name in ('transparent', 'reflective', 'one_sided_reflective', 'real_reflective_sigma0', 'reflective_spectral',
-                    'refractive_split'):
+                    'refractive_split', 'fresnel_conductor'):
             assert N.array_equal(par, o[pre + 'out_parents']), name
             assert N.allclose(dirs, o[pre + 'out_dirs'], rtol=RT, atol=1e-9), name
             assert N.allclose(en, o[pre + 'out_energy'], rtol=RT, atol=1e-12), name

@@ -60,7 +60,7 @@ def test_optics_variate_replay():
     # deterministic kinds go through shade() itself
     rid = N.arange(H, dtype=N.uint64)
     for name in ('transparent', 'reflective', 'one_sided_reflective', 'real_reflective_sigma0', 'reflective_spectral',
-                 'refractive_split'):
+                 'refractive_split', 'fresnel_conductor'):
         pre = _optics_case(o, name)
         blocks = optics.shade(int(o[pre + 'kind']), list(o[pre + 'opt']), o[pre + 'extra'], up, d, e, o[pre + 'ref_in'], wl, nrm, 1, rid, 1)
         dirs = N.hstack([b['directions'] for b in blocks])
@@ -87,6 +87,12 @@ def test_optics_variate_replay():
         pre = _optics_case(o, name)
         dirs = optics.lambertian_directions(nrm, o[pre + 'draw_xi1'], o[pre + 'draw_xi2'], o[pre + 'opt'][1])
         check(pre, dirs, e * (1. - o[pre + 'opt'][0]), N.arange(H))
+    # angle-dependent absorptance: energies are deterministic, directions replay the Lambertian draws
+    for name in ('lambertian_directional', 'lambertian_directional_spectral'):
+        pre = _optics_case(o, name)
+        blocks = optics.shade(int(o[pre + 'kind']), list(o[pre + 'opt']), o[pre + 'extra'], up, d, e, o[pre + 'ref_in'], wl, nrm, 1, rid, 1)
+        dirs = optics.lambertian_directions(nrm, o[pre + 'draw_xi1'], o[pre + 'draw_xi2'], N.pi / 2.)
+        check(pre, dirs, blocks[0]['energy'], N.arange(H))
     pre = _optics_case(o, 'lambertian_specular')
     spec = o[pre + 'draw_u'] < o[pre + 'opt'][1]
     dirs = N.zeros((3, H))

@@ -33,10 +33,11 @@ SURF_CAPTURE_HITS = 0x1
 # enum trc_optics_kind
 (OPT_TRANSPARENT, OPT_REFLECTIVE, OPT_ONE_SIDED_REFLECTIVE, OPT_REAL_REFLECTIVE,
  OPT_ONE_SIDED_REAL_REFLECTIVE, OPT_LAMBERTIAN, OPT_LAMBERTIAN_SPECULAR, OPT_REFRACTIVE_HOMOGENOUS,
- OPT_REFLECTIVE_SPECTRAL) = range(9)
+ OPT_REFLECTIVE_SPECTRAL, OPT_LAMBERTIAN_DIRECTIONAL, OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL,
+ OPT_FRESNEL_CONDUCTOR) = range(12)
 
 # enum trc_source_kind
-SRC_PILLBOX_DISK, SRC_PILLBOX_RECT, SRC_BUIE_DISK, SRC_BUIE_RECT = range(4)
+SRC_PILLBOX_DISK, SRC_PILLBOX_RECT, SRC_BUIE_DISK, SRC_BUIE_RECT, SRC_PILLBOX_TRIANGLE = range(5)
 
 _p_f64 = C.POINTER(C.c_double)
 _p_i64 = C.POINTER(C.c_int64)

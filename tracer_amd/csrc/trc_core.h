@@ -846,6 +846,42 @@ TRC_HD double trc_interp(const double *tab, int n, double x) {
     return slope * (x - xs[lo]) + ys[lo];
 }
 
+// RegularGridInterpolator (linear) on a (theta, lambda) grid, arguments clamped to the grid
+// tab: n_theta, n_lambda, theta[n_theta], lambda[n_lambda], value[n_theta][n_lambda]
+TRC_HD int trc_grid_cell(const double *xs, int n, double x, double *w) {
+    if (!(x > xs[0])) { *w = 0.0; return 0; }
+    if (x >= xs[n - 1]) { *w = 1.0; return n - 2; }
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (xs[mid] <= x) lo = mid; else hi = mid;
+    }
+    *w = (x - xs[lo]) / (xs[lo + 1] - xs[lo]);
+    return lo;
+}
+TRC_HD double trc_interp2(const double *tab, double th, double lam) {
+    int nt = (int)tab[0], nl = (int)tab[1];
+    const double *ts = tab + 2, *ls = ts + nt, *v = ls + nl;
+    double wt, wlam;
+    int it = trc_grid_cell(ts, nt, th, &wt), il = trc_grid_cell(ls, nl, lam, &wlam);
+    double v00 = v[it * nl + il], v01 = v[it * nl + il + 1], v10 = v[(it + 1) * nl + il], v11 = v[(it + 1) * nl + il + 1];
+    return (1.0 - wt) * ((1.0 - wlam) * v00 + wlam * v01) + wt * ((1.0 - wlam) * v10 + wlam * v11);
+}
+
+// reflectance of an absorbing medium, optics.py:63-81 (fresnel_to_attenuating), unpolarised mean
+TRC_HD double trc_fresnel_conductor(double cos_abs, double n1, double n2, double k2) {
+    double th = acos(cos_abs);
+    double sn = n1 * sin(th);
+    double b = n2 * n2 - k2 * k2 - sn * sn;
+    double a = sqrt(b * b + 4.0 * (n2 * k2) * (n2 * k2));
+    double p = sqrt(0.5 * (a + b)), q = sqrt(0.5 * (a - b));
+    double c = n1 * cos(th);
+    double rs = ((c - p) * (c - p) + q * q) / ((c + p) * (c + p) + q * q);
+    double st = sn * tan(th);
+    double rp = ((p - st) * (p - st) + q * q) / ((p + st) * (p + st) + q * q) * rs;
+    return (rp + rs) / 2.0;
+}
+
 // optics(geometry, rays, selector) for one hit.
 //   opt_kind / opt[8]: trc_surface_desc;  (ux,uy,uz): GeometryManager.up() = frame z axis;
 //   (dx..), e, ref, wl: incident ray;  (nx..): oriented normal from trc_normal.
@@ -917,6 +953,36 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
             trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
         }
         out[0].e = e * (1.0 - opt[0]);
+        return 1;
+    }
+    case TRC_OPT_LAMBERTIAN_DIRECTIONAL:
+    case TRC_OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL: {                 // :340-361, :373-391
+        double dn = dx * nx + dy * ny + dz * nz;
+        double wx = dn * nx, wy = dn * ny, wz = dn * nz;             // "vertical" component of the incident direction
+        double th = acos(sqrt(wx * wx + wy * wy + wz * wz));
+        double ab = (opt_kind == TRC_OPT_LAMBERTIAN_DIRECTIONAL) ? trc_interp(extra + extra_off, extra_len / 2, th)
+                                                                  : trc_interp2(extra + extra_off, th, wl);
+        double u0, u1, ax, ay, az;
+        trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
+        trc_pillbox_dir(TRC_TWO_PI * u0, u1, 1.57079632679489661923, &ax, &ay, &az);
+        trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
+        out[0].e = e * (1.0 - ab);
+        return 1;
+    }
+    case TRC_OPT_FRESNEL_CONDUCTOR: {                               // :1536-1558
+        int n = extra_len / 3;
+        const double *tab = extra + extra_off;
+        double n2, k2;
+        {   // interp1d of the complex index: linear in n and k separately
+            const double *xs = tab;
+            double w;
+            int i = trc_grid_cell(xs, n, wl, &w);
+            n2 = (1.0 - w) * tab[n + i] + w * tab[n + i + 1];
+            k2 = (1.0 - w) * tab[2 * n + i] + w * tab[2 * n + i + 1];
+        }
+        double R = trc_fresnel_conductor(fabs(dx * nx + dy * ny + dz * nz), opt[0], n2, k2);
+        trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);
+        out[0].e = e * R;
         return 1;
     }
     case TRC_OPT_REFRACTIVE_HOMOGENOUS: {                           // :1226-1296 on :836-858
@@ -1029,6 +1095,12 @@ TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint6
         double th = trc_buie_theta(buie, u2), xi = TRC_TWO_PI * u3;
         double st = sin(th);
         ax = cos(xi) * st; ay = sin(xi) * st; az = cos(th);
+        break;
+    }
+    case TRC_SRC_PILLBOX_TRIANGLE: {    // draws: r1, r2 (point picking), dir phi, dir R (sources.py:559-568)
+        double sq = sqrt(u0);
+        lx = sq * (1.0 - u1); ly = u1 * sq;     // A + sqrt(r1)(1-r2) AB + r2 sqrt(r1) AC; AB, AC are the columns of rot_pos
+        trc_pillbox_dir(TRC_TWO_PI * u2, u3, p[0], &ax, &ay, &az);
         break;
     }
     default: {                          // TRC_SRC_BUIE_RECT (sources.py:485-486)

@@ -1184,11 +1184,13 @@ static int validate_surface(const trc_surface_desc &s, int idx, int n_extra) {
         return trc_fail(TRC_ERR_UNSUPPORTED, "surface %d: geometry kind %d is not in the native table", idx, s.gm_kind);
     if (s.optics_kind < 0 || s.optics_kind >= TRC_OPT_KIND_COUNT)
         return trc_fail(TRC_ERR_UNSUPPORTED, "surface %d: optics kind %d is not in the native table", idx, s.optics_kind);
-    bool needs_extra = s.gm_kind == TRC_GM_RECT_PERFORATED || s.optics_kind == TRC_OPT_REFLECTIVE_SPECTRAL;
+    bool opt_table = s.optics_kind == TRC_OPT_REFLECTIVE_SPECTRAL || s.optics_kind == TRC_OPT_LAMBERTIAN_DIRECTIONAL ||
+                     s.optics_kind == TRC_OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL || s.optics_kind == TRC_OPT_FRESNEL_CONDUCTOR;
+    bool needs_extra = s.gm_kind == TRC_GM_RECT_PERFORATED || opt_table;
     if (needs_extra && (s.extra_off < 0 || s.extra_len <= 0 || s.extra_off + s.extra_len > n_extra))
         return trc_fail(TRC_ERR_INVALID, "surface %d: extra range [%d,+%d) outside the %d extra values", idx,
                         s.extra_off, s.extra_len, n_extra);
-    if (s.gm_kind == TRC_GM_RECT_PERFORATED && s.optics_kind == TRC_OPT_REFLECTIVE_SPECTRAL)
+    if (s.gm_kind == TRC_GM_RECT_PERFORATED && opt_table)
         return trc_fail(TRC_ERR_UNSUPPORTED, "surface %d: perforated plate with spectral optics shares one extra range", idx);
     // reference argument checks (flat_surface.py:192-195, :470-480; sphere_surface.py:31-32; cone.py:82-83)
     const double *g = s.gm;
@@ -1596,7 +1598,7 @@ static int stage_rays(const trc_rays *r, int64_t n, bool need_energy, DevRays *d
 }
 
 static int upload_source(const trc_source_desc *src, trc_source_desc **d_src) {
-    if (src->kind < TRC_SRC_PILLBOX_DISK || src->kind > TRC_SRC_BUIE_RECT)
+    if (src->kind < TRC_SRC_PILLBOX_DISK || src->kind > TRC_SRC_PILLBOX_TRIANGLE)
         return trc_fail(TRC_ERR_UNSUPPORTED, "source kind %d is not in the native table", src->kind);
     TRC_TRY(dev_alloc(d_src, 1));
     HIP_TRY(hipMemcpy(*d_src, src, sizeof(trc_source_desc), hipMemcpyHostToDevice));

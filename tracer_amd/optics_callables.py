@@ -157,6 +157,66 @@ class Reflective_spectral(NativeOptics):
         return _cabi.OPT_REFLECTIVE_SPECTRAL, [], N.concatenate((lam, ab)).tolist()
 
 
+class Lambertian_directional_axisymmetric_piecewise(NativeOptics):
+    """Lambertian reflector whose absorptance depends on the incidence angle, piecewise linear
+    (optics_callables.py:331-361)."""
+    def __init__(self, thetas, absorptance_th, specularity=0.):
+        self.thetas = thetas
+        self.abs_th = absorptance_th
+        self.specularity = specularity
+
+    def _native(self):
+        th = N.ravel(N.asarray(self.thetas, dtype=float))
+        ab = N.ravel(N.asarray(self.abs_th, dtype=float))
+        return _cabi.OPT_LAMBERTIAN_DIRECTIONAL, [], N.concatenate((th, ab)).tolist()
+
+
+class Lambertian_directional_axisymmetric_piecewise_spectral(NativeOptics):
+    """Same with absorptance tabulated on (incidence angle, wavelength), bilinear (optics_callables.py:363-391).
+    Arguments outside the table are clamped to its edge (the reference's RegularGridInterpolator raises)."""
+    def __init__(self, thetas, absorptance, wavelengths):
+        self._thetas, self._wavelengths = N.unique(thetas), N.unique(wavelengths)
+        self._abs = N.reshape(absorptance, (len(self._thetas), len(self._wavelengths)))
+
+    def _native(self):
+        tab = N.concatenate(([len(self._thetas), len(self._wavelengths)], self._thetas, self._wavelengths, N.ravel(self._abs)))
+        return _cabi.OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL, [], tab.tolist()
+
+
+class TabulatedMaterial(object):
+    """Complex refractive index m = n + i k tabulated over wavelength, linear in between (what the reference's
+    ray_trace_utils.optical_constants materials do with interp1d)."""
+    def __init__(self, wavelengths, n, k):
+        self.wavelengths = N.asarray(wavelengths, dtype=float)
+        self.n = N.asarray(n, dtype=float)
+        self.k = N.asarray(k, dtype=float)
+
+    def m(self, lambdas):
+        return N.interp(lambdas, self.wavelengths, self.n) + 1j * N.interp(lambdas, self.wavelengths, self.k)
+
+    def table(self):
+        return self.wavelengths, self.n, self.k
+
+
+class FresnelConductorHomogenous(NativeOptics):
+    """Mirror-like interface to an absorbing medium (metal): unpolarised Fresnel reflectance from the complex index
+    material.m(lambda) (optics_callables.py:1523-1558).  The material must expose its table: a TabulatedMaterial, or
+    an object holding a scipy interp1d in `m_func` like the reference's OpticalMaterialFromFile."""
+    def __init__(self, n1, material):
+        self._n1 = n1
+        self._material = material
+
+    def _native(self):
+        mat = self._material
+        if hasattr(mat, 'table'):
+            lam, n, k = mat.table()
+        elif hasattr(mat, 'm_func') and hasattr(mat.m_func, 'x'):
+            lam, n, k = mat.m_func.x, N.real(mat.m_func.y), N.imag(mat.m_func.y)
+        else:
+            raise NotImplementedError("FresnelConductorHomogenous needs a tabulated material")
+        return _cabi.OPT_FRESNEL_CONDUCTOR, [self._n1], N.concatenate((N.ravel(lam), N.ravel(n), N.ravel(k))).tolist()
+
+
 class RefractiveHomogenous(NativeOptics):
     """
     Interface between two homogeneous media of real indices n1, n2 (optics_callables.py:1186-1296):

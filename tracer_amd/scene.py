@@ -43,7 +43,10 @@ class CompiledScene(object):
             if nat is None:
                 raise NotNativeError("surface %d: optics %s is not in the native table" % (i, type(opt).__name__))
             gkind, gpar, gextra = gm._native()
-            okind, opar, oextra = nat._native()
+            try:
+                okind, opar, oextra = nat._native()
+            except NotImplementedError as err:
+                raise NotNativeError("surface %d: %s" % (i, err))
             if len(gextra) and len(oextra):
                 raise NotNativeError("surface %d: both geometry and optics carry tables" % i)
             ex = list(gextra) if len(gextra) else list(oextra)

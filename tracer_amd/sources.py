@@ -24,8 +24,9 @@ class LazySourceBundle(RayBundle):
     ray_offset + i.  Any column access generates the rays on the device; an engine that receives an
     untouched LazySourceBundle generates them inside its own kernel instead.
     """
-    def __init__(self, desc, n, seed, ray_offset=0):
-        RayBundle.__init__(self)
+    def __init__(self, desc, n, seed, ray_offset=0, constant_columns=None):
+        RayBundle.__init__(self, **dict((k, None) for k in (constant_columns or {})))
+        object.__setattr__(self, '_src_const', dict(constant_columns or {}))
         object.__setattr__(self, '_src_desc', desc)
         object.__setattr__(self, '_src_n', int(n))
         object.__setattr__(self, '_src_seed', int(seed))
@@ -33,7 +34,8 @@ class LazySourceBundle(RayBundle):
         object.__setattr__(self, '_src_done', False)
 
     def is_pending(self):
-        return not self._src_done
+        # bundles carrying extra per-ray columns (wavelength, ref_index) are materialised before tracing
+        return not self._src_done and not self._src_const
 
     def get_num_rays(self):
         if not self._src_done:
@@ -58,6 +60,8 @@ class LazySourceBundle(RayBundle):
         self._cols['vertices'] = v
         self._cols['directions'] = d
         self._cols['energy'] = e
+        for k, val in self._src_const.items():
+            self._cols[k] = N.ones(n) * val
 
 
 def _fill_source(kind, center, rot_pos, rot_dir, params, energy, buie=None):
@@ -80,10 +84,10 @@ def _fill_source(kind, center, rot_pos, rot_dir, params, energy, buie=None):
     return s
 
 
-def _new_bundle(desc, num_rays, seed, ray_offset):
+def _new_bundle(desc, num_rays, seed, ray_offset, constant_columns=None):
     if seed is None:
         seed = rng.next_seed()
-    return LazySourceBundle(desc, int(num_rays), seed, ray_offset)
+    return LazySourceBundle(desc, int(num_rays), seed, ray_offset, constant_columns)
 
 
 def _tilt_cos(rays_direction, direction):
@@ -121,6 +125,67 @@ def rect_bundle(num_rays, center, direction, x, y, ang_range, flux=None, procs=1
     rot = rotation_to_z(direction)
     desc = _fill_source(_cabi.SRC_PILLBOX_RECT, center, rot, rot, [x, y, ang_range, 1. if swap else 0.], energy)
     return _new_bundle(desc, num_rays, seed, ray_offset)
+
+
+def oblique_solar_rect_bundle(num_rays, center, source_direction, rays_direction, x, y, ang_range, flux=None, procs=1,
+                              wavelength=None, ref_index=None, seed=None, ray_offset=0):
+    """Pillbox rays about `rays_direction` leaving an x by y rectangle normal to `source_direction`
+    (sources.py:268-302); optional constant wavelength / ref_index columns."""
+    source_direction = N.asarray(source_direction, dtype=float)
+    rays_direction = N.asarray(rays_direction, dtype=float)
+    swap = bool((source_direction == N.array([0, 0, -1])).all())
+    if flux is not None:
+        cosangle = 2. * N.arcsin(0.5 * N.sqrt(N.sum((rays_direction - source_direction) ** 2)))
+        energy = x * y / num_rays * flux * N.cos(cosangle)
+    else:
+        energy = 1. / float(num_rays) / procs
+    desc = _fill_source(_cabi.SRC_PILLBOX_RECT, center, rotation_to_z(source_direction), rotation_to_z(rays_direction),
+                        [x, y, ang_range, 1. if swap else 0.], energy)
+    const = {}
+    if wavelength is not None:
+        const['wavelengths'] = wavelength
+    if ref_index is not None:
+        const['ref_index'] = ref_index
+    return _new_bundle(desc, num_rays, seed, ray_offset, const)
+
+
+def triangular_bundle(num_rays, A, B, C, direction=None, ang_range=N.pi / 2., flux=None, procs=1, seed=None, ray_offset=0):
+    """Pillbox rays leaving the triangle ABC (uniform point picking), about `direction` (default: the triangle
+    normal AB x AC) -- sources.py:544-597."""
+    A, B, C = [N.ravel(N.asarray(q, dtype=float)) for q in (A, B, C)]
+    AB, AC = B - A, C - A
+    normal = N.cross(AB, AC)
+    normal = normal / N.sqrt(N.sum(normal ** 2))
+    if direction is None:
+        direction = normal
+    direction = N.ravel(N.asarray(direction, dtype=float))
+    l1, l2, l3 = N.sqrt(N.sum(AB ** 2)), N.sqrt(N.sum(AC ** 2)), N.sqrt(N.sum((-AB + AC) ** 2))
+    sp = (l1 + l2 + l3) / 2.
+    area = N.sqrt(sp * (sp - l1) * (sp - l2) * (sp - l3))
+    if flux is not None:
+        cosangle = 2. * N.arcsin(0.5 * N.sqrt(N.sum((direction - normal) ** 2)))
+        energy = area / num_rays * flux * N.cos(cosangle)
+    else:
+        energy = 1. / float(num_rays) / procs
+    rot_pos = N.zeros((3, 3))
+    rot_pos[:, 0] = AB
+    rot_pos[:, 1] = AC
+    desc = _fill_source(_cabi.SRC_PILLBOX_TRIANGLE, A, rot_pos, rotation_to_z(direction), [ang_range], energy)
+    return _new_bundle(desc, num_rays, seed, ray_offset)
+
+
+def regular_square_bundle(num_rays, center, direction, width):
+    """Parallel rays on a regular square grid of half-width `width` normal to `direction` (sources.py:518-542);
+    deterministic, no energy column -- built on the host."""
+    direction = N.asarray(direction, dtype=float)
+    rot = rotation_to_z(direction)
+    rng_ = N.s_[-width:width:float(2 * width) / N.sqrt(num_rays)]
+    xs, ys = N.mgrid[rng_, rng_]
+    local = N.array([xs.flatten(), ys.flatten(), N.zeros(len(xs.flatten()))])
+    rayb = RayBundle()
+    rayb.set_vertices(N.dot(rot, local) + center)
+    rayb.set_directions(N.tile(direction[:, None], (1, local.shape[1])))
+    return rayb
 
 
 def solar_disk_bundle(num_rays, center, direction, radius, ang_range, flux=None, radius_in=0., angular_span=[0., 2. * N.pi],
