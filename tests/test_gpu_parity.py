@@ -379,3 +379,39 @@ def test_full_size_properties(ctx):
     frac_ref, frac_se = mc['nsttf_bounce_fractions_mean'], mc['nsttf_bounce_fractions_se']
     frac = N.array([h1[:218].sum() / n, h1[218] / n])
     assert N.all(N.abs(frac - frac_ref) <= 4. * N.sqrt(frac_se ** 2 + frac * (1 - frac) / n)), (frac, frac_ref)
+
+
+def test_mc_scenes_vs_reference_runs(ctx):
+    """
+    configs[1] (dish + Buie sunshape + radial slope error) and configs[0] (flat mirror, bi-variate slope error,
+    pillbox source, Lambertian receiver) against the reference's own Monte-Carlo runs (tests/golden/mc_reference.npz):
+    receiver power and focal-spot second moments within 3 sigma of the combined standard errors.
+    """
+    from tracer_amd import scenes
+    from tracer_amd.tracer_engine import TracerEngine
+    mc = load('mc_reference.npz')
+    # dish, 1e7 rays (the size of configs[1])
+    n = 10 ** 7
+    asm, dish_s, rec_s, src = scenes.dish()
+    eng = TracerEngine(asm)
+    eng.ray_tracer(scenes.dish_source(n, src, seed=77), reps=10, min_energy=1e-10, tree=False, seed=77, hit_capacity=n + 1024)
+    a, r, h = eng.get_tallies()
+    en = rec_s.get_optics_manager().get_all_hits()[0]
+    assert len(en) == h[1] and N.isclose(en.sum(), a[1], rtol=1e-9)
+    se_gpu = N.sqrt(N.sum(en ** 2) * (1. - h[1] / float(n)))          # binomial thinning of n equal-energy rays
+    assert abs(a[1] - mc['dish_receiver_mean']) <= 3. * N.sqrt(se_gpu ** 2 + mc['dish_receiver_se'] ** 2), (a[1], float(mc['dish_receiver_mean']))
+    assert N.isclose(a[0], 0.06 * r[0], rtol=1e-9)                       # the dish absorbs 6 % of what it receives
+    # flat pair, 1e6 rays: power and rms spot size on the receiver (slope error + sunshape broadening)
+    n = 10 ** 6
+    asm, mirror, rec, src = scenes.flat_pair()
+    eng = TracerEngine(asm)
+    eng.ray_tracer(scenes.flat_pair_source(n, src, seed=5), reps=10, min_energy=1e-10, tree=False, seed=5, hit_capacity=n + 1024)
+    en, pts = rec.get_optics_manager().get_all_hits()
+    loc = rec.global_to_local(pts)
+    got = N.array([en.sum(), N.sqrt(N.mean(loc[0] ** 2)), N.sqrt(N.mean(loc[1] ** 2))])
+    ref, se = mc['flat_receiver_mean'], mc['flat_receiver_se']
+    # standard errors of this run: power from the hit list; rms from the fourth moment
+    k = len(en)
+    se_run = N.array([N.sqrt(N.sum(en ** 2) * (1. - k / float(n))),
+                      N.sqrt(N.var(loc[0] ** 2) / k) / (2. * got[1]), N.sqrt(N.var(loc[1] ** 2) / k) / (2. * got[2])])
+    assert N.all(N.abs(got - ref) <= 3. * N.sqrt(se ** 2 + se_run ** 2)), (got, ref, se, se_run)

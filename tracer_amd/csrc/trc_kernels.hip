@@ -304,14 +304,12 @@ struct FastParams {
 #define COOP_E 128           // exact-test queue entries per wave
 #define COOP_MAX_NODES 16384 // stack entries are 4 bytes: node (14 bits) | axis code (2 bits) | interval end (16 bits)
 #define COOP_MAX_DEPTH 24
-#define COOP_FIXED_BYTES (6 * 64 * 8 + COOP_E * 8 + 64 * 8 + 6 * 64 * 4 + COOP_E * 4 + 64 * 4 + 64 * 4 + 64 * 4 + COOP_LEAFCAP * 64 * 2)
+#define COOP_FIXED_BYTES (COOP_E * 8 + 64 * 8 + COOP_E * 4 + 64 * 4 + 64 * 4 + 64 * 4 + COOP_LEAFCAP * 64 * 2)
 #define COOP_WAVE_BYTES(DEPTH) ((size_t)(DEPTH) * 64 * 4 + COOP_FIXED_BYTES)
 
 struct CoopLds {
-    double *rd;                   // [6][64]  ray origin / direction, float64
     double *exq_t;                // [COOP_E]
     unsigned long long *best_t;   // [64]
-    float *rf;                    // [6][64]  relative origin / inverse direction, float32
     uint32_t *exq;                // [COOP_E]
     int *best_s;                  // [64]
     int *dirty;                   // [64]
@@ -322,10 +320,8 @@ struct CoopLds {
 
 __device__ __forceinline__ CoopLds coop_carve(char *base) {
     CoopLds W;
-    W.rd = (double *)base; base += 6 * 64 * 8;
     W.exq_t = (double *)base; base += COOP_E * 8;
     W.best_t = (unsigned long long *)base; base += 64 * 8;
-    W.rf = (float *)base; base += 6 * 64 * 4;
     W.exq = (uint32_t *)base; base += COOP_E * 4;
     W.best_s = (int *)base; base += 64 * 4;
     W.dirty = (int *)base; base += 64 * 4;
@@ -343,18 +339,26 @@ __device__ __forceinline__ CoopLds coop_carve(char *base) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
     } while (0)
 
+// the float64 ray of every lane, kept in the owner's registers and read by other lanes with cross-lane shuffles
+struct CoopRay {
+    double px, py, pz, dx, dy, dz;
+};
+
 // drain the exact-test queue (wave-uniform call)
-__device__ __forceinline__ void coop_drain_exact(const CoopLds &W, int ecount, const double *recs, int stride,
+__device__ __forceinline__ void coop_drain_exact(const CoopLds &W, int ecount, const CoopRay &ray, const double *recs, int stride,
                                                  const double *extra, unsigned lane) {
     if (ecount == 0) return;
     WAVE_SYNC();
     for (int base = 0; base < ecount; base += 64) {
         int i = base + (int)lane;
-        if (i < ecount) {
-            uint32_t en = W.exq[i];
-            int L = (int)(en >> 16), sidx = (int)(en & 0xFFFFu);
-            double t = trc_intersect(recs + (size_t)sidx * stride, extra, W.rd[L], W.rd[64 + L], W.rd[128 + L], W.rd[192 + L],
-                                     W.rd[256 + L], W.rd[320 + L]);
+        const bool valid = i < ecount;
+        uint32_t en = valid ? W.exq[i] : 0u;
+        int L = (int)(en >> 16), sidx = (int)(en & 0xFFFFu);
+        // all lanes shuffle (the source lane must be active), only the valid ones compute
+        double qx = __shfl(ray.px, L, 64), qy = __shfl(ray.py, L, 64), qz = __shfl(ray.pz, L, 64);
+        double ex = __shfl(ray.dx, L, 64), ey = __shfl(ray.dy, L, 64), ez = __shfl(ray.dz, L, 64);
+        if (valid) {
+            double t = trc_intersect(recs + (size_t)sidx * stride, extra, qx, qy, qz, ex, ey, ez);
             if (!(t > 0.0) || !(t < TRC_INF)) t = TRC_INF;    // t == 0 is not a hit (tracer_engine.py:58)
             W.exq_t[i] = t;
             if (t < TRC_INF) {
@@ -382,19 +386,20 @@ __device__ __forceinline__ void coop_drain_exact(const CoopLds &W, int ecount, c
 }
 
 // append (ray lane, surface) to the exact queue for the lanes whose `want` is set (wave-uniform call)
-__device__ __forceinline__ void coop_push_exact(const CoopLds &W, int &ecount, bool want, uint32_t entry, const double *recs,
-                                                int stride, const double *extra, unsigned lane) {
+__device__ __forceinline__ void coop_push_exact(const CoopLds &W, int &ecount, bool want, uint32_t entry, const CoopRay &ray,
+                                                const double *recs, int stride, const double *extra, unsigned lane) {
     unsigned long long m = __ballot(want);
     if (!m) return;
     int add = __popcll(m);
-    if (ecount + add > COOP_E) { coop_drain_exact(W, ecount, recs, stride, extra, lane); ecount = 0; }
+    if (ecount + add > COOP_E) { coop_drain_exact(W, ecount, ray, recs, stride, extra, lane); ecount = 0; }
     if (want) W.exq[ecount + __popcll(m & ((1ull << lane) - 1ull))] = entry;
     ecount += add;
 }
 
 // drain the per-lane leaf lists: items (ray lane, leaf) are dealt to the 64 lanes round by round (wave-uniform call)
 __device__ __forceinline__ void coop_drain_leaves(const trc_accel_view &A, const CoopLds &W, unsigned cnt, int &ecount,
-                                                  const double *recs, int stride, const double *extra, unsigned lane) {
+                                                  const trc_ray32 &mine, const CoopRay &ray, const double *recs, int stride,
+                                                  const double *extra, unsigned lane) {
     // inclusive prefix sum of the list lengths
     unsigned incl = cnt;
 #pragma unroll
@@ -424,9 +429,9 @@ __device__ __forceinline__ void coop_drain_leaves(const trc_accel_view &A, const
             unsigned node = W.lst[j * 64 + L];
             off = A.nodes[2 * node];
             lc = A.nodes[2 * node + 1] >> 2;
-            r.ox = W.rf[L]; r.oy = W.rf[64 + L]; r.oz = W.rf[128 + L];
-            r.ix = W.rf[192 + L]; r.iy = W.rf[256 + L]; r.iz = W.rf[320 + L];
         }
+        r.ox = __shfl(mine.ox, (int)L, 64); r.oy = __shfl(mine.oy, (int)L, 64); r.oz = __shfl(mine.oz, (int)L, 64);
+        r.ix = __shfl(mine.ix, (int)L, 64); r.iy = __shfl(mine.iy, (int)L, 64); r.iz = __shfl(mine.iz, (int)L, 64);
         // box tests of the leaf's surfaces, four at a time (independent LDS loads in flight), hits kept as a bit mask;
         // the wave-level queue append happens once per round, for the (rare) set bits
         for (unsigned kb = 0; __ballot(kb < lc); kb += 32) {        // the hit mask holds 32 surfaces at a time
@@ -445,7 +450,7 @@ __device__ __forceinline__ void coop_drain_leaves(const trc_accel_view &A, const
                 bool want = hits != 0;
                 unsigned k = want ? kb + (unsigned)__ffs((int)hits) - 1u : 0u;
                 unsigned sidx = want ? (unsigned)A.leaf_surfs[off + k] : 0u;
-                coop_push_exact(W, ecount, want, (L << 16) | sidx, recs, stride, extra, lane);
+                coop_push_exact(W, ecount, want, (L << 16) | sidx, ray, recs, stride, extra, lane);
                 hits &= hits - 1u;
             }
         }
@@ -758,10 +763,8 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
         W.best_t[lane] = (unsigned long long)__double_as_longlong(TRC_INF);
         W.best_s[lane] = 0x7FFFFFFF;
         W.dirty[lane] = 0;
-        W.rd[lane] = px; W.rd[64 + lane] = py; W.rd[128 + lane] = pz;
-        W.rd[192 + lane] = dx; W.rd[256 + lane] = dy; W.rd[320 + lane] = dz;
-        W.rf[lane] = r.ox; W.rf[64 + lane] = r.oy; W.rf[128 + lane] = r.oz;
-        W.rf[192 + lane] = r.ix; W.rf[256 + lane] = r.iy; W.rf[320 + lane] = r.iz;
+        CoopRay ray;
+        ray.px = px; ray.py = py; ray.pz = pz; ray.dx = dx; ray.dy = dy; ray.dz = dz;
         int ecount = 0;   // wave-uniform
         const uint32_t me = (uint32_t)lane << 16;
         const bool searching = alive && prepared && in;
@@ -772,14 +775,16 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
                     const float *b = A.sbox + 6 * (size_t)A.always[k];
                     hit = hit && !(b[3] == TRC_INF && b[0] == -TRC_INF) && trc_box_hit32(b, r);
                 }
-                coop_push_exact(W, ecount, hit, me | (uint32_t)A.always[k], recs, stride, extra, lane);
+                coop_push_exact(W, ecount, hit, me | (uint32_t)A.always[k], ray, recs, stride, extra, lane);
             }
-            bool walk = searching && walking;
+            bool walk = searching && walking && !(P.flags & 0x100);   // 0x100, 0x200: timing experiments only
             uint32_t node = 0;
             int sp = 0;
             unsigned cnt = 0;     // leaves listed since the last drain
             while (__ballot(walk)) {
-                if (walk) {
+                // up to four steps of this lane's walk per wave-level iteration (amortises the loop's wave-level checks)
+#pragma unroll 1
+                for (int rep = 0; rep < 4 && walk && cnt < COOP_LEAFCAP; ++rep) {
                     uint32_t w0 = A.nodes[2 * node], w1 = A.nodes[2 * node + 1];
                     if ((w1 & 3u) != 3u) {
                         bool push;
@@ -808,13 +813,13 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
                     }
                 }
                 if (__ballot(cnt >= COOP_LEAFCAP)) {    // some lane's list is full: everybody drains
-                    coop_drain_leaves(A, W, cnt, ecount, recs, stride, extra, lane);
+                    if (!(P.flags & 0x200)) coop_drain_leaves(A, W, cnt, ecount, r, ray, recs, stride, extra, lane);
                     cnt = 0;
                 }
             }
-            coop_drain_leaves(A, W, cnt, ecount, recs, stride, extra, lane);
+            if (!(P.flags & 0x200)) coop_drain_leaves(A, W, cnt, ecount, r, ray, recs, stride, extra, lane);
         }
-        coop_drain_exact(W, ecount, recs, stride, extra, lane);
+        coop_drain_exact(W, ecount, ray, recs, stride, extra, lane);
 
         // ================= per lane: result of the segment, shading =================
         if (alive) {
@@ -1673,7 +1678,7 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         bool m32 = sc->accel_ok && !mode_env && S <= 65535 &&
                    (!accel || (sc->accel_kd_ok && sc->kd_nodes <= COOP_MAX_NODES && sc->accel.kd_depth <= COOP_MAX_DEPTH));
         int threads = 512;
-        if (threads_env == 256 || threads_env == 512 || threads_env == 1024) threads = threads_env;
+        if (threads_env == 256 || threads_env == 512 || threads_env == 768 || threads_env == 1024) threads = threads_env;
         size_t lds = 0;
         if (m32) {
             size_t b_acc = (size_t)6 * S * 4 + (accel ? ((size_t)2 * sc->kd_nodes * 4 + (size_t)sc->kd_nalways * 4 + (size_t)sc->kd_nleaf * 2)
@@ -1682,7 +1687,7 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
             for (;;) {
                 lds = b_buie + b_tally + b_acc + (size_t)(threads / 64) * COOP_WAVE_BYTES(accel ? (sc->accel.kd_depth > 0 ? sc->accel.kd_depth : 1) : 1);
                 if (lds <= 160 * 1024 - 512 || threads == 256) break;
-                threads /= 2;
+                threads = threads == 1024 ? 768 : (threads == 768 ? 512 : 256);
             }
             if (lds > 160 * 1024 - 512) m32 = false;
             P.lds_tally = 1;
@@ -1700,7 +1705,7 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
             if (P.lds_scene) lds += b_scene;
         }
         void (*kern)(FastParams) = nullptr;
-        if (m32) kern = threads == 1024 ? k_trace_coop<1024> : (threads == 512 ? k_trace_coop<512> : k_trace_coop<256>);
+        if (m32) kern = threads == 1024 ? k_trace_coop<1024> : (threads == 768 ? k_trace_coop<768> : (threads == 512 ? k_trace_coop<512> : k_trace_coop<256>));
         else kern = k_trace_fast<256>;
         if (lds > 64 * 1024) {
             hipError_t ae = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
