@@ -263,3 +263,30 @@ def test_sources_statistics():
     b3 = sources.buie_sunshape(n, N.c_[[0., 0., 6.]], N.r_[0., 0., -1.], 2.5, 0.05, flux=1000., seed=5)
     th = N.arccos(-b3.get_directions()[2])
     assert th.max() <= 43.6e-3 + 1e-9 and 0.9 < N.mean(th < 4.65e-3) < 0.99
+
+
+def test_view_factors_of_a_cylindrical_cavity():
+    """
+    The view-factor workload of emissive_losses (configs[4]): Lambertian emission from the aperture disc of a cylinder of
+    radius 1 m, depth 2 m in two 1 m wall sections, one bounce, black receivers.  Known answers (first row of the matrix in
+    emissive_losses/emissive_losses_test.py:15-18, analytic coaxial-disc formula): [0, 0.618, 0.210, 0.172].
+    """
+    walls = [Surface(FiniteCylinder(diameter=2., height=1.), opt.Lambertian(1.)) for _ in range(2)]   # black, tallies only
+    bottom = Surface(RoundPlateGM(1.), opt.Lambertian(1.))
+    asm = Assembly(objects=[AssembledObject(surfs=[walls[0]], transform=translate(0, 0, 0.5)),
+                            AssembledObject(surfs=[walls[1]], transform=translate(0, 0, 1.5)),
+                            AssembledObject(surfs=[bottom], transform=translate(0, 0, 2.))])
+    n = 4000000
+    src = sources.disk_bundle(n, N.c_[[0., 0., 0.]], N.r_[0., 0., 1.], 1., N.pi / 2., seed=2)      # energies 1/n
+    eng = TracerEngine(asm)
+    eng.ray_tracer(src, reps=1, min_energy=1e-10, tree=False, seed=2)
+    a, r, h = eng.get_tallies()
+    def disc_to_disc(hgt):
+        X = 1. + (1. + (1. / hgt) ** 2) / (1. / hgt) ** 2
+        return 0.5 * (X - N.sqrt(X ** 2 - 4.))
+    f_bottom, f_mid = disc_to_disc(2.), disc_to_disc(1.)
+    exact = N.array([1. - f_mid, f_mid - f_bottom, f_bottom])
+    assert N.allclose(exact, [0.618, 0.210, 0.172], atol=5e-4)
+    sigma = N.sqrt(exact * (1. - exact) / n)
+    assert N.all(N.abs(a - exact) <= 4. * sigma), (a, exact)
+    assert n - 5 <= h.sum() <= n and N.isclose(a.sum(), 1., atol=2e-6)   # a ray starting on the rim can slip under the 1e-6 threshold

@@ -415,3 +415,84 @@ def test_mc_scenes_vs_reference_runs(ctx):
     se_run = N.array([N.sqrt(N.sum(en ** 2) * (1. - k / float(n))),
                       N.sqrt(N.var(loc[0] ** 2) / k) / (2. * got[1]), N.sqrt(N.var(loc[1] ** 2) / k) / (2. * got[2])])
     assert N.all(N.abs(got - ref) <= 3. * N.sqrt(se ** 2 + se_run ** 2)), (got, ref, se, se_run)
+
+
+def _cavity_scene():
+    """configs[4]-like cavity: aperture annulus, frustum, cylinder and cone walls with angle/wavelength-dependent Lambertian
+    optics, a conductor (metal) back plate and a spectrally selective mirror ring -- every table-driven optics kind"""
+    from tracer_amd import _cabi as K
+    from tracer_amd.scene import TableScene
+    from tracer_amd.spatial_geometry import rotx, translate
+    ths = N.linspace(0., N.pi / 2., 7)
+    abth = N.array([0.9, 0.88, 0.85, 0.8, 0.7, 0.5, 0.1])
+    wls = N.linspace(0.25e-6, 2.6e-6, 5)
+    grid = 0.2 + 0.7 * N.outer(N.cos(ths) ** 0.5, 1. / (1. + (wls * 1e6 - 1.) ** 2))
+    mlam = N.linspace(0.2e-6, 3e-6, 8)
+    mn = N.array([0.1, 0.13, 0.2, 0.4, 0.9, 1.5, 2.4, 3.6])
+    mk = N.array([2.0, 3.5, 5.0, 7.0, 9.5, 13., 18., 24.])
+    slam = N.linspace(0.2e-6, 3e-6, 9)
+    sab = N.array([0.1, 0.2, 0.15, 0.4, 0.9, 0.5, 0.3, 0.2, 0.25])
+    tables = [N.concatenate((ths, abth)), N.concatenate(([len(ths), len(wls)], ths, wls, grid.ravel())),
+              N.concatenate((mlam, mn, mk)), N.concatenate((slam, sab))]
+    offs = N.concatenate(([0], N.cumsum([len(t) for t in tables])))
+    extra = N.concatenate(tables)
+    #            frustum 0<z<1 (r 1 -> 1.4)   cylinder 1<z<2.5 (r 1.4)                 cone back (apex at z=3.5)                    annulus at z=0           metal ring plate           spectral mirror disc
+    gm_kind = [K.GM_FRUSTUM, K.GM_CYL_FINITE, K.GM_CONE_FINITE, K.GM_ROUND, K.GM_ROUND, K.GM_ROUND]
+    frames = [N.eye(4), translate(0, 0, 1.75), N.dot(translate(0, 0, 3.5), rotx(N.pi)), N.eye(4), translate(0, 0, 2.2), translate(0.2, 0., 1.2)]
+    gm = N.zeros((6, 16))
+    c = (1.4 - 1.0) / (1.0 - 0.0)
+    gm[0, :4] = c, (1.4 * 0. - 1.0 * 1.0) / (1.4 - 1.0), 0., 1.
+    gm[1, :4] = 1.4, 0.75, 0., 2. * N.pi
+    gm[2, :3] = 1.4 / 1.0, 0., 1.0
+    gm[3, :2] = 1.6, 1.0
+    gm[4, :2] = 0.6, 0.2
+    gm[5, :2] = 0.3, -1.
+    ok = [K.OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL, K.OPT_LAMBERTIAN_DIRECTIONAL, K.OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL, K.OPT_LAMBERTIAN,
+          K.OPT_FRESNEL_CONDUCTOR, K.OPT_REFLECTIVE_SPECTRAL]
+    opt = N.zeros((6, 8))
+    opt[3, :2] = 0.95, N.pi / 2.
+    opt[4, 0] = 1.0
+    which = [1, 0, 1, -1, 2, 3]
+    eoff = N.array([offs[w] if w >= 0 else -1 for w in which])
+    elen = N.array([len(tables[w]) if w >= 0 else 0 for w in which])
+    return TableScene(gm_kind, ok, frames, gm, opt, extra, eoff, elen)
+
+
+def test_cavity_spectral_engines_vs_oracle(ctx):
+    """cavity scene (frustum / cylinder / cone / plates, table-driven spectral and directional optics, per-ray wavelengths):
+    ordered and fast engines against the oracle, ray by ray, on identical Philox streams"""
+    from oracle import engine
+    from tracer_amd.scene import DeviceScene
+    from tracer_amd.ray_bundle import RayBundle
+    ts = _cavity_scene()
+    rng = N.random.RandomState(12)
+    n = 5000
+    # rays entering through the aperture (r < 1 at z = -0.5) with a spread of directions and wavelengths
+    rr, ph = N.sqrt(rng.uniform(0, 0.9, n)), rng.uniform(0, 2 * N.pi, n)
+    v = N.vstack((rr * N.cos(ph), rr * N.sin(ph), -0.5 * N.ones(n)))
+    d = N.vstack((rng.normal(scale=0.35, size=n), rng.normal(scale=0.35, size=n), N.ones(n)))
+    d /= N.sqrt(N.sum(d ** 2, axis=0))
+    e = rng.uniform(0.5, 1.5, n)
+    wl = rng.uniform(0.3e-6, 2.5e-6, n)
+    seed, reps, emin = 99, 12, 1e-3
+    dev = DeviceScene(ts, ctx)
+    res, stats = dev.trace_ordered(RayBundle(vertices=v, directions=d, energy=e, wavelengths=wl), reps, emin, seed)
+    levels = [res.level(k, with_wavelength=True) for k in range(res.num_levels())]
+    res.close()
+    a_o, r_o, h_o = dev.get_tallies()
+    ref = engine.trace_bundle(ts, v, d, e, reps, emin, seed, wavelengths=wl)
+    assert [l['vertices'].shape[1] for l in levels] == [l['vertices'].shape[1] for l in ref['levels']]
+    assert len(levels) >= 6 and (ref['hits'] > 50).all(), "every surface kind of the cavity takes part"
+    for k in range(1, len(levels)):
+        L, O = levels[k], ref['levels'][k]
+        assert N.array_equal(L['parents'], O['parents']) and N.array_equal(L['surf'], O['surf']), k
+        assert N.allclose(L['vertices'], O['vertices'], rtol=RT, atol=AT), k
+        assert N.allclose(L['directions'], O['directions'], rtol=1e-8, atol=1e-8), k
+        assert N.allclose(L['energy'], O['energy'], rtol=RT, atol=1e-12), k
+        assert N.allclose(L['wavelengths'], O['wl']), k
+    assert N.array_equal(h_o, ref['hits']) and N.allclose(a_o, ref['absorbed'], rtol=1e-9, atol=1e-9)
+    dev.reset_tallies()
+    st, _ = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e, wavelengths=wl), reps, emin, seed)
+    a, r, h = dev.get_tallies()
+    dev.close()
+    assert N.array_equal(h, ref['hits']) and N.allclose(a, ref['absorbed'], rtol=1e-9, atol=1e-9) and st.segments == ref['segments']
