@@ -193,6 +193,8 @@ typedef struct trc_result trc_result;
 /* trace flags */
 #define TRC_TRACE_ACCEL 0x1        /* use the Kd-tree set on the scene (ray_tracer(accel=...)) */
 #define TRC_TRACE_KEEP_LAST 0x2    /* fast engine: keep rays still alive after `reps` bounces */
+#define TRC_TRACE_STREAM 0x4       /* fast engine: run the phases as separate kernels connected by HBM queues
+                                      (trc_stream.inc) instead of the persistent megakernel; same results */
 
 typedef struct trc_trace_stats {
     int64_t segments;     /* sum over bounces of live rays (SURVEY 8(d) unit of work) */

@@ -294,6 +294,13 @@ def test_engines_vs_oracle_monte_carlo(ctx):
     assert N.allclose(a, ref['absorbed'], rtol=1e-9, atol=1e-9)
     assert N.allclose(r, ref['received'], rtol=1e-9, atol=1e-9)
     assert st.segments == ref['segments'] and st.rays_left == ref['last_vertices'].shape[1]
+    # the streaming form of the fast engine (separate kernels + HBM queues): same tallies
+    dev = DeviceScene(ts, ctx)
+    st2, last2 = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e, ref_index=N.ones(n)), reps, emin, seed, keep_last=True, stream=True)
+    a2, r2, h2 = dev.get_tallies()
+    dev.close()
+    assert N.array_equal(h2, ref['hits']) and N.allclose(a2, ref['absorbed'], rtol=1e-9, atol=1e-9) and N.allclose(r2, ref['received'], rtol=1e-9, atol=1e-9)
+    assert st2.segments == ref['segments'] and st2.rays_left == st.rays_left and st2.hits == st.hits
     if st.rays_left:
         mine = N.vstack(last)[:, N.lexsort(N.round(N.vstack(last[:3]), 6))]
         theirs = N.vstack((ref['last_vertices'], ref['last_directions'], ref['last_energy'][None, :]))
@@ -333,6 +340,13 @@ def test_kd_accel_equals_brute_and_reference(ctx):
     a, r, h = dev.get_tallies()
     dev.close()
     assert N.array_equal(h, tl_b[2]) and N.allclose(a, tl_b[0], rtol=1e-12, atol=1e-9)
+    for accel in (True, False):      # streaming engine, with the tree and with the single-leaf brute form
+        dev = DeviceScene(cs, ctx)
+        dev.set_kdtree(kd)
+        st, _ = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e), 100, 1e-10, 1, accel=accel, stream=True)
+        a, r, h = dev.get_tallies()
+        dev.close()
+        assert N.array_equal(h, tl_b[2]) and N.allclose(a, tl_b[0], rtol=1e-12, atol=1e-9), accel
 
 
 def test_full_size_properties(ctx):
@@ -493,6 +507,11 @@ def test_cavity_spectral_engines_vs_oracle(ctx):
     assert N.array_equal(h_o, ref['hits']) and N.allclose(a_o, ref['absorbed'], rtol=1e-9, atol=1e-9)
     dev.reset_tallies()
     st, _ = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e, wavelengths=wl), reps, emin, seed)
+    a, r, h = dev.get_tallies()
+    dev.close()
+    assert N.array_equal(h, ref['hits']) and N.allclose(a, ref['absorbed'], rtol=1e-9, atol=1e-9) and st.segments == ref['segments']
+    dev = DeviceScene(ts, ctx)
+    st, _ = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e, wavelengths=wl), reps, emin, seed, stream=True)
     a, r, h = dev.get_tallies()
     dev.close()
     assert N.array_equal(h, ref['hits']) and N.allclose(a, ref['absorbed'], rtol=1e-9, atol=1e-9) and st.segments == ref['segments']

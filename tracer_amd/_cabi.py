@@ -20,6 +20,7 @@ BUIE_LEN = 3 * (TRC_BUIE_NELEM + 1) + 6
 # trace flags
 TRACE_ACCEL = 0x1
 TRACE_KEEP_LAST = 0x2
+TRACE_STREAM = 0x4
 # surface flags
 SURF_CAPTURE_HITS = 0x1
 

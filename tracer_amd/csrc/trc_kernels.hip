@@ -137,6 +137,7 @@ struct trc_scene {
     uint16_t *d_a_leaf;
     int32_t *d_a_unbounded;
     uint16_t *d_a_bleaf;
+    struct StreamWs *stream_ws;   // workspace of the streaming fast engine (trc_stream.inc), allocated on first use
     double *d_tally;
     int64_t tally_n;
     std::vector<FluxMapDev> fms_h;
@@ -850,6 +851,12 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
     }
 }
 
+#include "trc_stream.inc"
+
+static void scene_free_stream_ws(trc_scene *sc) {
+    if (sc->stream_ws) { stream_ws_free(*sc->stream_ws); delete sc->stream_ws; sc->stream_ws = nullptr; }
+}
+
 // ================================================================================================
 // source generation as a bundle (sources.*_bundle)
 // ================================================================================================
@@ -1318,6 +1325,7 @@ extern "C" int trc_scene_destroy(trc_scene *sc) {
     if (!sc) return TRC_OK;
     (void)hipSetDevice(sc->ctx->device);
     (void)hipStreamSynchronize(sc->ctx->stream);
+    scene_free_stream_ws(sc);
     dev_free(sc->d_recs); dev_free(sc->d_opt); dev_free(sc->d_extra); dev_free(sc->d_sflags);
     dev_free(sc->d_kd_a); dev_free(sc->d_kd_b); dev_free(sc->d_kd_leaf); dev_free(sc->d_kd_always);
     dev_free(sc->d_a_sbox); dev_free(sc->d_a_nodes); dev_free(sc->d_a_leaf); dev_free(sc->d_a_unbounded); dev_free(sc->d_a_bleaf);
@@ -1704,6 +1712,19 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
             P.lds_scene = (lds + b_scene <= LDS_MAX) ? 1 : 0;
             if (P.lds_scene) lds += b_scene;
         }
+        static int stream_env = -1;
+        if (stream_env < 0) { const char *ev = getenv("TRC_FAST_STREAM"); stream_env = (ev && atoi(ev)) ? 1 : 0; }
+        // on request: the streaming engine (phases as separate kernels connected by HBM queues, trc_stream.inc)
+        const bool use_stream = m32 && ((flags & TRC_TRACE_STREAM) || stream_env) && n >= 64;
+        if (use_stream) {
+            if (!sc->stream_ws) {
+                sc->stream_ws = new (std::nothrow) StreamWs();
+                if (!sc->stream_ws) { st = trc_fail(TRC_ERR_NOMEM, "out of host memory"); break; }
+                memset(sc->stream_ws, 0, sizeof(StreamWs));
+            }
+            double segd = 0, hitd = 0;
+            if ((st = stream_trace(sc, P, accel, *sc->stream_ws, &s, &segd, &hitd))) break;
+        } else {
         void (*kern)(FastParams) = nullptr;
         if (m32) kern = threads == 1024 ? k_trace_coop<1024> : (threads == 768 ? k_trace_coop<768> : (threads == 512 ? k_trace_coop<512> : k_trace_coop<256>));
         else kern = k_trace_fast<256>;
@@ -1733,6 +1754,7 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
             (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
             s.kernel_ms = ms;
             s.launches = 1;
+        }
         }
         double tally_after[2];
         unsigned long long cnt_after[4];
