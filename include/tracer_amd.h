@@ -140,7 +140,11 @@ typedef enum trc_source_kind {
     TRC_SRC_PILLBOX_RECT = 1,  /* rect_bundle    sources.py:241-264  p: x,y,ang_range,swap_xy */
     TRC_SRC_BUIE_DISK = 2,     /* buie_sunshape  sources.py:412-464  p: radius ; tables */
     TRC_SRC_BUIE_RECT = 3,     /* rect_buie_sunshape sources.py:466-515 p: width,height ; tables */
-    TRC_SRC_PILLBOX_TRIANGLE = 4 /* triangular_bundle sources.py:544-597  center = A, rot_pos columns 0,1 = AB, AC ; p: ang_range */
+    TRC_SRC_PILLBOX_TRIANGLE = 4, /* triangular_bundle sources.py:544-597  center = A, rot_pos columns 0,1 = AB, AC ; p: ang_range */
+    TRC_SRC_VF_CYLINDER = 5,   /* vf_cylinder_bundle sources.py:716-769  Lambertian emitter on a cylinder wall
+                                  p: rc,lc,span0,span1,ang_range,sign(+1 rays_in / -1) */
+    TRC_SRC_VF_FRUSTUM = 6     /* vf_frustum_bundle sources.py:644-714  Lambertian emitter on a frustum wall
+                                  p: r0,r1,depth,span0,span1,ang_range,sign */
 } trc_source_kind;
 
 #define TRC_BUIE_NELEM 210  /* sources.py:338 */
@@ -309,6 +313,14 @@ int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int32_t n_extra
                      const trc_rays *in, const double *hx, const double *hy, const double *hz,
                      const double *nx, const double *ny, const double *nz,
                      uint64_t seed, int32_t bounce, trc_rays *out);
+
+/*
+ * optics.fresnel_to_attenuating (tracer/optics.py:63-81): reflectances R_p, R_s and refraction angle at the
+ * interface between a dielectric of index n1 and an absorbing medium of complex index m_re + i m_im, for n
+ * incidence angles theta1 (radians).  Host arrays of length n.
+ */
+int trc_optics_fresnel_attenuating(trc_ctx *ctx, int64_t n, double n1, const double *m_re, const double *m_im,
+                                   const double *theta1, double *r_p, double *r_s, double *theta2);
 
 #ifdef __cplusplus
 }

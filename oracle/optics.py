@@ -111,6 +111,18 @@ def fresnel(d, n, n1, n2):
     return (Rs + Rp) / 2
 
 
+def fresnel_to_attenuating(n1, m2, theta1):
+    """optics.py:63-81 as written: R_p, R_s, theta2"""
+    b = (m2.real ** 2 - m2.imag ** 2 - (n1 * N.sin(theta1)) ** 2)
+    a = N.sqrt(b ** 2 + 4. * (m2.real * m2.imag) ** 2)
+    p = N.sqrt(0.5 * (a + b))
+    q = N.sqrt(0.5 * (a - b))
+    theta2 = N.arctan(n1 * N.sin(theta1) / p)
+    R_s = ((n1 * N.cos(theta1) - p) ** 2 + q ** 2) / ((n1 * N.cos(theta1) + p) ** 2 + q ** 2)
+    R_p = ((p - n1 * N.sin(theta1) * N.tan(theta1)) ** 2 + q ** 2) / ((p + n1 * N.sin(theta1) * N.tan(theta1)) ** 2 + q ** 2) * R_s
+    return R_p, R_s, theta2
+
+
 def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event):
     """
     One optics call on H hits.  Returns a list of blocks (reflected block first, refracted second), each a dict
@@ -177,13 +189,7 @@ def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event):
         k = len(extra) // 3
         m2 = N.interp(wl, extra[:k], extra[k:2 * k]) + 1j * N.interp(wl, extra[:k], extra[2 * k:])
         theta1 = N.arccos(N.abs((nrm * d).sum(axis=0)))
-        n1 = opt[0]
-        b = (m2.real ** 2 - m2.imag ** 2 - (n1 * N.sin(theta1)) ** 2)
-        a = N.sqrt(b ** 2 + 4. * (m2.real * m2.imag) ** 2)
-        p = N.sqrt(0.5 * (a + b))
-        q = N.sqrt(0.5 * (a - b))
-        R_s = ((n1 * N.cos(theta1) - p) ** 2 + q ** 2) / ((n1 * N.cos(theta1) + p) ** 2 + q ** 2)
-        R_p = ((p - n1 * N.sin(theta1) * N.tan(theta1)) ** 2 + q ** 2) / ((p + n1 * N.sin(theta1) * N.tan(theta1)) ** 2 + q ** 2) * R_s
+        R_p, R_s, _ = fresnel_to_attenuating(opt[0], m2, theta1)
         return [dict(sel=allsel, directions=reflections(d, nrm), energy=e * (R_p + R_s) / 2., ref=ref.copy(), rid=rid)]
     if opt_kind == OPT_REFRACTIVE_HOMOGENOUS:                    # :1226-1296 on :836-858
         na, nb, single, sigma = opt[0], opt[1], opt[2] != 0., opt[3]

@@ -105,6 +105,25 @@ def generate(src, n, seed, offset, uniforms=None):
         sq = N.sqrt(u0)
         loc = N.vstack((sq * (1. - u1), u1 * sq, N.zeros(n)))
         a = pillbox_directions(2. * N.pi * u2, u3, p[0])
+    elif kind in (SRC_VF_CYLINDER, SRC_VF_FRUSTUM):
+        if kind == SRC_VF_CYLINDER:     # sources.py:737-746
+            zs = p[1] * u0 - p[1] / 2.
+            phi = p[2] + (p[3] - p[2]) * u1
+            loc = N.vstack((p[0] * N.cos(phi), p[0] * N.sin(phi), zs))
+            flat = pillbox_directions(2. * N.pi * u2, u3, p[4])
+            slope, sign = 0., p[5]
+        else:                           # sources.py:670-685
+            flat = pillbox_directions(2. * N.pi * u0, u1, p[5])
+            slope = (p[1] - p[0]) / p[2]
+            rs = N.sqrt((p[1] ** 2. - p[0] ** 2.) * u2 + p[0] ** 2.)
+            zs = (rs - p[0]) / ((p[1] - p[0]) / p[2])
+            phi = p[3] + (p[4] - p[3]) * u3
+            loc = N.vstack((rs * N.cos(phi), rs * N.sin(phi), zs))
+            sign = p[6]
+        trot = -N.pi / 2. + N.arctan(slope)     # sources.py:687-695, :748-753: rotz(phi) . roty(trot) . dir_flat
+        cy, sy = N.cos(trot), N.sin(trot)
+        rx, ry, rz = cy * flat[0] + sy * flat[2], flat[1], -sy * flat[0] + cy * flat[2]
+        a = sign * N.vstack((N.cos(phi) * rx - N.sin(phi) * ry, N.sin(phi) * rx + N.cos(phi) * ry, rz))
     else:
         tab = table_from_desc_buie(src['buie'])
         if kind == SRC_BUIE_DISK:       # sources.py:431-434

@@ -301,6 +301,13 @@ def make_optics(ref, amd, out):
     mat = A.TabulatedMaterial(mlam, mn, mk)
     run('fresnel_conductor', oc.FresnelConductorHomogenous(1., mat), A.FresnelConductorHomogenous(1., mat), wavelengths=wl)
 
+    # O1: optics.fresnel_to_attenuating on a grid of incidence angles x complex indices (optics.py:63-81)
+    th = N.tile(N.linspace(0., N.pi / 2. - 1e-3, 40), 6)
+    m2 = N.repeat(N.array([1.5 + 0.01j, 0.2 + 3.4j, 2.7 + 2.9j, 1.0 + 0.j, 0.05 + 6.j, 3.9 + 0.2j]), 40)
+    rp, rs, t2 = ref.optics.fresnel_to_attenuating(1.33, m2, th)
+    out['fta_theta1'], out['fta_m_re'], out['fta_m_im'], out['fta_n1'] = th, m2.real, m2.imag, N.float64(1.33)
+    out['fta_rp'], out['fta_rs'], out['fta_theta2'] = rp, rs, t2
+
     out['n_cases'] = N.int32(len(cases))
     out['names'] = N.array(cases)
     out['frame'] = frame
@@ -409,6 +416,30 @@ def make_sources(ref, amd, out):
     xs = N.random.uniform(low=-1.5, high=1.5, size=n); ys = N.random.uniform(low=-1., high=1., size=n)
     store('oblique_solar_rect_bundle', b, A.oblique_solar_rect_bundle(n, N.c_[[1., 0., 8.]], sd, rd, 3., 2., 4.65e-3, flux=1000., seed=1),
           (xi1 / (2. * N.pi), xi2, (xs + 1.5) / 3., (ys + 1.) / 2.))
+    # S4 view-factor emitters (sources.py:644-769): cylinder draws zs, phi_s, dir phi, dir R; frustum dir phi, dir R, R, phi_s
+    for name, kw in (('vf_cylinder_in', dict(rays_in=True)),
+                     ('vf_cylinder_out_wedge_flux', dict(rays_in=False, angular_span=[0.3, 2.1], flux=700., ang_range=1.2))):
+        dvec = N.r_[0.2, -0.3, N.sqrt(1. - 0.13)]
+        N.random.seed(20)
+        b = S.vf_cylinder_bundle(n, 0.8, 1.7, N.c_[[0.5, -1., 2.]], dvec, **kw)
+        N.random.seed(20)
+        span = kw.get('angular_span', [0., 2. * N.pi])
+        zs = N.random.uniform(size=n); ph = N.random.uniform(low=span[0], high=span[1], size=n)
+        xi1 = N.random.uniform(low=0., high=2. * N.pi, size=n); xi2 = N.random.uniform(size=n)
+        store(name, b, A.vf_cylinder_bundle(n, 0.8, 1.7, N.c_[[0.5, -1., 2.]], dvec, seed=1, **kw),
+              (zs, (ph - span[0]) / (span[1] - span[0]), xi1 / (2. * N.pi), xi2))
+    for name, r0, r1, kw in (('vf_frustum_widening', 0.5, 1.2, dict(rays_in=True)),
+                             ('vf_frustum_narrowing_out_flux', 1.1, 0.4, dict(rays_in=False, angular_span=[1., 4.], flux=300., angular_range=1.)),
+                             ('vf_frustum_cone_tip', 1., 0., dict(rays_in=True))):
+        dvec = N.r_[0., 0., 1.] if name.endswith('tip') else N.r_[-0.1, 0.4, N.sqrt(1. - 0.17)]
+        N.random.seed(21)
+        b = S.vf_frustum_bundle(n, r0, r1, 0.9, N.c_[[0., 0.3, 1.]], dvec, **kw)
+        N.random.seed(21)
+        span = kw.get('angular_span', [0., 2. * N.pi])
+        xi1 = N.random.uniform(low=0., high=2. * N.pi, size=n); xi2 = N.random.uniform(size=n)
+        R = N.random.uniform(size=n); ph = N.random.uniform(low=span[0], high=span[1], size=n)
+        store(name, b, A.vf_frustum_bundle(n, r0, r1, 0.9, N.c_[[0., 0.3, 1.]], dvec, seed=1, **kw),
+              (xi1 / (2. * N.pi), xi2, R, (ph - span[0]) / (span[1] - span[0])))
     out['n_cases'] = N.int32(len(cases))
     out['names'] = N.array(cases)
     print('sources: %d cases' % len(cases))
@@ -706,11 +737,16 @@ def main():
         return
     ref = NS('tracer')
     amd = NS('tracer_amd')
+    only = [a[len('--only='):] for a in sys.argv if a.startswith('--only=')]
     for fname, maker in (('geometry.npz', make_geometry), ('optics.npz', make_optics), ('sources.npz', make_sources),
                          ('engine.npz', make_engine)):
+        if only and fname not in only:
+            continue
         out = {}
         maker(ref, amd, out)
         N.savez_compressed(os.path.join(HERE, fname), **out)
+    if only:
+        return
     out = {}
     make_kdtree(ref, out)
     N.savez_compressed(os.path.join(HERE, 'kdtree_nsttf.npz'), **out)

@@ -140,6 +140,21 @@ def test_optics_laws():
     assert N.allclose(optics.fresnel(steep, n, 1.5, 1.), 1.)
 
 
+def test_fresnel_conductor_laws():
+    """optics.fresnel_to_attenuating / fresnel_conductor against the reference's values (fixture) -- optics.py:41-81"""
+    from helpers import load
+    from tracer_amd.optics_callables import TabulatedMaterial
+    o = load('optics.npz')
+    rp, rs, t2 = optics.fresnel_to_attenuating(float(o['fta_n1']), o['fta_m_re'] + 1j * o['fta_m_im'], o['fta_theta1'])
+    assert N.allclose(rp, o['fta_rp'], rtol=1e-10, atol=1e-14) and N.allclose(rs, o['fta_rs'], rtol=1e-10, atol=1e-14)
+    assert N.allclose(t2, o['fta_theta2'], rtol=1e-10, atol=1e-14)
+    # normal incidence on a conductor: R = ((n-1)^2 + k^2) / ((n+1)^2 + k^2)
+    mat = TabulatedMaterial(N.r_[0.4e-6, 0.8e-6], N.r_[0.2, 0.2], N.r_[3.4, 3.4])
+    rp, rs, _ = optics.fresnel_conductor(N.c_[[0., 0., -1.]], N.c_[[0., 0., 1.]], N.r_[0.5e-6], mat)
+    expect = ((0.2 - 1.) ** 2 + 3.4 ** 2) / ((0.2 + 1.) ** 2 + 3.4 ** 2)
+    assert N.allclose(rp, expect, rtol=1e-12) and N.allclose(rs, expect, rtol=1e-12)
+
+
 def test_optics_callables_and_accountants():
     """tests/test_opt_callable.py:20-61 (energies, parents, accumulation across calls), :92-109 (TIR), :139-189 (Lambertian)"""
     b = _bundle45()
@@ -290,3 +305,43 @@ def test_view_factors_of_a_cylindrical_cavity():
     sigma = N.sqrt(exact * (1. - exact) / n)
     assert N.all(N.abs(a - exact) <= 4. * sigma), (a, exact)
     assert n - 5 <= h.sum() <= n and N.isclose(a.sum(), 1., atol=2e-6)   # a ray starting on the rim can slip under the 1e-6 threshold
+
+    # second row of the same matrix: the first wall section as the emitter (sources.vf_cylinder_bundle, S4), aperture closed
+    # by a black disc: [aperture, itself, other wall, bottom] = [0.309, 0.382, 0.204, 0.105]
+    aperture = Surface(RoundPlateGM(1.), opt.Lambertian(1.))
+    asm2 = Assembly(objects=[AssembledObject(surfs=[aperture]),
+                             AssembledObject(surfs=[Surface(FiniteCylinder(diameter=2., height=1.), opt.Lambertian(1.))], transform=translate(0, 0, 0.5)),
+                             AssembledObject(surfs=[Surface(FiniteCylinder(diameter=2., height=1.), opt.Lambertian(1.))], transform=translate(0, 0, 1.5)),
+                             AssembledObject(surfs=[Surface(RoundPlateGM(1.), opt.Lambertian(1.))], transform=translate(0, 0, 2.))])
+    src = sources.vf_cylinder_bundle(n, 1., 1., N.c_[[0., 0., 0.5]], N.r_[0., 0., 1.], rays_in=True, seed=3)
+    eng = TracerEngine(asm2)
+    eng.ray_tracer(src, reps=1, min_energy=1e-10, tree=False, seed=3)
+    a, r, h = eng.get_tallies()
+    f_w_ap = 0.5 * (1. - f_mid)                   # reciprocity: A_ap / A_wall = 1/2
+    f_w_bot = 0.5 * (f_mid - f_bottom)           # reciprocity with the bottom disc's view of the far wall section
+    exact = N.array([f_w_ap, 1. - 2. * f_w_ap, f_w_ap - f_w_bot, f_w_bot])
+    assert N.allclose(exact, [0.309, 0.382, 0.204, 0.105], atol=5e-4)
+    sigma = N.sqrt(exact * (1. - exact) / n)
+    assert N.all(N.abs(a - exact) <= 4. * sigma), (a, exact)
+    assert h.sum() >= n - 50 and N.isclose(a.sum(), 1., atol=2e-5)
+
+    # a frustum wall emitter (sources.vf_frustum_bundle): cone frustum r 1 -> 0.5 over depth 1 closed by two discs;
+    # wall -> base discs by reciprocity with the analytic coaxial-disc factor
+    from tracer_amd.cone import ConicalFrustum
+    def discs(r1, r2, hgt):
+        R1, R2 = r1 / hgt, r2 / hgt
+        X = 1. + (1. + R2 ** 2) / R1 ** 2
+        return 0.5 * (X - N.sqrt(X ** 2 - 4. * (R2 / R1) ** 2))
+    f12 = discs(1., 0.5, 1.)                       # big disc -> small disc
+    a_wall = N.pi * 1.5 * N.sqrt(0.25 + 1.)
+    exact = N.array([N.pi * (1. - f12) / a_wall, N.pi * 0.25 * (1. - f12 * 4.) / a_wall])
+    asm3 = Assembly(objects=[AssembledObject(surfs=[Surface(RoundPlateGM(1.), opt.Lambertian(1.))]),
+                             AssembledObject(surfs=[Surface(RoundPlateGM(0.5), opt.Lambertian(1.))], transform=translate(0, 0, 1.)),
+                             AssembledObject(surfs=[Surface(ConicalFrustum(z1=0., r1=1., z2=1., r2=0.5), opt.Lambertian(1.))])])
+    src = sources.vf_frustum_bundle(n, 1., 0.5, 1., N.c_[[0., 0., 0.]], N.r_[0., 0., 1.], rays_in=True, seed=4)
+    eng = TracerEngine(asm3)
+    eng.ray_tracer(src, reps=1, min_energy=1e-10, tree=False, seed=4)
+    a, r, h = eng.get_tallies()
+    sigma = N.sqrt(exact * (1. - exact) / n)
+    assert N.all(N.abs(a[:2] - exact) <= 4. * sigma), (a, exact)
+    assert N.isclose(a.sum(), 1., atol=1e-4)

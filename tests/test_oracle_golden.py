@@ -131,6 +131,14 @@ def test_optics_variate_replay():
     assert sigma > 0
 
 
+def test_fresnel_to_attenuating_grid():
+    o = load('optics.npz')
+    with N.errstate(all='ignore'):
+        rp, rs, t2 = optics.fresnel_to_attenuating(float(o['fta_n1']), o['fta_m_re'] + 1j * o['fta_m_im'], o['fta_theta1'])
+    assert N.allclose(rp, o['fta_rp'], rtol=1e-12) and N.allclose(rs, o['fta_rs'], rtol=1e-12)
+    assert N.allclose(t2, o['fta_theta2'], rtol=1e-12)
+
+
 def test_sources_variate_replay():
     s = load('sources.npz')
     names = case_names(s)

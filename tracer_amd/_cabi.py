@@ -38,7 +38,7 @@ SURF_CAPTURE_HITS = 0x1
  OPT_FRESNEL_CONDUCTOR) = range(12)
 
 # enum trc_source_kind
-SRC_PILLBOX_DISK, SRC_PILLBOX_RECT, SRC_BUIE_DISK, SRC_BUIE_RECT, SRC_PILLBOX_TRIANGLE = range(5)
+SRC_PILLBOX_DISK, SRC_PILLBOX_RECT, SRC_BUIE_DISK, SRC_BUIE_RECT, SRC_PILLBOX_TRIANGLE, SRC_VF_CYLINDER, SRC_VF_FRUSTUM = range(7)
 
 _p_f64 = C.POINTER(C.c_double)
 _p_i64 = C.POINTER(C.c_int64)
@@ -116,6 +116,7 @@ SIGNATURES = {
     'trc_gm_get_normals': (C.c_int, [_vp, C.POINTER(SurfaceDesc), C.c_int64] + [_p_f64] * 9),
     'trc_optics_apply': (C.c_int, [_vp, C.POINTER(SurfaceDesc), C.c_int32, _p_f64, C.POINTER(Rays)] + [_p_f64] * 6 +
                          [C.c_uint64, C.c_int32, C.POINTER(Rays)]),
+    'trc_optics_fresnel_attenuating': (C.c_int, [_vp, C.c_int64, C.c_double] + [_p_f64] * 6),
 }
 
 

@@ -25,6 +25,7 @@
 #define TRC_INF (__builtin_inf())
 #define TRC_NAN (__builtin_nan(""))
 #define TRC_TWO_PI 6.283185307179586476925286766559
+#define TRC_PI 3.14159265358979323846264338327950288
 
 // ---------------------------------------------------------------------------------------------
 // Compact per-surface record used by the kernels (LDS-staged).  Layout in doubles:
@@ -868,9 +869,10 @@ TRC_HD double trc_interp2(const double *tab, double th, double lam) {
     return (1.0 - wt) * ((1.0 - wlam) * v00 + wlam * v01) + wt * ((1.0 - wlam) * v10 + wlam * v11);
 }
 
-// reflectance of an absorbing medium, optics.py:63-81 (fresnel_to_attenuating), unpolarised mean
-TRC_HD double trc_fresnel_conductor(double cos_abs, double n1, double n2, double k2) {
-    double th = acos(cos_abs);
+// interface between a perfect dielectric and an absorbing medium, optics.py:63-81 (fresnel_to_attenuating):
+// parallel / perpendicular reflectances and the refraction angle for an incidence angle th
+TRC_HD void trc_fresnel_attenuating(double th, double n1, double n2, double k2, double *rp_out, double *rs_out,
+                                    double *theta2) {
     double sn = n1 * sin(th);
     double b = n2 * n2 - k2 * k2 - sn * sn;
     double a = sqrt(b * b + 4.0 * (n2 * k2) * (n2 * k2));
@@ -878,7 +880,15 @@ TRC_HD double trc_fresnel_conductor(double cos_abs, double n1, double n2, double
     double c = n1 * cos(th);
     double rs = ((c - p) * (c - p) + q * q) / ((c + p) * (c + p) + q * q);
     double st = sn * tan(th);
-    double rp = ((p - st) * (p - st) + q * q) / ((p + st) * (p + st) + q * q) * rs;
+    *rp_out = ((p - st) * (p - st) + q * q) / ((p + st) * (p + st) + q * q) * rs;
+    *rs_out = rs;
+    *theta2 = atan(sn / p);
+}
+
+// unpolarised mean used by FresnelConductorHomogenous (optics_callables.py:1523-1558)
+TRC_HD double trc_fresnel_conductor(double cos_abs, double n1, double n2, double k2) {
+    double rp, rs, t2;
+    trc_fresnel_attenuating(acos(cos_abs), n1, n2, k2, &rp, &rs, &t2);
     return (rp + rs) / 2.0;
 }
 
@@ -1072,9 +1082,34 @@ TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint6
     double u0, u1, u2, u3;
     trc_uniform_pair(seed, rid, 0, 0, &u0, &u1);
     trc_uniform_pair(seed, rid, 0, 1, &u2, &u3);
-    double lx, ly, ax, ay, az;
+    double lx, ly, lz = 0.0, ax, ay, az;
     const double *p = src->p;
     switch (src->kind) {
+    case TRC_SRC_VF_CYLINDER:           // draws: zs, phi_s, dir phi, dir R (sources.py:737-746)
+    case TRC_SRC_VF_FRUSTUM: {          // draws: dir phi, dir R, R, phi_s (sources.py:670-685)
+        double phi, slope, sign, fx, fy, fz;
+        if (src->kind == TRC_SRC_VF_CYLINDER) {
+            lz = p[1] * u0 - p[1] / 2.0;
+            phi = p[2] + (p[3] - p[2]) * u1;
+            lx = p[0] * cos(phi); ly = p[0] * sin(phi);
+            trc_pillbox_dir(TRC_TWO_PI * u2, u3, p[4], &fx, &fy, &fz);
+            slope = 0.0; sign = p[5];
+        } else {
+            trc_pillbox_dir(TRC_TWO_PI * u0, u1, p[5], &fx, &fy, &fz);
+            slope = (p[1] - p[0]) / p[2];
+            double rs = sqrt((p[1] * p[1] - p[0] * p[0]) * u2 + p[0] * p[0]);
+            lz = (rs - p[0]) / slope;
+            phi = p[3] + (p[4] - p[3]) * u3;
+            lx = rs * cos(phi); ly = rs * sin(phi);
+            sign = p[6];
+        }
+        // local_unit = rotz(phi) . roty(-pi/2 + atan(slope)) . dir_flat   (:687-695, :748-753)
+        double trot = -TRC_PI / 2.0 + atan(slope);
+        double cy = cos(trot), sy = sin(trot), cz = cos(phi), sz = sin(phi);
+        double rx = cy * fx + sy * fz, ry = fy, rz = -sy * fx + cy * fz;
+        ax = sign * (cz * rx - sz * ry); ay = sign * (sz * rx + cz * ry); az = sign * rz;
+        break;
+    }
     case TRC_SRC_PILLBOX_DISK: {        // draws: dir phi, dir R, pos xi, pos theta (sources.py:200-213)
         trc_pillbox_dir(TRC_TWO_PI * u0, u1, p[4], &ax, &ay, &az);
         double r = sqrt(p[1] * p[1] + u2 * (p[0] * p[0] - p[1] * p[1]));
@@ -1112,9 +1147,15 @@ TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint6
     }
     }
     const double *rp = src->rot_pos, *rd = src->rot_dir;
-    *px = rp[0] * lx + rp[1] * ly + src->center[0];
-    *py = rp[3] * lx + rp[4] * ly + src->center[1];
-    *pz = rp[6] * lx + rp[7] * ly + src->center[2];
+    if (src->kind >= TRC_SRC_VF_CYLINDER) {      // wall emitters have a third local coordinate
+        *px = rp[0] * lx + rp[1] * ly + rp[2] * lz + src->center[0];
+        *py = rp[3] * lx + rp[4] * ly + rp[5] * lz + src->center[1];
+        *pz = rp[6] * lx + rp[7] * ly + rp[8] * lz + src->center[2];
+    } else {
+        *px = rp[0] * lx + rp[1] * ly + src->center[0];
+        *py = rp[3] * lx + rp[4] * ly + src->center[1];
+        *pz = rp[6] * lx + rp[7] * ly + src->center[2];
+    }
     *dx = rd[0] * ax + rd[1] * ay + rd[2] * az;
     *dy = rd[3] * ax + rd[4] * ay + rd[5] * az;
     *dz = rd[6] * ax + rd[7] * ay + rd[8] * az;

@@ -1611,7 +1611,7 @@ static int stage_rays(const trc_rays *r, int64_t n, bool need_energy, DevRays *d
 }
 
 static int upload_source(const trc_source_desc *src, trc_source_desc **d_src) {
-    if (src->kind < TRC_SRC_PILLBOX_DISK || src->kind > TRC_SRC_PILLBOX_TRIANGLE)
+    if (src->kind < TRC_SRC_PILLBOX_DISK || src->kind > TRC_SRC_VF_FRUSTUM)
         return trc_fail(TRC_ERR_UNSUPPORTED, "source kind %d is not in the native table", src->kind);
     TRC_TRY(dev_alloc(d_src, 1));
     HIP_TRY(hipMemcpy(*d_src, src, sizeof(trc_source_desc), hipMemcpyHostToDevice));
@@ -2134,6 +2134,39 @@ extern "C" int trc_gm_get_normals(trc_ctx *ctx, const trc_surface_desc *surf, in
     } while (0);
     dev_free(d_rec); dev_free(d_extra);
     for (int i = 0; i < 9; ++i) dev_free(d[i]);
+    return st;
+}
+
+__global__ __launch_bounds__(256) void k_fresnel_attenuating(long long n, double n1, const double *m_re, const double *m_im,
+                                                             const double *th, double *rp, double *rs, double *t2) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) trc_fresnel_attenuating(th[i], n1, m_re[i], m_im[i], &rp[i], &rs[i], &t2[i]);
+}
+
+extern "C" int trc_optics_fresnel_attenuating(trc_ctx *ctx, int64_t n, double n1, const double *m_re, const double *m_im,
+                                              const double *theta1, double *r_p, double *r_s, double *theta2) {
+    if (!ctx || n < 0 || (n > 0 && (!m_re || !m_im || !theta1 || !r_p || !r_s || !theta2)))
+        return trc_fail(TRC_ERR_INVALID, "trc_optics_fresnel_attenuating: bad arguments");
+    if (n == 0) return TRC_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    double *d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const double *src[3] = {m_re, m_im, theta1};
+    double *dst[3] = {r_p, r_s, theta2};
+    int st = TRC_OK;
+    do {
+        for (int i = 0; i < 6 && st == TRC_OK; ++i) st = dev_alloc(&d[i], (size_t)n);
+        if (st) break;
+        for (int i = 0; i < 3; ++i)
+            if (hipMemcpy(d[i], src[i], (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        if (st) break;
+        hipLaunchKernelGGL(k_fresnel_attenuating, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, n1,
+                           d[0], d[1], d[2], d[3], d[4], d[5]);
+        hipError_t se = hipStreamSynchronize(ctx->stream);
+        if (se != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "k_fresnel_attenuating failed: %s", hipGetErrorString(se)); break; }
+        for (int i = 0; i < 3; ++i)
+            if (hipMemcpy(dst[i], d[3 + i], (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+    } while (0);
+    for (int i = 0; i < 6; ++i) dev_free(d[i]);
     return st;
 }
 

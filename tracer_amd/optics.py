@@ -1,6 +1,7 @@
 """
 Physical laws of the optics callables as stand-alone functions, with the signatures of the
-reference's tracer/optics.py (:13-39 fresnel, :145-157 reflections, :159-192 refractions).
+reference's tracer/optics.py (:13-39 fresnel, :41-81 fresnel_conductor / fresnel_to_attenuating,
+:145-157 reflections, :159-192 refractions).
 They are evaluated by the same device code the engines use (trc_shade via trc_optics_apply),
 not by a NumPy re-implementation.
 """
@@ -80,3 +81,28 @@ def fresnel(ray_dirs, normals, n1, n2):
                               normals[:, sel], 1., ref_index=pa)
         R[sel] = e[:len(sel)]               # reflected block carries E*R with E = 1
     return R
+
+
+def fresnel_to_attenuating(n1, m2, theta1):
+    """
+    Interface between a perfect dielectric (index n1) and an absorbing medium of complex index m2, incidence
+    angles theta1 (radians).  Returns R_p, R_s, theta2 (the parallel / perpendicular reflectances and the
+    refraction angle), as optics.py:63-81.
+    """
+    th = _cabi.f64(N.atleast_1d(theta1))
+    n = len(th)
+    m = N.broadcast_to(N.asarray(m2, dtype=complex), (n,))
+    mre, mim = _cabi.f64(m.real), _cabi.f64(m.imag)
+    rp, rs, t2 = N.empty(n), N.empty(n), N.empty(n)
+    ctx = _cabi.get_context()
+    _cabi.check(ctx.lib.trc_optics_fresnel_attenuating(ctx.handle, n, float(n1), _cabi.ptr(mre), _cabi.ptr(mim),
+                                                       _cabi.ptr(th), _cabi.ptr(rp), _cabi.ptr(rs), _cabi.ptr(t2)))
+    return rp, rs, t2
+
+
+def fresnel_conductor(ray_dirs, normals, lambdas, material, n1=1., m2=None):
+    """Fresnel reflection from a dielectric onto a conductor (optics.py:41-61); material.m(lambdas) gives the complex index."""
+    if m2 is None:
+        m2 = material.m(lambdas)
+    theta_in = N.arccos(N.abs((N.asarray(normals) * N.asarray(ray_dirs)).sum(axis=0)))
+    return fresnel_to_attenuating(n1, m2, theta_in)

@@ -174,6 +174,45 @@ def triangular_bundle(num_rays, A, B, C, direction=None, ang_range=N.pi / 2., fl
     return _new_bundle(desc, num_rays, seed, ray_offset)
 
 
+def vf_cylinder_bundle(num_rays, rc, lc, center, direction, flux=None, rays_in=True, angular_span=[0., 2. * N.pi],
+                       ang_range=N.pi / 2., seed=None, ray_offset=0):
+    """
+    Lambertian emitter on the wall of a cylinder of radius rc and length lc centred on `center` with its axis along
+    `direction`, firing towards the axis (rays_in) or away from it (sources.py:716-769; the view-factor workload of
+    emissive_losses).  Energies flux*area/N, or 1/N without flux.
+    """
+    rc, lc = float(rc), float(lc)
+    if flux is None:
+        energy = 1. / float(num_rays)
+    else:
+        energy = flux * rc * (angular_span[1] - angular_span[0]) * lc / float(num_rays)
+    rot = rotation_to_z(direction)
+    desc = _fill_source(_cabi.SRC_VF_CYLINDER, center, rot, rot,
+                        [rc, lc, angular_span[0], angular_span[1], ang_range, 1. if rays_in else -1.], energy)
+    return _new_bundle(desc, num_rays, seed, ray_offset)
+
+
+def vf_frustum_bundle(num_rays, r0, r1, depth, center, direction, flux=None, rays_in=True, angular_span=[0., 2. * N.pi],
+                      angular_range=N.pi / 2., seed=None, ray_offset=0):
+    """
+    Lambertian emitter on the wall of a frustum: radius r0 at the base centred on `center`, r1 at `depth` along
+    `direction` (sources.py:644-714).  r0 == r1 is a cylinder and must use vf_cylinder_bundle (the reference divides
+    by the wall slope).
+    """
+    r0, r1, depth = float(r0), float(r1), float(depth)
+    if r0 == r1:
+        raise ValueError("vf_frustum_bundle needs r0 != r1; use vf_cylinder_bundle for a cylinder")
+    if flux is None:
+        energy = 1. / float(num_rays)
+    else:
+        area = (angular_span[1] - angular_span[0]) * (r1 + r0) / 2. * N.sqrt(abs(r1 - r0) ** 2. + depth ** 2.)
+        energy = flux * area / float(num_rays)
+    rot = rotation_to_z(direction)
+    desc = _fill_source(_cabi.SRC_VF_FRUSTUM, center, rot, rot,
+                        [r0, r1, depth, angular_span[0], angular_span[1], angular_range, 1. if rays_in else -1.], energy)
+    return _new_bundle(desc, num_rays, seed, ray_offset)
+
+
 def regular_square_bundle(num_rays, center, direction, width):
     """Parallel rays on a regular square grid of half-width `width` normal to `direction` (sources.py:518-542);
     deterministic, no energy column -- built on the host."""
