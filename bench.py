@@ -16,7 +16,8 @@ Prints ONE JSON line on rank 0: metric/value/unit per BASELINE.json, plus
   roofline      algorithmic HBM bytes of the dominant kernel (k_trace_fast: 112 B per ray segment)
                 over its launch time measured with HIP events on the launch stream, against the 8 TB/s HBM peak
   cpu_baseline  the oracle (NumPy restatement of the reference's algorithm = the reference's own CPU path, which
-                is NumPy too) timed on this host on a bounded sample of the same workload, rank 0 at N=1 only.
+                is NumPy too) timed on this host's cores (one process per core, independent batches) on a bounded
+                sample of the same workload, rank 0 at N=1 only, before the GPU part starts.
 """
 import argparse
 import json
@@ -36,23 +37,49 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(n_rays):
-    """oracle (kind "port"), one core, brute force like the reference's default path, on n_rays NSTTF source rays"""
+def cpu_worker(n_rays, seed):
+    """one CPU worker: the oracle, brute force like the reference's default path, on n_rays NSTTF source rays"""
     import numpy as N
     from tracer_amd import scenes
     from tracer_amd.scene import compile_scene
     from oracle import engine as oracle_engine
     plant, field, rec, src = scenes.nsttf_field()
     cs = compile_scene(plant)
-    b = scenes.nsttf_source(n_rays, src, seed=99)
+    b = scenes.nsttf_source(n_rays, src, seed=seed)
     t0 = time.time()
     with N.errstate(all='ignore'):
         ref = oracle_engine.trace_from_compiled(cs, b.source_args(), reps=100, min_energy=1e-10)
     dt = time.time() - t0
-    return dict(value=ref['segments'] / dt / 1e6, unit='Mray-bounces/s', cores=1, kind='port',
-                sample='NSTTF 218 heliostats + receiver, %d source rays (%d segments), brute force, %.1f s'
-                       % (n_rays, ref['segments'], dt),
-                receiver_kW=float(ref['absorbed'][-1] / 1e3))
+    return dict(segments=int(ref['segments']), seconds=dt, receiver_kW=float(ref['absorbed'][-1] / 1e3))
+
+
+def cpu_baseline(n_rays, workers):
+    """
+    oracle (kind "port") timed on this host: `workers` independent processes, one core each, every one tracing its own
+    batch of n_rays NSTTF source rays (the reference's multi-core driver, tracer_engine_mp.py, also runs independent
+    batches per process).  Must run BEFORE this process touches the GPU: the workers are started with exec.
+    """
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(n_rays), str(99 + w)],
+                              stdout=subprocess.PIPE, env=env, cwd=ROOT) for w in range(workers)]
+    res = []
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('CPU baseline worker failed')
+        res.append(json.loads(out.decode().strip().splitlines()[-1]))
+    wall = time.time() - t0
+    seg = sum(r['segments'] for r in res)
+    slowest = max(r['seconds'] for r in res)
+    per_core = [r['segments'] / r['seconds'] / 1e6 for r in res]
+    return dict(value=seg / slowest / 1e6, unit='Mray-bounces/s', cores=workers, kind='port',
+                per_core=sum(per_core) / len(per_core),
+                sample='NSTTF 218 heliostats + receiver, brute force (the reference default), %d processes x %d source rays '
+                       '(%d segments in total), slowest worker %.1f s, wall incl. start-up %.1f s'
+                       % (workers, n_rays, seg, slowest, wall),
+                receiver_kW=sum(r['receiver_kW'] for r in res) / len(res))
 
 
 def main():
@@ -61,9 +88,15 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--rays', type=float, default=1e8, help='source rays per step per GPU')
-    ap.add_argument('--cpu-rays', type=int, default=600000, help='source rays of the CPU baseline sample (0 = skip)')
+    ap.add_argument('--cpu-rays', type=int, default=250000, help='source rays per CPU baseline worker (0 = skip)')
+    ap.add_argument('--cpu-workers', type=int, default=0, help='CPU baseline processes (0 = one per core, at most 16)')
+    ap.add_argument('--cpu-worker', nargs=2, metavar=('RAYS', 'SEED'), help=argparse.SUPPRESS)
     ap.add_argument('--no-accel', action='store_true', help='brute force instead of the Kd-tree')
     args = ap.parse_args()
+
+    if args.cpu_worker:
+        print(json.dumps(cpu_worker(int(args.cpu_worker[0]), int(args.cpu_worker[1]))), flush=True)
+        return
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -71,6 +104,13 @@ def main():
     if world != args.gpus:
         log('note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE' % (world, args.gpus))
     n = int(args.rays)
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_rays > 0:
+        # before anything initialises the GPU in this process (the workers are separate programs)
+        workers = args.cpu_workers or min(os.cpu_count() or 1, 16)
+        log('timing the CPU baseline (oracle, %d processes x %d rays) ...' % (workers, args.cpu_rays))
+        cpu = cpu_baseline(args.cpu_rays, workers)
 
     import torch
     import torch.distributed as dist
@@ -178,11 +218,7 @@ def main():
                       'heliostat_hits_per_ray': float(h[:218].sum()) / total_rays,
                       'fluxmap_sum_kW': float(fm.sum()) / args.steps / world / 1e3, 'energy_per_ray_W': e_ray},
         }
-        if world == 1 and args.cpu_rays > 0:
-            log('timing the CPU baseline (oracle, %d rays) ...' % args.cpu_rays)
-            out['cpu_baseline'] = cpu_baseline(args.cpu_rays)
-        else:
-            out['cpu_baseline'] = None
+        out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
     dev.close()
     if world > 1:

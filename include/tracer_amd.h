@@ -71,7 +71,10 @@ typedef enum trc_gm_kind {
     TRC_GM_QUADRATIC_RECT = 25,    /* RectFlatQuadricSurfaceGM   quadratic_surface.py:64-105 gm: a..f,w/2,h/2 */
     TRC_GM_ELLIPSOID = 26,         /* Ellipsoid                  ellipsoid.py:5-61        gm: a,b,c (1/semi-axis^2) */
     TRC_GM_ELLIPSOID_CUT = 27,     /* EllipsoidGM                ellipsoid.py:63-118      gm: a,b,c,xlo,xhi,ylo,yhi,zlo,zhi */
-    TRC_GM_KIND_COUNT = 28
+    TRC_GM_SPHERE_CUT = 28,        /* CutSphereGM                sphere_surface.py:168-204  gm: r, bound type (1 BoundaryPlane,
+                                      2 BoundarySphere, 3 BoundaryCylinder; boundary_shape.py:89-162), bound rotation[9] and
+                                      location[3] in the surface's frame, bound radius */
+    TRC_GM_KIND_COUNT = 29
 } trc_gm_kind;
 
 /* ---- optics callables (reference: tracer/optics_callables.py) -------------- */

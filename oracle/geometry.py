@@ -150,6 +150,21 @@ def _select(kind, frame, g, coords, prm):
             return _restrict(_base_select(prm), (~outside) & (prm > 1e-6))
         if kind == GM_HEMISPHERE:                                # sphere_surface.py:128-137
             return _restrict(_base_select(prm), (z <= 0) & (prm > 1e-6))
+        if kind == GM_SPHERE_CUT:                                # :188-202 (with range for xrange), bound shapes of
+            rb, cb = N.asarray(g[2:11]).reshape(3, 3), N.asarray(g[11:14])   # boundary_shape.py:104-110, :139-149, :152-162
+            bound = N.eye(4)
+            bound[:3, :3], bound[:3, 3] = rb, cb
+            temp = N.dot(frame, bound)                           # CutSphereGM.find_intersections: bound.transform_frame(frame)
+            in_bd = []
+            for k in range(2):
+                pts = N.vstack((coords[k], N.ones(n)))
+                if int(g[1]) == 1:
+                    in_bd.append(N.dot(N.linalg.inv(temp)[2], pts) >= 0)
+                elif int(g[1]) == 2:       # the reference keeps the sphere at its untransformed location (defect); intended form
+                    in_bd.append(g[14] ** 2 >= ((coords[k] - temp[:3, 3:4]) ** 2).sum(axis=0))
+                else:                      # the reference applies temp_frame[:2] instead of its inverse (defect); intended form
+                    in_bd.append(N.sum(N.dot(N.linalg.inv(temp)[:2], pts) ** 2, axis=0) <= g[14] ** 2)
+            return _restrict(_base_select(prm), N.array(in_bd) & (prm > 1e-6))
         if kind == GM_SPHERE_RECT:                               # :217-227
             good = (z <= 0) & (prm > 1e-6) & (N.abs(x) <= g[1]) & (N.abs(y) <= g[2])
             return _restrict(_base_select(prm), good)

@@ -94,6 +94,13 @@ def gm_cases():
         ('ellipsoid', 'ellipsoid', 'Ellipsoid', (1.2, 0.8, 1.5), {}, 1.5),
         ('ellipsoid_cut', 'ellipsoid', 'EllipsoidGM', (1.2, 0.8, 1.5), {'xlim': [-0.5, 1.0], 'ylim': None, 'zlim': [-1., 0.7]}, 1.5),
         ('ellipsoid_alllims', 'ellipsoid', 'EllipsoidGM', (1.2, 0.8, 1.5), {'xlim': [-0.5, 1.0], 'ylim': [-0.3, 0.3], 'zlim': [-1., 0.7]}, 1.5),
+        # CutSphereGM: the bounding volume is built per package (callable values get the package namespace)
+        ('sphere_cut_plane', 'sphere_surface', 'CutSphereGM', (1.3,),
+         {'bounding_volume': lambda pkg: pkg.boundary_shape.BoundaryPlane(location=N.r_[0.1, 0., 0.4], rotation=rot([1., 0.3, 0.], 0.5))}, 1.5),
+        ('sphere_cut_plane_lens_cap', 'sphere_surface', 'CutSphereGM', (2.,),
+         {'bounding_volume': lambda pkg: pkg.boundary_shape.BoundaryPlane(location=N.r_[0., 0., 1.2])}, 2.),
+        ('sphere_cut_sphere', 'sphere_surface', 'CutSphereGM', (2.,),
+         {'bounding_volume': lambda pkg: pkg.boundary_shape.BoundarySphere(radius=4., location=N.r_[0., 0., -4 * N.sqrt(3) / 2.])}, 2.),
     ]
 
 
@@ -118,6 +125,8 @@ def ray_fan(rng, n, frame, scale):
 
 
 def make_geometry(ref, amd, out):
+    # CutSphereGM._select_coords still says `xrange` (sphere_surface.py:198); give the imported module the Python-3 name
+    ref.sphere_surface.xrange = range
     rng = N.random.RandomState(20240601)
     frames = [N.eye(4),
               frame_of(rot([1, 2, 3], 0.7), [0.5, -1.0, 2.0]),
@@ -126,11 +135,13 @@ def make_geometry(ref, amd, out):
     ci = 0
     for name, mod, cls, args, kwargs, scale in gm_cases():
         for fi, frame in enumerate(frames):
-            gm_ref = getattr(getattr(ref, mod), cls)(*args, **kwargs)
-            gm_amd = getattr(getattr(amd, mod), cls)(*args, **kwargs)
+            if name == 'sphere_cut_sphere' and fi > 0:
+                continue        # the reference's BoundarySphere ignores frame transforms (keeps `_loc`, boundary_shape.py:101-110)
+            gm_ref = getattr(getattr(ref, mod), cls)(*args, **dict((k, a(ref) if callable(a) else a) for k, a in kwargs.items()))
+            gm_amd = getattr(getattr(amd, mod), cls)(*args, **dict((k, a(amd) if callable(a) else a) for k, a in kwargs.items()))
             kind, params, extra = gm_amd._native()
             v, d = ray_fan(rng, 240, frame, scale)
-            if cls in ('HemisphereGM', 'SphericalRectFacet'):
+            if cls in ('HemisphereGM', 'SphericalRectFacet', 'CutSphereGM'):
                 # Reference defect: these two classes assign the chosen root with
                 # `N.nonzero(mask[:, one_hit])[0]` (sphere_surface.py:137, :227), which lists the root indices
                 # sorted, not per ray -- in a bundle where some rays keep root 0 and others root 1 the choices are

@@ -234,6 +234,82 @@ def test_models_and_compat_script():
     assert N.allclose(det[0], [0.1, 1.]) and det[1].shape == (3, 2) and det[2].shape == (3, 2)
 
 
+def test_cut_sphere_gm():
+    """tests/test_cut_sphere.py: a sphere of radius 2 trimmed to its bottom part by a bounding sphere"""
+    from tracer_amd.sphere_surface import CutSphereGM
+    from tracer_amd.boundary_shape import BoundarySphere
+    n = 10
+    theta = N.linspace(0, 2 * N.pi, n, endpoint=False)
+    pos = N.vstack((N.cos(theta), N.sin(theta), N.ones(n)))
+    bund = RayBundle(pos, N.tile(N.c_[[0, 0, -1]], (1, n)))
+    gm = CutSphereGM(2., BoundarySphere(radius=4., location=N.r_[0., 0., -4 * N.sqrt(3) / 2.]))
+    prm = gm.find_intersections(N.eye(4), bund)
+    assert prm.shape == (n,) and N.allclose(prm, 1 + 2 * N.sin(N.pi / 3))
+    gm.select_rays(N.arange(n))
+    nrm = gm.get_normals()
+    assert N.allclose(nrm[-1, 0], nrm[-1, 1:])
+    assert N.allclose(pos[:2], -nrm[:2] / N.sqrt((nrm[:2] ** 2).sum(axis=0)))      # centre-pointing
+    pts = gm.get_intersection_points_global()
+    assert N.allclose(pts[:2], pos[:2], atol=1e-15) and N.allclose(pts[2], -2 * N.sin(N.pi / 3))
+
+
+def test_homogenizer_first_hits():
+    """tests/models/test_homogenizer.py::test_first_hits: one ray to each wall of a 5 x 3 x 10 duct"""
+    from tracer_amd.models.homogenizer import rect_homogenizer
+    eng = TracerEngine(rect_homogenizer(5., 3., 10., 0.9))
+    pos = N.zeros((3, 4))
+    pos[2] = 11.
+    dirs = N.c_[[1, 0, -1], [-1, 0, -1], [0, 1, -1], [0, -1, -1]] / N.sqrt(2)
+    v, d = eng.ray_tracer(RayBundle(pos, dirs, energy=N.ones(4) * 4., ref_index=N.ones(4)), 1, 0.05)
+    assert N.allclose(d, N.c_[[-1, 0, -1], [1, 0, -1], [0, -1, -1], [0, 1, -1]] / N.sqrt(2))
+    assert N.allclose(v, N.c_[[2.5, 0, 8.5], [-2.5, 0, 8.5], [0, 1.5, 9.5], [0, -1.5, 9.5]])
+    assert N.allclose(eng.tree[1].get_energy(), 3.6)
+
+
+def test_spherical_lens_imaging():
+    """tests/models/test_spherical_lens.py: paraxial rays reach the focus (biconvex, planoconvex), chief-ray image height
+    of a biconcave lens, the edge cylinder exists.  RefractiveHomogenous draws reflect-or-refract per ray, so a fan of
+    identical rays is sent and the ones that reached the screen are checked."""
+    from tracer_amd.models.spherical_lens import SphericalLens
+    from tracer_amd.models.one_sided_mirror import rect_one_sided_mirror
+    k = 64
+
+    def to_screen(lens, origin, direct, screen_z, seed):
+        screen = rect_one_sided_mirror(5, 5)
+        screen.set_transform(translate(0, 0, screen_z))
+        rb = RayBundle(N.tile(origin, (1, k)), N.tile(direct, (1, k)), energy=N.ones(k), ref_index=N.ones(k))
+        eng = TracerEngine(Assembly([lens, screen]))
+        vert, _ = eng.ray_tracer(rb, 3, 1e-6, seed=seed)
+        on_screen = N.abs(vert[2] - screen_z) < 1e-9
+        assert on_screen.sum() > k // 2          # ~8 % are lost to the two Fresnel reflections
+        return vert[:, on_screen]
+
+    for lens in (SphericalLens(diameter=1., depth=0.1, R1=10., R2=-10., refr_idx=1.5),
+                 SphericalLens(diameter=1., depth=0.05, R1=10., R2=N.inf, refr_idx=1.5)):
+        hits = to_screen(lens, N.c_[[0., 0.001, 1.]], N.c_[[0., 0., -1.]], -lens.focal_length(), seed=5)
+        assert N.all(N.abs(hits[1]) < 5e-5) and N.all(N.abs(hits[0]) < 1e-12)
+
+    lens = SphericalLens(diameter=1., depth=0.1, R1=-10., R2=10., refr_idx=1.5)
+    origin = N.c_[[0., 0.001, 1.]]
+    f = lens.focal_length()
+    m = f / (origin[2, 0] + f)
+    hits = to_screen(lens, origin, -origin / N.linalg.norm(origin), -origin[2, 0] * m, seed=6)
+    assert N.all(N.abs(hits[1] + m * origin[1, 0]) < 5e-5)
+
+    # the bounding cylinder: a ray travelling inside the glass towards the rim meets it at r = 0.5
+    for lens, z in ((SphericalLens(diameter=1., depth=0.1, R1=10., R2=-10., refr_idx=1.5), 0.08),
+                    (SphericalLens(diameter=1., depth=0.1, R1=-10., R2=10., refr_idx=1.5), 0.08),
+                    (SphericalLens(diameter=1., depth=0.05, R1=10., R2=N.inf, refr_idx=1.5), 0.001)):
+        rb = RayBundle(N.tile(N.c_[[0., 0., z]], (1, k)), N.tile(N.c_[[1., 0., 0.]], (1, k)), energy=N.ones(k), ref_index=N.ones(k) * 1.5)
+        verts, dirs = TracerEngine(Assembly([lens])).ray_tracer(rb, 1, 1e-6, seed=7)
+        assert verts.shape == (3, k) and N.allclose(verts, N.c_[[0.5, 0., z]])
+        assert set(dirs[0]) == {-1., 1.} and N.all(dirs[1:] == 0)       # reflected back or transmitted straight
+    lens = SphericalLens(diameter=1., depth=0.05, R1=10., R2=N.inf, refr_idx=1.5)
+    rb = RayBundle(N.c_[[0., 0., -0.01]], N.c_[[1., 0., 0.]], energy=N.r_[1.], ref_index=N.r_[1.5])
+    verts, dirs = TracerEngine(Assembly([lens])).ray_tracer(rb, 1, 1e-6)
+    assert verts.shape == (3, 0)                                         # below the flat back face: no cylinder there
+
+
 def test_protocol_engine_with_python_plugin():
     """a user-defined optics callable (pure Python) in the scene: engine='auto' falls back to the protocol loop, native
     geometry still runs on the GPU, results equal the all-native scene"""

@@ -138,3 +138,45 @@ def test_compat_aliases():
         for k in [k for k in sys.modules if k == 'tracer' or k.startswith('tracer.')]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_boundary_shapes_in_bounds():
+    """tests/test_boundary_surface.py::TestInBounds"""
+    from tracer_amd.boundary_shape import BoundarySphere, BoundaryCylinder, BoundaryPlane
+    from tracer_amd.spatial_geometry import rotx
+    pts = N.array([[0., 0., 0.], [1., 1., 1.], [2., 2., 2.]])
+    assert list(BoundarySphere(radius=2.).in_bounds(pts)) == [True, True, False]
+    assert list(BoundaryCylinder(diameter=3.).in_bounds(pts)) == [True, True, False]
+    plane = BoundaryPlane(rotation=rotx(-N.pi / 6)[:3, :3], location=N.r_[0., 1., 0.])
+    assert list(plane.in_bounds(pts)) == [False, True, True]
+
+
+def test_radial_stagger_positions():
+    """tests/models/test_tower.py::TestRadialStagger"""
+    from tracer_amd.models.heliostat_field import radial_stagger
+    pos = radial_stagger(-N.pi / 4, N.pi / 4 + 0.0001, N.pi / 2, 5, 10, 1)
+    assert N.allclose(N.sqrt(N.sum(pos ** 2, axis=1)), N.r_[5, 5, 7, 7, 9, 9, 6, 8])
+
+
+def test_spherical_lens_focal_lengths_and_layout():
+    """tests/models/test_spherical_lens.py::*::test_focal_length (lensmaker equation, exact) + the surfaces created"""
+    from tracer_amd.models.spherical_lens import SphericalLens
+    assert SphericalLens(diameter=1., depth=0.1, R1=10., R2=-10., refr_idx=1.5).focal_length() == 2. / (0.2 - 0.05 / 150)
+    assert SphericalLens(diameter=1., depth=0.1, R1=-10., R2=10., refr_idx=1.5).focal_length() == 2. / (-0.2 - 0.05 / 150)
+    pc = SphericalLens(diameter=1., depth=0.05, R1=10., R2=N.inf, refr_idx=1.5)
+    assert pc.focal_length() == 20.
+    assert len(pc.get_surfaces()) == 3                       # front cap, flat back, edge cylinder
+    kinds = [s.get_geometry_manager()._native()[0] for s in pc.get_surfaces()]
+    from tracer_amd import _cabi
+    assert kinds == [_cabi.GM_SPHERE_CUT, _cabi.GM_ROUND, _cabi.GM_CYL_FINITE]
+
+
+def test_homogenizer_layout():
+    from tracer_amd.models.homogenizer import rect_homogenizer
+    hmg = rect_homogenizer(5., 3., 10., 0.9)
+    frames = [s.get_surfaces()[0] for s in hmg.get_objects()]
+    hmg.transform_children(N.eye(4))
+    normals = N.array([s._temp_frame[:3, 2] for s in frames])
+    assert N.allclose(normals, [[-1, 0, 0], [1, 0, 0], [0, -1, 0], [0, 1, 0]], atol=1e-15)   # mirrors face the duct axis
+    centres = N.array([s._temp_frame[:3, 3] for s in frames])
+    assert N.allclose(centres, [[2.5, 0, 5], [-2.5, 0, 5], [0, 1.5, 5], [0, -1.5, 5]])

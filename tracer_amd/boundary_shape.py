@@ -1,7 +1,7 @@
 """
 Bounding shapes attached to objects.  BoundaryBox (a local AABB whose global AABB is refreshed on
-every transform_frame) is the input of the Kd-tree builder; interface of the reference's
-tracer/boundary_shape.py:7-87.
+every transform_frame) is the input of the Kd-tree builder; BoundarySphere / BoundaryCylinder /
+BoundaryPlane trim a CutSphereGM.  Interface of the reference's tracer/boundary_shape.py:7-162.
 """
 import numpy as N
 from .has_frame import HasFrame
@@ -40,3 +40,42 @@ class BoundaryBox(BoundaryShape):
     def transform_frame(self, transform):
         BoundaryShape.transform_frame(self, transform)
         self.update_AABB()
+
+
+class BoundarySphere(BoundaryShape):
+    """Points within `radius` of the shape's location are in bounds (boundary_shape.py:89-110)."""
+    def __init__(self, location=None, radius=1.):
+        BoundaryShape.__init__(self, location, None)
+        self._radius = radius
+
+    def in_bounds(self, bund_vertices):
+        return self._radius ** 2 >= ((N.asarray(bund_vertices) - self._temp_frame[:3, 3]) ** 2).sum(axis=1)
+
+    def _native(self):
+        return 2, self._radius
+
+
+class BoundaryCylinder(BoundaryShape):
+    """An infinite cylinder along the shape's local Z axis (boundary_shape.py:130-149)."""
+    def __init__(self, diameter=1., location=None, rotation=None):
+        self._R = diameter / 2.
+        BoundaryShape.__init__(self, location, rotation)
+
+    def in_bounds(self, vertices):
+        v = N.asarray(vertices)
+        local_xy = N.dot(N.linalg.inv(self._temp_frame)[:2], N.vstack((v.T, N.ones(v.shape[0]))))
+        return N.sum(local_xy ** 2, axis=0) <= self._R ** 2
+
+    def _native(self):
+        return 3, self._R
+
+
+class BoundaryPlane(BoundaryShape):
+    """The half space on the positive local Z side of the shape's XY plane (boundary_shape.py:151-162)."""
+    def in_bounds(self, vertices):
+        v = N.asarray(vertices)
+        local_z = N.dot(N.linalg.inv(self._temp_frame)[2], N.vstack((v.T, N.ones(v.shape[0]))))
+        return local_z >= 0
+
+    def _native(self):
+        return 1, 0.

@@ -36,7 +36,7 @@ static inline bool trc_surface_bounds(const trc_surface_desc &s, double lo[3], d
         double rx = std::sqrt(g[2] / g[0]);
         l[0] = -rx; h[0] = rx; l[1] = -g[1]; h[1] = g[1]; l[2] = 0.0; h[2] = g[2]; break;
     }
-    case TRC_GM_SPHERE: case TRC_GM_HEMISPHERE: case TRC_GM_SPHERE_RECT:
+    case TRC_GM_SPHERE: case TRC_GM_HEMISPHERE: case TRC_GM_SPHERE_RECT: case TRC_GM_SPHERE_CUT:
         for (int i = 0; i < 3; ++i) { lo[i] = s.frame[4 * i + 3] - g[0]; hi[i] = s.frame[4 * i + 3] + g[0]; }
         return true;
     case TRC_GM_CYL_FINITE: case TRC_GM_CYL_RECTCUT:

@@ -72,6 +72,7 @@ TRC_HD int trc_gm_nparams(int kind) {
     case TRC_GM_QUADRATIC_RECT: return 8;
     case TRC_GM_ELLIPSOID: return 3;
     case TRC_GM_ELLIPSOID_CUT: return 9;
+    case TRC_GM_SPHERE_CUT: return 15;
     default: return -1;
     }
 }
@@ -247,6 +248,17 @@ TRC_HD bool trc_quadric_aperture(int kind, const double *rec, const double *g, d
     case TRC_GM_PARAB_TROUGH: return (fabs(ly) <= g[1]) && (lz <= g[2]) && (lz >= 0.0); // :433-438
     case TRC_GM_HEMISPHERE: return lz <= 0.0;                                            // sphere_surface.py:133
     case TRC_GM_SPHERE_RECT: return (lz <= 0.0) && (fabs(lx) <= g[1]) && (fabs(ly) <= g[2]); // :222-223
+    case TRC_GM_SPHERE_CUT: {                 // :194-199 with the bound carried in the surface's frame
+        double qx = lx - g[11], qy = ly - g[12], qz = lz - g[13];
+        int bound = (int)g[1];
+        if (bound == 1) return (g[4] * qx + g[7] * qy + g[10] * qz) >= 0.0;             // boundary_shape.py:152-162
+        if (bound == 2) return g[14] * g[14] >= qx * qx + qy * qy + qz * qz;             // :104-110
+        if (bound == 3) {                                                                // :139-149
+            double bx = g[2] * qx + g[5] * qy + g[8] * qz, by = g[3] * qx + g[6] * qy + g[9] * qz;
+            return bx * bx + by * by <= g[14] * g[14];
+        }
+        return true;
+    }
     case TRC_GM_CYL_FINITE: {                                                           // cylinder.py:97-103
         double ang = atan2(ly, lx);
         if (ang < 0.0) ang = TRC_TWO_PI + ang;
@@ -280,7 +292,7 @@ TRC_HD int trc_quadric_select_mode(int kind, double *eps) {
     case TRC_GM_ELLIPSOID_CUT: *eps = 1e-7; return 1;          // ellipsoid.py:96
     case TRC_GM_PARAB_HEX: *eps = 0.0; return 2;               // paraboloid.py:217
     case TRC_GM_PARAB_RECT: case TRC_GM_PARAB_RECT_OFFAXIS: case TRC_GM_HEMISPHERE: case TRC_GM_SPHERE_RECT:
-    case TRC_GM_QUADRATIC_RECT:
+    case TRC_GM_QUADRATIC_RECT: case TRC_GM_SPHERE_CUT:
         *eps = 1e-6; return 2;
     default: *eps = 1e-6; return 0;
     }
@@ -290,7 +302,7 @@ TRC_HD double trc_intersect_quadric(int kind, const double *rec, double vx, doub
                                     double dy, double dz) {
     const double *g = rec + TRC_REC_HDR;
     double A, B, C;
-    if (kind == TRC_GM_SPHERE || kind == TRC_GM_HEMISPHERE || kind == TRC_GM_SPHERE_RECT) {
+    if (kind == TRC_GM_SPHERE || kind == TRC_GM_HEMISPHERE || kind == TRC_GM_SPHERE_RECT || kind == TRC_GM_SPHERE_CUT) {
         // global frame, sphere_surface.py:58-66
         double qx = vx - rec[9], qy = vy - rec[10], qz = vz - rec[11];
         A = dx * dx + dy * dy + dz * dz;
@@ -408,7 +420,7 @@ TRC_HD void trc_normal(const double *rec, double hx, double hy, double hz, doubl
         *nx = ux; *ny = uy; *nz = uz;
         return;
     }
-    if (kind == TRC_GM_SPHERE || kind == TRC_GM_HEMISPHERE || kind == TRC_GM_SPHERE_RECT) {
+    if (kind == TRC_GM_SPHERE || kind == TRC_GM_HEMISPHERE || kind == TRC_GM_SPHERE_RECT || kind == TRC_GM_SPHERE_CUT) {
         double ux = hx - rec[9], uy = hy - rec[10], uz = hz - rec[11];
         double sides = (-ux) * dx + (-uy) * dy + (-uz) * dz;
         if (sides < 0.0) { ux = -ux; uy = -uy; uz = -uz; }

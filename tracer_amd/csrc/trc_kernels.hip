@@ -1214,7 +1214,7 @@ static int validate_surface(const trc_surface_desc &s, int idx, int n_extra) {
         if (!(g[0] > 0)) return trc_fail(TRC_ERR_INVALID, "surface %d: radius must be positive", idx);
         if (g[1] >= 0 && !(g[1] < g[0])) return trc_fail(TRC_ERR_INVALID, "surface %d: inner radius must be lower than the outer one", idx);
         break;
-    case TRC_GM_SPHERE: case TRC_GM_HEMISPHERE: case TRC_GM_SPHERE_RECT:
+    case TRC_GM_SPHERE: case TRC_GM_HEMISPHERE: case TRC_GM_SPHERE_RECT: case TRC_GM_SPHERE_CUT:
         if (!(g[0] > 0)) return trc_fail(TRC_ERR_INVALID, "surface %d: radius must be positive", idx);
         break;
     default: break;
