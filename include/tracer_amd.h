@@ -139,7 +139,8 @@ typedef struct trc_rays {
 
 /* ---- sources (reference: tracer/sources.py) -------------------------------- */
 typedef enum trc_source_kind {
-    TRC_SRC_PILLBOX_DISK = 0,  /* disk_bundle    sources.py:175-239  p: radius,radius_in,span0,span1,ang_range */
+    TRC_SRC_PILLBOX_DISK = 0,  /* disk_bundle    sources.py:175-239  p: radius,radius_in,span0,span1,ang_range,
+                                  has_x_cut,x_cut (positions redrawn until local x < x_cut) */
     TRC_SRC_PILLBOX_RECT = 1,  /* rect_bundle    sources.py:241-264  p: x,y,ang_range,swap_xy */
     TRC_SRC_BUIE_DISK = 2,     /* buie_sunshape  sources.py:412-464  p: radius ; tables */
     TRC_SRC_BUIE_RECT = 3,     /* rect_buie_sunshape sources.py:466-515 p: width,height ; tables */

@@ -93,7 +93,18 @@ def generate(src, n, seed, offset, uniforms=None):
         a = pillbox_directions(2. * N.pi * u0, u1, p[4])
         rs = N.sqrt(p[1] ** 2. + u2 * (p[0] ** 2. - p[1] ** 2.))
         th = p[2] + (p[3] - p[2]) * u3
-        loc = N.vstack((rs * N.cos(th), rs * N.sin(th), N.zeros(n)))
+        xs, ys = rs * N.cos(th), rs * N.sin(th)
+        if p[5] != 0. and uniforms is None:     # x_cut (sources.py:216-228): rejected positions are redrawn; per-ray stream here
+            blk = 2
+            redo = N.nonzero(~(xs < p[6]))[0]
+            while len(redo) and blk < 2 + 4096:
+                a2, a3 = philox.uniform_pair(seed, rid[redo], 0, blk)
+                r2 = N.sqrt(p[1] ** 2. + a2 * (p[0] ** 2. - p[1] ** 2.))
+                t2 = p[2] + (p[3] - p[2]) * a3
+                xs[redo], ys[redo] = r2 * N.cos(t2), r2 * N.sin(t2)
+                redo = redo[~(xs[redo] < p[6])]
+                blk += 1
+        loc = N.vstack((xs, ys, N.zeros(n)))
     elif kind == SRC_PILLBOX_RECT:      # sources.py:243-256
         a = pillbox_directions(2. * N.pi * u0, u1, p[2])
         xs = -p[0] / 2. + p[0] * u2

@@ -188,6 +188,24 @@ def test_sources_vs_oracle(ctx):
         assert N.allclose(d, do, rtol=1e-9, atol=1e-11), name
         assert N.allclose(e, eo, rtol=1e-14), name
         assert N.allclose(N.sum(d ** 2, axis=0), 1., atol=1e-12), name
+        if name == 'disk_bundle':
+            # x_cut (sources.py:216-228): rejected positions are redrawn from the ray's own stream; device == oracle,
+            # every position qualifies, and what is left is still uniform over the remaining part of the annulus
+            desc.p[5], desc.p[6] = 1., 0.4
+            src_cut = dict(src, p=list(src['p'][:5]) + [1., 0.4, 0.])
+            _cabi.check(ctx.lib.trc_source_generate(ctx.handle, C.byref(desc), n, 777, 5, C.byref(rays)))
+            vo, do, eo, rid = sources.generate(src_cut, n, 777, 5)
+            assert N.allclose(v, vo, rtol=1e-10, atol=1e-8) and N.allclose(d, do, rtol=1e-9, atol=1e-11)
+            loc = N.dot(src['rot_pos'].T, v - N.asarray(src['center']).reshape(3, 1))
+            assert N.all(loc[0] < 0.4) and N.allclose(loc[2], 0., atol=1e-9)
+            r2 = loc[0] ** 2 + loc[1] ** 2
+            assert 0.3 ** 2 - 1e-9 <= r2.min() and r2.max() <= 1.5 ** 2 + 1e-9
+            frac = N.mean(loc[0] < -0.5)                       # area of {x < -0.5} over area of {x < 0.4}, both inside the annulus
+            def seg(a, R):                                     # area of the disc of radius R with x < a
+                a = N.clip(a, -R, R)
+                return R * R * (N.pi - N.arccos(a / R)) + a * N.sqrt(R * R - a * a)
+            expect = (seg(-0.5, 1.5) - seg(-0.5, 0.3)) / (seg(0.4, 1.5) - seg(0.4, 0.3))
+            assert abs(frac - expect) < 4. * N.sqrt(expect * (1. - expect) / n), (frac, expect)
 
 
 def _ordered(ctx, ts, v, d, e, reps, min_energy, seed, accel=False, ref_index=None, kd=None):

@@ -103,8 +103,10 @@ def test_source_descriptors_host_part():
     assert list(r.source_args()[0].p)[:4] == [2., 3., 0.1, 1.] and N.isclose(r.source_args()[0].energy, 1. / 10.)
     d = sources.disk_bundle(10, N.c_[[0., 0., 1.]], N.r_[0., 0., 1.], 1., N.pi / 2., flux=2.)
     assert N.isclose(d.source_args()[0].energy, N.pi / 10. * 2.)
-    with pytest.raises(NotImplementedError):
-        sources.disk_bundle(10, N.c_[[0., 0., 1.]], N.r_[0., 0., 1.], 1., 0.1, x_cut=0.5)
+    dc = sources.disk_bundle(10, N.c_[[0., 0., 1.]], N.r_[0., 0., 1.], 1., 0.1, x_cut=0.5)
+    assert list(dc.source_args()[0].p)[5:7] == [1., 0.5]
+    with pytest.raises(ValueError):
+        sources.disk_bundle(10, N.c_[[0., 0., 1.]], N.r_[0., 0., 1.], 1., 0.1, x_cut=-1.)
 
 
 def test_rng_plumbing_and_sharding():

@@ -1127,6 +1127,14 @@ TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint6
         double r = sqrt(p[1] * p[1] + u2 * (p[0] * p[0] - p[1] * p[1]));
         double th = p[2] + (p[3] - p[2]) * u3;
         lx = r * cos(th); ly = r * sin(th);
+        if (p[5] != 0.0) {              // x_cut: redraw the position until x < x_cut (rejection, sources.py:216-228)
+            for (uint32_t blk = 2; !(lx < p[6]) && blk < 2 + 4096; ++blk) {
+                trc_uniform_pair(seed, rid, 0, blk, &u2, &u3);
+                r = sqrt(p[1] * p[1] + u2 * (p[0] * p[0] - p[1] * p[1]));
+                th = p[2] + (p[3] - p[2]) * u3;
+                lx = r * cos(th); ly = r * sin(th);
+            }
+        }
         break;
     }
     case TRC_SRC_PILLBOX_RECT: {        // draws: dir phi, dir R, xs, ys (sources.py:243-256)

@@ -100,11 +100,13 @@ def disk_bundle(num_rays, center, direction, radius, ang_range, flux=None, radiu
                 x_cut=None, procs=1, rays_direction=None, seed=None, ray_offset=0):
     """
     Pillbox/Lambertian-cone rays leaving an annular disc.  center: 3x1 column, direction: 3-vector
-    normal of the disc; energies flux*area/N*cos(tilt), or 1/N/procs without flux.
+    normal of the disc; energies flux*area/N*cos(tilt), or 1/N/procs without flux.  x_cut keeps the part of the disc
+    with local x < x_cut (positions are redrawn until they qualify; the energy still refers to the whole disc, as in
+    the reference).
     """
-    if x_cut is not None:
-        raise NotImplementedError("disk_bundle(x_cut=...) uses rejection sampling and is not in the native table")
     radius, radius_in = float(radius), float(radius_in)
+    if x_cut is not None and not x_cut > -radius:
+        raise ValueError("disk_bundle: x_cut leaves no part of the disc")
     if rays_direction is None:
         rays_direction = direction
     if flux is not None:
@@ -113,7 +115,8 @@ def disk_bundle(num_rays, center, direction, radius, ang_range, flux=None, radiu
         energy = 1. / float(num_rays) / procs
     rot = rotation_to_z(rays_direction)
     desc = _fill_source(_cabi.SRC_PILLBOX_DISK, center, rot, rot,
-                        [radius, radius_in, angular_span[0], angular_span[1], ang_range], energy)
+                        [radius, radius_in, angular_span[0], angular_span[1], ang_range,
+                         0. if x_cut is None else 1., 0. if x_cut is None else float(x_cut)], energy)
     return _new_bundle(desc, num_rays, seed, ray_offset)
 
 

@@ -3,6 +3,7 @@ Spheres: full sphere, lower hemisphere, rectangular spherical facet (reference:
 tracer/sphere_surface.py:9-68, :117-139, :168-204, :206-228).  CutSphereGM trims the sphere by a
 BoundaryPlane / BoundarySphere / BoundaryCylinder given in the surface's own frame.
 """
+import numpy as N
 from . import _cabi
 from .quadric import QuadricGM
 
@@ -22,6 +23,17 @@ class SphericalGM(QuadricGM):
 
     def _native(self):
         return _cabi.GM_SPHERE, [self._rad], []
+
+    def get_fluxmap(self, eners, local_coords, resolution):
+        """Energy per area on a (polar angle, azimuth) grid of resolution x 2*resolution bins (sphere_surface.py:100-115)."""
+        ths_bin = N.linspace(0., N.pi, resolution + 1)
+        phis_bin = N.linspace(0., 2. * N.pi, resolution * 2 + 1)
+        ths = N.arccos(local_coords[2] / self._rad)
+        phis = N.arctan2(local_coords[1], local_coords[0])
+        phis[phis < 0.] += 2. * N.pi
+        h = N.histogram2d(ths, phis, bins=[ths_bin, phis_bin], weights=eners)[0]
+        areas = self._rad ** 2. * N.diff(phis_bin)[None, :] * (N.cos(ths_bin[:-1]) - N.cos(ths_bin[1:]))[:, None]
+        return N.hstack(h / areas)
 
 
 class HemisphereGM(SphericalGM):
