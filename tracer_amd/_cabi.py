@@ -12,7 +12,7 @@ import threading
 import numpy as N
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libtracer_amd.so')
+LIB_PATH = os.environ.get("TRACER_AMD_LIB") or os.path.join(_HERE, "lib", "libtracer_amd.so")
 
 TRC_BUIE_NELEM = 210
 BUIE_LEN = 3 * (TRC_BUIE_NELEM + 1) + 6

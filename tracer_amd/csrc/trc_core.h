@@ -116,12 +116,17 @@ TRC_HD void trc_uniform_pair(uint64_t seed, uint64_t rid, uint32_t event, uint32
     *u1 = trc_u01_from_bits(o[2], o[3]);
 }
 
+// sine and cosine of the same angle with one argument reduction
+TRC_HD void trc_sincos(double x, double *s, double *c) { sincos(x, s, c); }
+
 // Box-Muller: two independent N(0,1) from two uniforms (1-u0 keeps the log argument in (0,1])
 TRC_HD void trc_normal_pair(double u0, double u1, double *g0, double *g1) {
     double r = sqrt(-2.0 * log(1.0 - u0));
     double a = TRC_TWO_PI * u1;
-    *g0 = r * cos(a);
-    *g1 = r * sin(a);
+    double sa, ca;
+    trc_sincos(a, &sa, &ca);
+    *g0 = r * ca;
+    *g1 = r * sa;
 }
 
 // stream id of the second ray created when an interaction splits a ray in two
@@ -787,7 +792,10 @@ TRC_HD void trc_rotate_z_to_normal(double ex, double ey, double ez, double nx, d
     double kn = sqrt(kx * kx + ky * ky);
     kx /= kn; ky /= kn;
     if (kx != kx) { kx = 1.0; ky = 0.0; kz = 0.0; }
-    double s = trc_round14(sin(ang)), c = trc_round14(cos(ang)), vv = 1.0 - c;
+    double s, c;
+    trc_sincos(ang, &s, &c);
+    s = trc_round14(s); c = trc_round14(c);
+    double vv = 1.0 - c;
     // M = outer(k,k)*v + I*c + [k]x*s
     double m00 = kx * kx * vv + c, m01 = kx * ky * vv - kz * s, m02 = kx * kz * vv + ky * s;
     double m10 = ky * kx * vv + kz * s, m11 = ky * ky * vv + c, m12 = ky * kz * vv - kx * s;
@@ -814,8 +822,10 @@ TRC_HD void trc_rotation_to_z_apply(double nx, double ny, double nz, double ax, 
 TRC_HD void trc_pillbox_dir(double xi1, double xi2, double ang_range, double *ax, double *ay, double *az) {
     if (ang_range == 0.0) { *ax = 0.0; *ay = 0.0; *az = 1.0; return; }
     double s = sin(ang_range) * sqrt(xi2);
-    *ax = cos(xi1) * s;
-    *ay = sin(xi1) * s;
+    double s1, c1;
+    trc_sincos(xi1, &s1, &c1);
+    *ax = c1 * s;
+    *ay = s1 * s;
     *az = sqrt(1.0 - s * s);
 }
 
@@ -828,17 +838,21 @@ TRC_HD void trc_slope_error_local(double sigma, bool bi_var, double g0, double g
         *ex = tx * z; *ey = ty * z; *ez = z;
     } else {
         double th = sigma * g0, phi = TRC_TWO_PI * u2;
-        *ez = cos(th);
-        *ex = sin(th) * cos(phi);
-        *ey = sin(th) * sin(phi);
+        double st, ct, sp, cp;
+        trc_sincos(th, &st, &ct);
+        trc_sincos(phi, &sp, &cp);
+        *ez = ct;
+        *ex = st * cp;
+        *ey = st * sp;
     }
 }
 
 // unpolarised Fresnel reflectance, optics.py:28-38 (formula kept as written, through arccos/sin)
 TRC_HD double trc_fresnel(double cos_abs, double n1, double n2) {
     double th = acos(cos_abs);
-    double foo = cos(th);
-    double sn = n1 / n2 * sin(th);
+    double foo, sth;
+    trc_sincos(th, &sth, &foo);
+    double sn = n1 / n2 * sth;
     double bar = sqrt(1.0 - sn * sn);
     double rs = (n1 * foo - n2 * bar) / (n1 * foo + n2 * bar);
     double rp = (n1 * bar - n2 * foo) / (n1 * bar + n2 * foo);
@@ -885,11 +899,13 @@ TRC_HD double trc_interp2(const double *tab, double th, double lam) {
 // parallel / perpendicular reflectances and the refraction angle for an incidence angle th
 TRC_HD void trc_fresnel_attenuating(double th, double n1, double n2, double k2, double *rp_out, double *rs_out,
                                     double *theta2) {
-    double sn = n1 * sin(th);
+    double sth, cth;
+    trc_sincos(th, &sth, &cth);
+    double sn = n1 * sth;
     double b = n2 * n2 - k2 * k2 - sn * sn;
     double a = sqrt(b * b + 4.0 * (n2 * k2) * (n2 * k2));
     double p = sqrt(0.5 * (a + b)), q = sqrt(0.5 * (a - b));
-    double c = n1 * cos(th);
+    double c = n1 * cth;
     double rs = ((c - p) * (c - p) + q * q) / ((c + p) * (c + p) + q * q);
     double st = sn * tan(th);
     *rp_out = ((p - st) * (p - st) + q * q) / ((p + st) * (p + st) + q * q) * rs;
@@ -1018,7 +1034,10 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
             double g0, g1;
             trc_normal_pair(u0, u1, &g0, &g1);
             double th = sigma * g0, phi = TRC_TWO_PI * u2;
-            double ex = sin(th) * cos(phi), ey = sin(th) * sin(phi), ez = cos(th);
+            double st, ct, sp, cp;
+            trc_sincos(th, &st, &ct);
+            trc_sincos(phi, &sp, &cp);
+            double ex = st * cp, ey = st * sp, ez = ct;
             double rx, ry, rz;
             trc_rotation_to_z_apply(nx, ny, nz, ex, ey, ez, &rx, &ry, &rz);
             nx = rx; ny = ry; nz = rz;
@@ -1096,6 +1115,9 @@ TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint6
     trc_uniform_pair(seed, rid, 0, 1, &u2, &u3);
     double lx, ly, lz = 0.0, ax, ay, az;
     const double *p = src->p;
+#ifdef TRC_EXPERIMENT_BUIE_ONLY
+    if (src->kind != TRC_SRC_BUIE_DISK) __builtin_unreachable();
+#endif
     switch (src->kind) {
     case TRC_SRC_VF_CYLINDER:           // draws: zs, phi_s, dir phi, dir R (sources.py:737-746)
     case TRC_SRC_VF_FRUSTUM: {          // draws: dir phi, dir R, R, phi_s (sources.py:670-685)
@@ -1103,7 +1125,7 @@ TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint6
         if (src->kind == TRC_SRC_VF_CYLINDER) {
             lz = p[1] * u0 - p[1] / 2.0;
             phi = p[2] + (p[3] - p[2]) * u1;
-            lx = p[0] * cos(phi); ly = p[0] * sin(phi);
+            { double sp, cp; trc_sincos(phi, &sp, &cp); lx = p[0] * cp; ly = p[0] * sp; }
             trc_pillbox_dir(TRC_TWO_PI * u2, u3, p[4], &fx, &fy, &fz);
             slope = 0.0; sign = p[5];
         } else {
@@ -1112,12 +1134,14 @@ TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint6
             double rs = sqrt((p[1] * p[1] - p[0] * p[0]) * u2 + p[0] * p[0]);
             lz = (rs - p[0]) / slope;
             phi = p[3] + (p[4] - p[3]) * u3;
-            lx = rs * cos(phi); ly = rs * sin(phi);
+            { double sp, cp; trc_sincos(phi, &sp, &cp); lx = rs * cp; ly = rs * sp; }
             sign = p[6];
         }
         // local_unit = rotz(phi) . roty(-pi/2 + atan(slope)) . dir_flat   (:687-695, :748-753)
         double trot = -TRC_PI / 2.0 + atan(slope);
-        double cy = cos(trot), sy = sin(trot), cz = cos(phi), sz = sin(phi);
+        double cy, sy, cz, sz;
+        trc_sincos(trot, &sy, &cy);
+        trc_sincos(phi, &sz, &cz);
         double rx = cy * fx + sy * fz, ry = fy, rz = -sy * fx + cy * fz;
         ax = sign * (cz * rx - sz * ry); ay = sign * (sz * rx + cz * ry); az = sign * rz;
         break;
@@ -1126,13 +1150,15 @@ TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint6
         trc_pillbox_dir(TRC_TWO_PI * u0, u1, p[4], &ax, &ay, &az);
         double r = sqrt(p[1] * p[1] + u2 * (p[0] * p[0] - p[1] * p[1]));
         double th = p[2] + (p[3] - p[2]) * u3;
-        lx = r * cos(th); ly = r * sin(th);
+        { double st, ct; trc_sincos(th, &st, &ct); lx = r * ct; ly = r * st; }
         if (p[5] != 0.0) {              // x_cut: redraw the position until x < x_cut (rejection, sources.py:216-228)
             for (uint32_t blk = 2; !(lx < p[6]) && blk < 2 + 4096; ++blk) {
                 trc_uniform_pair(seed, rid, 0, blk, &u2, &u3);
                 r = sqrt(p[1] * p[1] + u2 * (p[0] * p[0] - p[1] * p[1]));
                 th = p[2] + (p[3] - p[2]) * u3;
-                lx = r * cos(th); ly = r * sin(th);
+                double st, ct;
+                trc_sincos(th, &st, &ct);
+                lx = r * ct; ly = r * st;
             }
         }
         break;
@@ -1146,10 +1172,13 @@ TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint6
     }
     case TRC_SRC_BUIE_DISK: {           // draws: xv1, phiv, R_theta, xi (sources.py:431-434, :365, :380)
         double r = p[0] * sqrt(u0), ph = TRC_TWO_PI * u1;
-        lx = r * cos(ph); ly = r * sin(ph);
+        double sph, cph, st, ct, sxi, cxi;
+        trc_sincos(ph, &sph, &cph);
+        lx = r * cph; ly = r * sph;
         double th = trc_buie_theta(buie, u2), xi = TRC_TWO_PI * u3;
-        double st = sin(th);
-        ax = cos(xi) * st; ay = sin(xi) * st; az = cos(th);
+        trc_sincos(th, &st, &ct);
+        trc_sincos(xi, &sxi, &cxi);
+        ax = cxi * st; ay = sxi * st; az = ct;
         break;
     }
     case TRC_SRC_PILLBOX_TRIANGLE: {    // draws: r1, r2 (point picking), dir phi, dir R (sources.py:559-568)
@@ -1161,8 +1190,10 @@ TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint6
     default: {                          // TRC_SRC_BUIE_RECT (sources.py:485-486)
         lx = p[0] * (u0 - 0.5); ly = p[1] * (u1 - 0.5);
         double th = trc_buie_theta(buie, u2), xi = TRC_TWO_PI * u3;
-        double st = sin(th);
-        ax = cos(xi) * st; ay = sin(xi) * st; az = cos(th);
+        double st, ct, sxi, cxi;
+        trc_sincos(th, &st, &ct);
+        trc_sincos(xi, &sxi, &cxi);
+        ax = cxi * st; ay = sxi * st; az = ct;
         break;
     }
     }
