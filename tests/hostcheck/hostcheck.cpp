@@ -141,4 +141,58 @@ int hc_nearest32(int n_surf, const trc_surface_desc *surfs, const double *extra,
     return 0;
 }
 
+// the streaming engine's candidate search: uniform grid + DDA in single precision, box tests, exact tests.
+// stats[0] = cells visited, [1] = box tests, [2] = exact tests (sums over the rays).  Returns -2 when no grid can be built.
+int hc_nearest_grid(int n_surf, const trc_surface_desc *surfs, const double *extra, long n, const double *x, const double *y,
+                    const double *z, const double *dx, const double *dy, const double *dz, double *t_out, int *s_out, double *stats) {
+    int max_np = 0;
+    for (int i = 0; i < n_surf; ++i) { int np = trc_gm_nparams(surfs[i].gm_kind); if (np > max_np) max_np = np; }
+    int stride = TRC_REC_HDR + max_np;
+    if ((stride & 1) == 0) stride += 1;
+    std::vector<double> recs_v((size_t)n_surf * stride);
+    for (int i = 0; i < n_surf; ++i) pack_record(surfs[i], recs_v.data() + (size_t)i * stride, stride);
+    const double *recs = recs_v.data();
+    trc_accel_host H;
+    trc_accel_build_surfaces(surfs, n_surf, H);
+    trc_accel_build_grid(H, n_surf);
+    if (!H.grid_ok) return -2;
+    trc_grid_view G;
+    G.off = H.grid_off.data(); G.list = H.grid_list.data();
+    G.nx = H.grid_dim[0]; G.ny = H.grid_dim[1]; G.nz = H.grid_dim[2];
+    G.lox = H.grid_lo[0]; G.loy = H.grid_lo[1]; G.loz = H.grid_lo[2];
+    G.csx = H.grid_cs[0]; G.csy = H.grid_cs[1]; G.csz = H.grid_cs[2];
+    G.ivx = H.grid_inv[0]; G.ivy = H.grid_inv[1]; G.ivz = H.grid_inv[2];
+    stats[0] = stats[1] = stats[2] = 0.0;
+    stats[3] = (double)((long)G.nx * G.ny * G.nz); stats[4] = (double)H.grid_list.size();
+    for (long i = 0; i < n; ++i) {
+        const double vx = x[i], vy = y[i], vz = z[i];
+        const double ddx = dx[i], ddy = dy[i], ddz = dz[i];
+        double tb = TRC_INF;
+        int sb = -1;
+        {
+            const double dx = ddx, dy = ddy, dz = ddz;
+            for (size_t k = 0; k < H.unbounded.size(); ++k) TRC_TEST_EXACT(H.unbounded[k]);
+            trc_ray32 r;
+            double t0;
+            float tmin, tmax;
+            if (trc_ray32_prepare(H.slo, H.shi, H.cen, vx, vy, vz, dx, dy, dz, &r, &t0) && trc_kd32_root(H.brute_root, r, &tmin, &tmax)) {
+                trc_dda s;
+                trc_dda_start(G, r, tmin, &s);
+                do {
+                    stats[0] += 1.0;
+                    int c = trc_dda_cell(G, s);
+                    for (int k = G.off[c]; k < G.off[c + 1]; ++k) {
+                        int sidx = G.list[k];
+                        stats[1] += 1.0;
+                        if (trc_box_hit32(H.sbox.data() + 6 * (size_t)sidx, r)) { stats[2] += 1.0; TRC_TEST_EXACT(sidx); }
+                    }
+                } while (trc_dda_next(G, r, tmax, &s));
+            }
+        }
+        t_out[i] = tb;
+        s_out[i] = sb;
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -154,6 +154,13 @@ def test_core_kd_traversal_equals_brute_force(hc):
         assert rc == 0
         assert N.array_equal(s32, sb), use_kd
         assert N.array_equal(t32, tb), use_kd
+    # the streaming engine's uniform grid + DDA: identical (t, surface) again
+    t32, s32, st = N.empty(m), N.empty(m, dtype=N.int32), N.zeros(8)
+    rc = hc.hc_nearest_grid(cs.n_surf, cs.descs, _p(extra), C.c_long(m), _p(v[0]), _p(v[1]), _p(v[2]), _p(dr[0]), _p(dr[1]), _p(dr[2]),
+                            _p(t32), _p(s32, C.c_int32), _p(st))
+    assert rc == 0
+    assert N.array_equal(s32, sb) and N.array_equal(t32, tb)
+    print('grid: %d cells, %d list entries; per ray %.1f cells, %.1f box tests, %.2f exact tests' % (st[3], st[4], st[0] / m, st[1] / m, st[2] / m))
     # and the oracle agrees with the brute-force core on which surface is hit first
     scene = engine.scene_from_compiled(cs)
     with N.errstate(all='ignore'):

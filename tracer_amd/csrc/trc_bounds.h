@@ -93,6 +93,12 @@ struct trc_accel_host {
     double cen[3], slo[3], shi[3];
     bool any_bounded;
     int kd_depth;
+    // uniform grid over the scene box (trc_accel_build_grid)
+    bool grid_ok;
+    int32_t grid_dim[3];
+    float grid_lo[3], grid_cs[3], grid_inv[3];
+    std::vector<uint16_t> grid_off;    // cells + 1
+    std::vector<uint16_t> grid_list;
 };
 
 // surfaces -> boxes, scene box, centre, delta
@@ -125,6 +131,7 @@ static inline void trc_accel_build_surfaces(const trc_surface_desc *surfs, int n
         A.brute_root[k] = trc_f32_down(A.slo[k] - A.cen[k]);
         A.brute_root[3 + k] = trc_f32_up(A.shi[k] - A.cen[k]);
     }
+    A.grid_ok = false;
     A.sbox.assign(6 * (size_t)n, 0.0f);
     for (int i = 0; i < n; ++i)
         for (int k = 0; k < 3; ++k) {
@@ -136,6 +143,83 @@ static inline void trc_accel_build_surfaces(const trc_surface_desc *surfs, int n
                 A.sbox[6 * (size_t)i + 3 + k] = INFINITY;
             }
         }
+}
+
+// Uniform grid over the scene box for the DDA of trc_core.h (call after trc_accel_build_surfaces).  About four cells per
+// bounded surface, cubic cells, at most 8192 cells and 65535 list entries (uint16 offsets, everything stays in LDS);
+// the resolution is halved until that holds.  A surface is listed in every cell its box, inflated by 2*delta on top of
+// the delta already in sbox, overlaps.
+static inline void trc_accel_build_grid(trc_accel_host &A, int n_surf) {
+    A.grid_ok = false;
+    A.grid_off.clear();
+    A.grid_list.clear();
+    const size_t nb = A.brute_leaf.size();
+    if (nb == 0 || n_surf > 65535) return;
+    double lo[3], ext[3];
+    for (int k = 0; k < 3; ++k) { lo[k] = (double)A.brute_root[k]; ext[k] = (double)A.brute_root[3 + k] - lo[k]; }
+#ifndef TRC_GRID_DENSITY
+#define TRC_GRID_DENSITY 4.0
+#endif
+    double target = std::fmin(8192.0, std::fmax(8.0, TRC_GRID_DENSITY * (double)nb));
+    for (int attempt = 0; attempt < 12; ++attempt, target *= 0.5) {
+        // cubic cells of volume V/target over the axes that have an extent; flat axes get one cell
+        double emax = std::fmax(ext[0], std::fmax(ext[1], ext[2]));
+        if (!(emax > 0.0)) return;
+        double vol = 1.0;
+        int nax = 0;
+        for (int k = 0; k < 3; ++k) if (ext[k] > 1e-3 * emax) { vol *= ext[k]; ++nax; }
+        double cell = std::pow(vol / target, 1.0 / (double)(nax > 0 ? nax : 1));
+        int dim[3];
+        size_t cells = 1;
+        for (int k = 0; k < 3; ++k) {
+            int n = (ext[k] > 1e-3 * emax) ? (int)std::ceil(ext[k] / cell) : 1;
+            dim[k] = n < 1 ? 1 : (n > 128 ? 128 : n);
+            cells *= (size_t)dim[k];
+        }
+        if (cells > 8192) continue;
+        float cs[3], inv[3];
+        for (int k = 0; k < 3; ++k) {
+            double c = ext[k] / dim[k];
+            if (!(c > 0.0)) c = 1.0;
+            cs[k] = (float)c;
+            inv[k] = (float)(1.0 / c);
+        }
+        const double pad = 2.0 * (double)A.delta;
+        std::vector<uint32_t> count(cells + 1, 0u);
+        std::vector<int> range(6 * nb);
+        size_t total = 0;
+        for (size_t j = 0; j < nb; ++j) {
+            const float *b = &A.sbox[6 * (size_t)A.brute_leaf[j]];
+            size_t c = 1;
+            for (int k = 0; k < 3; ++k) {
+                int a = (int)std::floor(((double)b[k] - pad - lo[k]) / (double)cs[k]);
+                int z = (int)std::floor(((double)b[3 + k] + pad - lo[k]) / (double)cs[k]);
+                a = a < 0 ? 0 : (a >= dim[k] ? dim[k] - 1 : a);
+                z = z < 0 ? 0 : (z >= dim[k] ? dim[k] - 1 : z);
+                range[6 * j + k] = a; range[6 * j + 3 + k] = z;
+                c *= (size_t)(z - a + 1);
+            }
+            total += c;
+        }
+        if (total > 65535) continue;
+        for (size_t j = 0; j < nb; ++j)
+            for (int z = range[6 * j + 2]; z <= range[6 * j + 5]; ++z)
+                for (int y = range[6 * j + 1]; y <= range[6 * j + 4]; ++y)
+                    for (int x = range[6 * j]; x <= range[6 * j + 3]; ++x) count[((size_t)z * dim[1] + y) * dim[0] + x + 1]++;
+        for (size_t c = 0; c < cells; ++c) count[c + 1] += count[c];
+        A.grid_off.assign(cells + 1, 0);
+        for (size_t c = 0; c <= cells; ++c) A.grid_off[c] = (uint16_t)count[c];
+        A.grid_list.assign(total > 0 ? total : 1, 0);
+        std::vector<uint32_t> cur(count.begin(), count.end() - 1);
+        for (size_t j = 0; j < nb; ++j)      // ascending surface index inside every cell
+            for (int z = range[6 * j + 2]; z <= range[6 * j + 5]; ++z)
+                for (int y = range[6 * j + 1]; y <= range[6 * j + 4]; ++y)
+                    for (int x = range[6 * j]; x <= range[6 * j + 3]; ++x)
+                        A.grid_list[cur[((size_t)z * dim[1] + y) * dim[0] + x]++] = A.brute_leaf[j];
+        for (int k = 0; k < 3; ++k) { A.grid_dim[k] = dim[k]; A.grid_lo[k] = (float)lo[k]; A.grid_cs[k] = cs[k]; A.grid_inv[k] = inv[k]; }
+        A.grid_ok = true;
+        return;
+    }
 }
 
 // Kd-tree -> packed nodes relative to the centre (call after trc_accel_build_surfaces). Returns false when the

@@ -23,6 +23,7 @@
 #endif
 
 #define TRC_INF (__builtin_inf())
+#define TRC_INF32 (__builtin_inff())
 #define TRC_NAN (__builtin_nan(""))
 #define TRC_TWO_PI 6.283185307179586476925286766559
 #define TRC_PI 3.14159265358979323846264338327950288
@@ -668,6 +669,69 @@ TRC_HD bool trc_kd32_root(const float *root, const trc_ray32 &r, float *tmin, fl
     *tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
     *tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0001f + 1e-6f;
     return *tmax >= *tmin;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Uniform grid over the scene box (built by trc_bounds.h from the same inflated surface boxes): the streaming engine's
+// candidate search.  A ray visits the cells of a 3-D DDA in single precision; every surface whose box, inflated by a
+// further 2*delta, overlaps a cell is listed there, so that the float32 rounding of the walk (~1e-5 of the scene
+// extent, 400 times below delta) cannot lose a surface the exact ray touches.  Cell planes are recomputed from the
+// integer cell index at every step (no accumulated error).
+// ---------------------------------------------------------------------------------------------
+struct trc_grid_view {
+    const uint16_t *off;       // cells + 1 offsets into list
+    const uint16_t *list;      // surface indices
+    int32_t nx, ny, nz;
+    float lox, loy, loz;       // grid origin relative to cen
+    float csx, csy, csz;       // cell size
+    float ivx, ivy, ivz;       // 1 / cell size
+};
+
+struct trc_dda {
+    int32_t cx, cy, cz;
+    float tnx, tny, tnz;       // parameter at which the ray leaves the current cell along each axis
+};
+
+TRC_HD float trc_dda_plane_t(float lo, float cs, int32_t c, float o, float iv) {
+    // leaving plane of cell c along one axis: upper face when the ray goes up (iv >= 0), lower face otherwise
+    if (!(fabsf(iv) < 3.0e38f)) return TRC_INF32;      // parallel to the axis: never leaves
+    float plane = lo + (float)(c + (iv >= 0.0f ? 1 : 0)) * cs;
+    return (plane - o) * iv;
+}
+
+TRC_HD void trc_dda_start(const trc_grid_view &G, const trc_ray32 &r, float tmin, trc_dda *s) {
+    float px = r.ox + tmin * (1.0f / r.ix), py = r.oy + tmin * (1.0f / r.iy), pz = r.oz + tmin * (1.0f / r.iz);
+    int32_t cx = (int32_t)floorf((px - G.lox) * G.ivx), cy = (int32_t)floorf((py - G.loy) * G.ivy),
+            cz = (int32_t)floorf((pz - G.loz) * G.ivz);
+    s->cx = cx < 0 ? 0 : (cx >= G.nx ? G.nx - 1 : cx);
+    s->cy = cy < 0 ? 0 : (cy >= G.ny ? G.ny - 1 : cy);
+    s->cz = cz < 0 ? 0 : (cz >= G.nz ? G.nz - 1 : cz);
+    s->tnx = trc_dda_plane_t(G.lox, G.csx, s->cx, r.ox, r.ix);
+    s->tny = trc_dda_plane_t(G.loy, G.csy, s->cy, r.oy, r.iy);
+    s->tnz = trc_dda_plane_t(G.loz, G.csz, s->cz, r.oz, r.iz);
+}
+
+TRC_HD int32_t trc_dda_cell(const trc_grid_view &G, const trc_dda &s) { return (s.cz * G.ny + s.cy) * G.nx + s.cx; }
+
+// moves to the next cell; false when the ray has left the grid or passed tmax
+TRC_HD bool trc_dda_next(const trc_grid_view &G, const trc_ray32 &r, float tmax, trc_dda *s) {
+    if (s->tnx <= s->tny && s->tnx <= s->tnz) {
+        if (!(s->tnx <= tmax)) return false;
+        s->cx += (r.ix >= 0.0f) ? 1 : -1;
+        if ((uint32_t)s->cx >= (uint32_t)G.nx) return false;
+        s->tnx = trc_dda_plane_t(G.lox, G.csx, s->cx, r.ox, r.ix);
+    } else if (s->tny <= s->tnz) {
+        if (!(s->tny <= tmax)) return false;
+        s->cy += (r.iy >= 0.0f) ? 1 : -1;
+        if ((uint32_t)s->cy >= (uint32_t)G.ny) return false;
+        s->tny = trc_dda_plane_t(G.loy, G.csy, s->cy, r.oy, r.iy);
+    } else {
+        if (!(s->tnz <= tmax)) return false;
+        s->cz += (r.iz >= 0.0f) ? 1 : -1;
+        if ((uint32_t)s->cz >= (uint32_t)G.nz) return false;
+        s->tnz = trc_dda_plane_t(G.loz, G.csz, s->cz, r.oz, r.iz);
+    }
+    return true;
 }
 
 // float64 entry into the scene box and the relative single-precision ray from there
