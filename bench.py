@@ -13,8 +13,8 @@ Rays are sharded over the GPUs by stream id (weak scaling: every rank traces `--
 exchange is ONE all-reduce (RCCL) of the packed tally buffer at the end of the job.
 
 Prints ONE JSON line on rank 0: metric/value/unit per BASELINE.json, plus
-  roofline      algorithmic HBM bytes of the dominant kernel (k_trace_fast: 112 B per ray segment)
-                over its launch time measured with HIP events on the launch stream, against the 8 TB/s HBM peak
+  roofline      algorithmic HBM bytes of the fast engine (112 B per ray segment) over the time of its
+                kernels for one step, measured with HIP events on the launch stream, against the 8 TB/s HBM peak
   cpu_baseline  the oracle (NumPy restatement of the reference's algorithm = the reference's own CPU path, which
                 is NumPy too) timed on this host's cores (one process per core, independent batches) on a bounded
                 sample of the same workload, rank 0 at N=1 only, before the GPU part starts.
@@ -37,23 +37,27 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_worker(n_rays, seed):
-    """one CPU worker: the oracle, brute force like the reference's default path, on n_rays NSTTF source rays"""
+def cpu_worker(n_rays, seed, batches):
+    """one CPU worker: the oracle, brute force like the reference's default path, `batches` bundles of n_rays NSTTF source rays"""
     import numpy as N
     from tracer_amd import scenes
     from tracer_amd.scene import compile_scene
     from oracle import engine as oracle_engine
     plant, field, rec, src = scenes.nsttf_field()
     cs = compile_scene(plant)
-    b = scenes.nsttf_source(n_rays, src, seed=seed)
     t0 = time.time()
-    with N.errstate(all='ignore'):
-        ref = oracle_engine.trace_from_compiled(cs, b.source_args(), reps=100, min_energy=1e-10)
+    seg, kw = 0, 0.
+    for k in range(batches):
+        b = scenes.nsttf_source(n_rays, src, seed=seed, ray_offset=k * n_rays)
+        with N.errstate(all='ignore'):
+            ref = oracle_engine.trace_from_compiled(cs, b.source_args(), reps=100, min_energy=1e-10)
+        seg += int(ref['segments'])
+        kw += float(ref['absorbed'][-1] / 1e3) / batches
     dt = time.time() - t0
-    return dict(segments=int(ref['segments']), seconds=dt, receiver_kW=float(ref['absorbed'][-1] / 1e3))
+    return dict(segments=seg, seconds=dt, receiver_kW=kw)
 
 
-def cpu_baseline(n_rays, workers):
+def cpu_baseline(n_rays, workers, batches):
     """
     oracle (kind "port") timed on this host: `workers` independent processes, one core each, every one tracing its own
     batch of n_rays NSTTF source rays (the reference's multi-core driver, tracer_engine_mp.py, also runs independent
@@ -62,7 +66,7 @@ def cpu_baseline(n_rays, workers):
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
     t0 = time.time()
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(n_rays), str(99 + w)],
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(n_rays), str(99 + w), str(batches)],
                               stdout=subprocess.PIPE, env=env, cwd=ROOT) for w in range(workers)]
     res = []
     for p in procs:
@@ -76,9 +80,9 @@ def cpu_baseline(n_rays, workers):
     per_core = [r['segments'] / r['seconds'] / 1e6 for r in res]
     return dict(value=seg / slowest / 1e6, unit='Mray-bounces/s', cores=workers, kind='port',
                 per_core=sum(per_core) / len(per_core),
-                sample='NSTTF 218 heliostats + receiver, brute force (the reference default), %d processes x %d source rays '
-                       '(%d segments in total), slowest worker %.1f s, wall incl. start-up %.1f s'
-                       % (workers, n_rays, seg, slowest, wall),
+                sample='NSTTF 218 heliostats + receiver, brute force (the reference default), %d processes x %d bundles of %d '
+                       'source rays (%d segments in total), slowest worker %.1f s, wall incl. start-up %.1f s'
+                       % (workers, batches, n_rays, seg, slowest, wall),
                 receiver_kW=sum(r['receiver_kW'] for r in res) / len(res))
 
 
@@ -88,14 +92,17 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--rays', type=float, default=1e8, help='source rays per step per GPU')
-    ap.add_argument('--cpu-rays', type=int, default=250000, help='source rays per CPU baseline worker (0 = skip)')
+    ap.add_argument('--cpu-rays', type=int, default=250000, help='source rays per bundle of a CPU baseline worker (0 = skip)')
+    ap.add_argument('--cpu-batches', type=int, default=6, help='bundles traced by every CPU baseline worker')
     ap.add_argument('--cpu-workers', type=int, default=0, help='CPU baseline processes (0 = one per core, at most 16)')
-    ap.add_argument('--cpu-worker', nargs=2, metavar=('RAYS', 'SEED'), help=argparse.SUPPRESS)
-    ap.add_argument('--no-accel', action='store_true', help='brute force instead of the Kd-tree')
+    ap.add_argument('--cpu-worker', nargs=3, metavar=('RAYS', 'SEED', 'BATCHES'), help=argparse.SUPPRESS)
+    ap.add_argument('--no-accel', action='store_true', help='brute force instead of the accelerated candidate search')
+    ap.add_argument('--kernel', choices=['auto', 'stream', 'megakernel'], default='auto',
+                    help='fast-engine form: streaming kernels (default at this size) or the single persistent kernel')
     args = ap.parse_args()
 
     if args.cpu_worker:
-        print(json.dumps(cpu_worker(int(args.cpu_worker[0]), int(args.cpu_worker[1]))), flush=True)
+        print(json.dumps(cpu_worker(int(args.cpu_worker[0]), int(args.cpu_worker[1]), int(args.cpu_worker[2]))), flush=True)
         return
 
     rank = int(os.environ.get('RANK', '0'))
@@ -109,8 +116,8 @@ def main():
     if rank == 0 and world == 1 and args.cpu_rays > 0:
         # before anything initialises the GPU in this process (the workers are separate programs)
         workers = args.cpu_workers or min(os.cpu_count() or 1, 16)
-        log('timing the CPU baseline (oracle, %d processes x %d rays) ...' % (workers, args.cpu_rays))
-        cpu = cpu_baseline(args.cpu_rays, workers)
+        log('timing the CPU baseline (oracle, %d processes x %d x %d rays) ...' % (workers, args.cpu_batches, args.cpu_rays))
+        cpu = cpu_baseline(args.cpu_rays, workers, args.cpu_batches)
 
     import torch
     import torch.distributed as dist
@@ -151,7 +158,7 @@ def main():
         # stream ids: disjoint per (step, rank) -- results do not depend on the number of GPUs
         offset = (k * world + rank) * n
         b = scenes.nsttf_source(n, src, seed=2024, ray_offset=offset)
-        stats, _ = dev.trace_fast(b, 100, 1e-10, 2024, accel=accel)
+        stats, _ = dev.trace_fast(b, 100, 1e-10, 2024, accel=accel, stream={'auto': None, 'stream': True, 'megakernel': False}[args.kernel])
         return stats
 
     for k in range(args.warmup):
@@ -169,6 +176,7 @@ def main():
         st = step(args.warmup + k)
         seg += st.segments
         kms += st.kernel_ms
+        launches = st.launches
     # the single exchange of the job: sum the tally buffers of all ranks (per-surface energies, counts, flux map)
     reduce_scene_tallies(dev)
     barrier()
@@ -208,11 +216,17 @@ def main():
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'Sandia NSTTF heliostat field: 218 heliostats + receiver, Buie sunshape CSR 0.01, '
                                    '%.0e source rays per step per GPU, %s, reps=100, min_energy=1e-10; tallies + 50x50 '
-                                   'flux map + receiver hit list on device' % (n, 'Kd-tree (1065 nodes)' if accel else 'brute force'),
+                                   'flux map + receiver hit list on device'
+                                   % (n, 'accel=True (Kd-tree built on the host as in the reference; the device searches a '
+                                         'uniform grid over the same geometry boxes)' if accel else 'brute force'),
                        'rays_per_step_per_gpu': n, 'segments_per_step_per_gpu': seg / args.steps, 'accel': accel,
                        'parallelism': 'rays sharded by stream id over %d GPU(s), one all-reduce of tallies at the end' % world},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                         'traffic': traffic, 'kernel': 'k_trace_coop<512>', 'kernel_ms_per_launch': kms / args.steps,
+                         'traffic': traffic,
+                         'kernel': 'k_trace_coop<512>' if launches == 1 else
+                                   'fast engine, streaming form: k_s_gen + k_s_walk<512> + k_s_exact + k_s_tie + k_s_shade per '
+                                   'bounce (%d launches per step)' % launches,
+                         'kernel_ms_per_launch': kms / args.steps,
                          'algorithmic_bytes_per_launch': seg / args.steps * B_SEG},
             'check': {'receiver_kW': receiver_kw, 'receiver_hits_per_ray': h[218] / total_rays,
                       'heliostat_hits_per_ray': float(h[:218].sum()) / total_rays,

@@ -201,8 +201,10 @@ typedef struct trc_result trc_result;
 /* trace flags */
 #define TRC_TRACE_ACCEL 0x1        /* use the Kd-tree set on the scene (ray_tracer(accel=...)) */
 #define TRC_TRACE_KEEP_LAST 0x2    /* fast engine: keep rays still alive after `reps` bounces */
-#define TRC_TRACE_STREAM 0x4       /* fast engine: run the phases as separate kernels connected by HBM queues
-                                      (trc_stream.inc) instead of the persistent megakernel; same results */
+#define TRC_TRACE_STREAM 0x4       /* fast engine: always run the phases as separate kernels connected by HBM queues
+                                      (the default for calls of 262144 rays and more); same results */
+#define TRC_TRACE_MEGAKERNEL 0x8   /* fast engine: always run the persistent single-launch kernel (the default for
+                                      smaller calls); same results */
 
 typedef struct trc_trace_stats {
     int64_t segments;     /* sum over bounces of live rays (SURVEY 8(d) unit of work) */

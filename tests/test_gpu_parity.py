@@ -381,14 +381,19 @@ def test_full_size_properties(ctx):
     ue, ve = scenes.nsttf_fluxmap_edges()
     eng.set_fluxmap(218, ue, ve)
     out = {}
-    for accel in (False, True):
+    # brute force and accelerated on the streaming kernels (the default at this size), accelerated on the megakernel
+    for key, accel, kern in (('brute', False, 'auto'), ('mega', True, 'megakernel'), ('accel', True, 'auto')):
         eng.reset_tallies(); plant.reset_all_optics()
-        eng.ray_tracer(scenes.nsttf_source(n, src, seed=31), reps=100, min_energy=1e-10, tree=False, accel=accel, seed=31)
+        eng.ray_tracer(scenes.nsttf_source(n, src, seed=31), reps=100, min_energy=1e-10, tree=False, accel=accel, seed=31,
+                       fast_kernel=kern)
         a, r, h = eng.get_tallies()
-        out[accel] = (a.copy(), r.copy(), h.copy(), eng.get_fluxmap(218).copy(), dict(eng.stats))
-    (a0, r0, h0, f0, s0), (a1, r1, h1, f1, s1) = out[False], out[True]
+        out[key] = (a.copy(), r.copy(), h.copy(), eng.get_fluxmap(218).copy(), dict(eng.stats))
+    (a0, r0, h0, f0, s0), (a1, r1, h1, f1, s1) = out['brute'], out['accel']
     assert N.array_equal(h0, h1) and s0['segments'] == s1['segments']
     assert N.allclose(a0, a1, rtol=1e-10) and N.allclose(f0, f1, rtol=1e-9, atol=1e-9)
+    a2, r2, h2, f2, s2 = out['mega']
+    assert N.array_equal(h2, h1) and s2['segments'] == s1['segments'] and s2['launches'] == 1 and s1['launches'] > 1
+    assert N.allclose(a2, a1, rtol=1e-10) and N.allclose(f2, f1, rtol=1e-9, atol=1e-9)
     # energy: what a surface received is absorbed or reflected; reflected energy is received downstream or escapes
     assert N.all(a1 <= r1 * (1 + 1e-12))
     e_ray = 1000. * N.pi * src['radius'] ** 2 / n

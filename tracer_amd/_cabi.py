@@ -21,6 +21,7 @@ BUIE_LEN = 3 * (TRC_BUIE_NELEM + 1) + 6
 TRACE_ACCEL = 0x1
 TRACE_KEEP_LAST = 0x2
 TRACE_STREAM = 0x4
+TRACE_MEGAKERNEL = 0x8
 # surface flags
 SURF_CAPTURE_HITS = 0x1
 

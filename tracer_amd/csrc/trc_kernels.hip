@@ -856,6 +856,7 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
     }
 }
 
+#define TRC_STREAM_MIN_RAYS 262144
 #include "trc_stream.inc"
 
 static void scene_free_stream_ws(trc_scene *sc) {
@@ -1735,10 +1736,18 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
             P.lds_scene = (lds + b_scene <= LDS_MAX) ? 1 : 0;
             if (P.lds_scene) lds += b_scene;
         }
-        static int stream_env = -1;
-        if (stream_env < 0) { const char *ev = getenv("TRC_FAST_STREAM"); stream_env = (ev && atoi(ev)) ? 1 : 0; }
-        // on request: the streaming engine (phases as separate kernels connected by HBM queues, trc_stream.inc)
-        const bool use_stream = m32 && ((flags & TRC_TRACE_STREAM) || stream_env) && n >= 64;
+        // Large calls run the streaming engine (phases as separate kernels connected by HBM queues, trc_stream.inc);
+        // small ones the persistent megakernel, which needs one launch and no workspace.  TRC_TRACE_STREAM /
+        // TRC_TRACE_MEGAKERNEL (or TRC_FAST_STREAM=1 / 0) force one or the other.
+        static int stream_env = -2;
+        if (stream_env == -2) { const char *ev = getenv("TRC_FAST_STREAM"); stream_env = ev ? (atoi(ev) ? 1 : 0) : -1; }
+        const bool want_accel = (flags & TRC_TRACE_ACCEL) != 0;
+        int stream_mode = 0;
+        size_t stream_lds = 0;
+        const bool stream_ok = !mode_env && n >= 64 && stream_plan(sc, want_accel, &stream_mode, &stream_lds);
+        const bool force_stream = (flags & TRC_TRACE_STREAM) || stream_env == 1;
+        const bool force_mega = (flags & TRC_TRACE_MEGAKERNEL) || stream_env == 0;
+        const bool use_stream = stream_ok && (force_stream || (!force_mega && n >= TRC_STREAM_MIN_RAYS));
         if (use_stream) {
             if (!sc->stream_ws) {
                 sc->stream_ws = new (std::nothrow) StreamWs();
@@ -1746,7 +1755,7 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
                 memset(sc->stream_ws, 0, sizeof(StreamWs));
             }
             double segd = 0, hitd = 0;
-            if ((st = stream_trace(sc, P, accel, *sc->stream_ws, &s, &segd, &hitd))) break;
+            if ((st = stream_trace(sc, P, want_accel, *sc->stream_ws, &s, &segd, &hitd))) break;
         } else {
         void (*kern)(FastParams) = nullptr;
         if (m32) kern = threads == 1024 ? k_trace_coop<1024> : (threads == 768 ? k_trace_coop<768> : (threads == 512 ? k_trace_coop<512> : k_trace_coop<256>));

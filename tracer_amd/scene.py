@@ -250,12 +250,12 @@ class DeviceScene(object):
                                ref_index=cols.get('ref_index'), wavelength=cols.get('wavelength'))
         return rays, None, n, None, 0, cols
 
-    def trace_fast(self, bundle, reps, min_energy, seed, accel=False, keep_last=False, stream=False):
+    def trace_fast(self, bundle, reps, min_energy, seed, accel=False, keep_last=False, stream=None):
         rays, src, n, src_seed, off, keep = self._bundle_args(bundle)
         if src_seed is not None:
             seed = src_seed
         flags = (_cabi.TRACE_ACCEL if accel else 0) | (_cabi.TRACE_KEEP_LAST if keep_last else 0) | \
-            (_cabi.TRACE_STREAM if stream else 0)
+            (0 if stream is None else (_cabi.TRACE_STREAM if stream else _cabi.TRACE_MEGAKERNEL))
         stats = _cabi.TraceStats()
         last = None
         last_cols = None

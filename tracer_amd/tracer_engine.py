@@ -91,6 +91,7 @@ class TracerEngine(object):
         engine = kwargs.pop('engine', 'auto')
         seed = kwargs.pop('seed', None)
         hit_capacity = kwargs.pop('hit_capacity', None)
+        fast_kernel = kwargs.pop('fast_kernel', 'auto')     # 'auto' | 'stream' | 'megakernel' (fast engine only)
         if seed is None:
             seed = rng.next_seed()
         self.reps = reps
@@ -124,20 +125,21 @@ class TracerEngine(object):
         if engine == 'auto':
             engine = 'ordered' if (tree or dev.compiled.splits) else 'fast'
         if engine == 'fast':
-            return self._trace_fast(dev, bundle, reps, min_energy, seed, bool(accel), hit_capacity)
+            return self._trace_fast(dev, bundle, reps, min_energy, seed, bool(accel), hit_capacity, fast_kernel)
         if engine == 'ordered':
             return self._trace_ordered(dev, bundle, reps, min_energy, seed, bool(accel), tree)
         raise ValueError("unknown engine %r" % (engine,))
 
     # -- fast engine --------------------------------------------------------------------------------
-    def _trace_fast(self, dev, bundle, reps, min_energy, seed, accel, hit_capacity):
+    def _trace_fast(self, dev, bundle, reps, min_energy, seed, accel, hit_capacity, fast_kernel='auto'):
         n = bundle.get_num_rays()
         capture = any(dev.compiled.capture)
         if capture:
             dev.set_hit_capacity(hit_capacity if hit_capacity is not None else 2 * n + 1024)
             dev.lib.trc_scene_clear_hits(dev.handle)
         t0 = time.time()
-        stats, last = dev.trace_fast(bundle, reps, min_energy, seed, accel=accel, keep_last=True)
+        stream = {'auto': None, 'stream': True, 'megakernel': False}[fast_kernel]
+        stats, last = dev.trace_fast(bundle, reps, min_energy, seed, accel=accel, keep_last=True, stream=stream)
         wall = time.time() - t0
         self._set_stats(stats, wall, 'fast')
         if stats.hits_dropped:
