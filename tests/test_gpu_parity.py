@@ -8,6 +8,7 @@ of up to a few hundred metres is asserted, and hit/miss patterns, parents and or
 """
 import ctypes as C
 
+import os
 import numpy as N
 import pytest
 
@@ -358,6 +359,17 @@ def test_kd_accel_equals_brute_and_reference(ctx):
     a, r, h = dev.get_tallies()
     dev.close()
     assert N.array_equal(h, tl_b[2]) and N.allclose(a, tl_b[0], rtol=1e-12, atol=1e-9)
+    # a candidate queue that is too small: the bounce is run again with twice the room, same results
+    os.environ['TRC_STREAM_Q3_ENTRIES'] = '2048'
+    try:
+        dev = DeviceScene(cs, ctx)
+        dev.set_kdtree(kd)
+        st_small, _ = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e), 100, 1e-10, 1, accel=True, stream=True)
+        a_s, r_s, h_s = dev.get_tallies()
+        dev.close()
+    finally:
+        del os.environ['TRC_STREAM_Q3_ENTRIES']
+    assert N.array_equal(h_s, tl_b[2]) and N.allclose(a_s, tl_b[0], rtol=1e-12, atol=1e-9) and st_small.segments == st.segments
     for accel in (True, False):      # streaming engine, with the tree and with the single-leaf brute form
         dev = DeviceScene(cs, ctx)
         dev.set_kdtree(kd)
