@@ -70,7 +70,7 @@ int hc_shade(const trc_surface_desc *s, const double *extra, long n, const doubl
 int hc_source(const trc_source_desc *src, long n, uint64_t seed, uint64_t offset, double *x, double *y, double *z, double *dx,
               double *dy, double *dz) {
     for (long i = 0; i < n; ++i)
-        trc_source_ray(src, src->buie, seed, offset + (uint64_t)i, &x[i], &y[i], &z[i], &dx[i], &dy[i], &dz[i]);
+        trc_source_ray(src, src->buie, nullptr, seed, offset + (uint64_t)i, &x[i], &y[i], &z[i], &dx[i], &dy[i], &dz[i]);
     return 0;
 }
 

@@ -145,7 +145,7 @@ static inline void trc_accel_build_surfaces(const trc_surface_desc *surfs, int n
         }
 }
 
-// Uniform grid over the scene box for the DDA of trc_core.h (call after trc_accel_build_surfaces).  About four cells per
+// Uniform grid over the scene box for the DDA of trc_core.h (call after trc_accel_build_surfaces).  About two cells per
 // bounded surface, cubic cells, at most 8192 cells and 65535 list entries (uint16 offsets, everything stays in LDS);
 // the resolution is halved until that holds.  A surface is listed in every cell its box, inflated by 2*delta on top of
 // the delta already in sbox, overlaps.
@@ -158,7 +158,7 @@ static inline void trc_accel_build_grid(trc_accel_host &A, int n_surf) {
     double lo[3], ext[3];
     for (int k = 0; k < 3; ++k) { lo[k] = (double)A.brute_root[k]; ext[k] = (double)A.brute_root[3 + k] - lo[k]; }
 #ifndef TRC_GRID_DENSITY
-#define TRC_GRID_DENSITY 4.0
+#define TRC_GRID_DENSITY 2.0
 #endif
     double target = std::fmin(8192.0, std::fmax(8.0, TRC_GRID_DENSITY * (double)nb));
     for (int attempt = 0; attempt < 12; ++attempt, target *= 0.5) {

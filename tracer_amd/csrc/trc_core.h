@@ -27,6 +27,8 @@
 #define TRC_NAN (__builtin_nan(""))
 #define TRC_TWO_PI 6.283185307179586476925286766559
 #define TRC_PI 3.14159265358979323846264338327950288
+#define TRC_BUIE_TABLE (3 * (TRC_BUIE_NELEM + 1) + 6)     /* doubles in trc_source_desc.buie */
+#define TRC_BUIE_STAGED (TRC_BUIE_TABLE + 3)              /* + trc_buie_aureole_consts, in the kernels' LDS copies */
 
 // ---------------------------------------------------------------------------------------------
 // Compact per-surface record used by the kernels (LDS-staged).  Layout in doubles:
@@ -119,6 +121,24 @@ TRC_HD void trc_uniform_pair(uint64_t seed, uint64_t rid, uint32_t event, uint32
 
 // sine and cosine of the same angle with one argument reduction
 TRC_HD void trc_sincos(double x, double *s, double *c) { sincos(x, s, c); }
+
+// sin and cos of 2*pi*u for u in [0,1): on the device through sincospi (exact argument reduction, cheaper than reducing
+// the rounded product 2*pi*u); the two forms agree to a few units of the last place
+TRC_HD void trc_sincos_2pi(double u, double *s, double *c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincospi(2.0 * u, s, c);
+#else
+    sincos(TRC_TWO_PI * u, s, c);
+#endif
+}
+
+// sin and cos of a small angle (|x| <= 0.05: the Buie polar angle is below 43.6 mrad) by their Taylor series: the
+// first neglected terms are x^11/11! and x^12/12!, below 1e-21 relative -- full double precision without range reduction
+TRC_HD void trc_sincos_small(double x, double *s, double *c) {
+    double x2 = x * x;
+    *s = x * (1.0 + x2 * (-1.0 / 6.0 + x2 * (1.0 / 120.0 + x2 * (-1.0 / 5040.0 + x2 * (1.0 / 362880.0)))));
+    *c = 1.0 + x2 * (-0.5 + x2 * (1.0 / 24.0 + x2 * (-1.0 / 720.0 + x2 * (1.0 / 40320.0 + x2 * (-1.0 / 3628800.0)))));
+}
 
 // Box-Muller: two independent N(0,1) from two uniforms (1-u0 keeps the log argument in (0,1])
 TRC_HD void trc_normal_pair(double u0, double u1, double *g0, double *g1) {
@@ -1147,11 +1167,22 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
 // S1..S3 -- sources.  One ray from its four uniforms.
 // ---------------------------------------------------------------------------------------------
 // Buie sunshape polar angle from its uniform (sources.py:364-377).  tab: trc_source_desc.buie
-TRC_HD double trc_buie_theta(const double *tab, double Rv) {
+// ray-independent parts of the aureole inversion (:377); kernels compute them once per block
+TRC_HD void trc_buie_aureole_consts(const double *tab, double *c) {
+    const double *sc = tab + 3 * (TRC_BUIE_NELEM + 1);
+    double I_dni = sc[0], gamma = sc[1], kappa = sc[2], theta_dni = sc[3], theta_tot = sc[4];
+    double gp2 = gamma + 2.0;
+    c[0] = gp2 / (pow(10.0, 3.0 * gamma) * exp(kappa)) * I_dni - pow(theta_dni, gp2);
+    c[1] = pow(theta_tot, gp2);
+    c[2] = 1.0 / gp2;
+}
+
+// aur: the three values of trc_buie_aureole_consts, or null to compute them here
+TRC_HD double trc_buie_theta(const double *tab, const double *aur, double Rv) {
     const int NE = TRC_BUIE_NELEM;
     const double *theta = tab, *g = tab + (NE + 1), *cdf = tab + 2 * (NE + 1);
     const double *sc = tab + 3 * (NE + 1);
-    double I_dni = sc[0], gamma = sc[1], kappa = sc[2], theta_dni = sc[3], theta_tot = sc[4];
+    double I_dni = sc[0];
     bool csr_pos = sc[5] != 0.0;
     if (Rv < cdf[NE]) {
         int lo = 0, hi = NE;                       // largest i with cdf[i] <= R
@@ -1166,27 +1197,30 @@ TRC_HD double trc_buie_theta(const double *tab, double Rv) {
         return -(-A * theta[i + 1] + B * theta[i] + sqrt(w * w + Cq * (B - A))) / (A - B);     // :371
     }
     if (!csr_pos) return 0.0;                      // thetas stay 0 (sources.py:364, :376)
-    double gp2 = gamma + 2.0;                      // aureole, :377
-    double base = (Rv - 1.0) * (gp2 / (pow(10.0, 3.0 * gamma) * exp(kappa)) * I_dni - pow(theta_dni, gp2)) +
-                  Rv * pow(theta_tot, gp2);
-    return pow(base, 1.0 / gp2);
+    double c[3];                                   // aureole, :377
+    if (aur) { c[0] = aur[0]; c[1] = aur[1]; c[2] = aur[2]; }
+    else trc_buie_aureole_consts(tab, c);
+    double base = (Rv - 1.0) * c[0] + Rv * c[1];
+    return pow(base, c[2]);
 }
 
-TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint64_t seed, uint64_t rid,
-                           double *px, double *py, double *pz, double *dx, double *dy, double *dz) {
+// buie: the table of the descriptor (or its LDS copy); aur: trc_buie_aureole_consts of it, or null.
+// KIND >= 0 promises src->kind == KIND (the streaming engine compiles the Buie disc on its own: 158 instead of 237
+// VGPRs); KIND < 0 reads the kind from the descriptor.
+template <int KIND>
+TRC_HD void trc_source_ray_t(const trc_source_desc *src, const double *buie, const double *aur, uint64_t seed, uint64_t rid,
+                             double *px, double *py, double *pz, double *dx, double *dy, double *dz) {
     double u0, u1, u2, u3;
     trc_uniform_pair(seed, rid, 0, 0, &u0, &u1);
     trc_uniform_pair(seed, rid, 0, 1, &u2, &u3);
     double lx, ly, lz = 0.0, ax, ay, az;
     const double *p = src->p;
-#ifdef TRC_EXPERIMENT_BUIE_ONLY
-    if (src->kind != TRC_SRC_BUIE_DISK) __builtin_unreachable();
-#endif
-    switch (src->kind) {
+    const int kind = KIND >= 0 ? KIND : src->kind;
+    switch (kind) {
     case TRC_SRC_VF_CYLINDER:           // draws: zs, phi_s, dir phi, dir R (sources.py:737-746)
     case TRC_SRC_VF_FRUSTUM: {          // draws: dir phi, dir R, R, phi_s (sources.py:670-685)
         double phi, slope, sign, fx, fy, fz;
-        if (src->kind == TRC_SRC_VF_CYLINDER) {
+        if (kind == TRC_SRC_VF_CYLINDER) {
             lz = p[1] * u0 - p[1] / 2.0;
             phi = p[2] + (p[3] - p[2]) * u1;
             { double sp, cp; trc_sincos(phi, &sp, &cp); lx = p[0] * cp; ly = p[0] * sp; }
@@ -1235,13 +1269,13 @@ TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint6
         break;
     }
     case TRC_SRC_BUIE_DISK: {           // draws: xv1, phiv, R_theta, xi (sources.py:431-434, :365, :380)
-        double r = p[0] * sqrt(u0), ph = TRC_TWO_PI * u1;
+        double r = p[0] * sqrt(u0);
         double sph, cph, st, ct, sxi, cxi;
-        trc_sincos(ph, &sph, &cph);
+        trc_sincos_2pi(u1, &sph, &cph);
         lx = r * cph; ly = r * sph;
-        double th = trc_buie_theta(buie, u2), xi = TRC_TWO_PI * u3;
-        trc_sincos(th, &st, &ct);
-        trc_sincos(xi, &sxi, &cxi);
+        double th = trc_buie_theta(buie, aur, u2);
+        trc_sincos_small(th, &st, &ct);
+        trc_sincos_2pi(u3, &sxi, &cxi);
         ax = cxi * st; ay = sxi * st; az = ct;
         break;
     }
@@ -1253,16 +1287,16 @@ TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint6
     }
     default: {                          // TRC_SRC_BUIE_RECT (sources.py:485-486)
         lx = p[0] * (u0 - 0.5); ly = p[1] * (u1 - 0.5);
-        double th = trc_buie_theta(buie, u2), xi = TRC_TWO_PI * u3;
+        double th = trc_buie_theta(buie, aur, u2);
         double st, ct, sxi, cxi;
-        trc_sincos(th, &st, &ct);
-        trc_sincos(xi, &sxi, &cxi);
+        trc_sincos_small(th, &st, &ct);
+        trc_sincos_2pi(u3, &sxi, &cxi);
         ax = cxi * st; ay = sxi * st; az = ct;
         break;
     }
     }
     const double *rp = src->rot_pos, *rd = src->rot_dir;
-    if (src->kind >= TRC_SRC_VF_CYLINDER) {      // wall emitters have a third local coordinate
+    if (kind >= TRC_SRC_VF_CYLINDER) {      // wall emitters have a third local coordinate
         *px = rp[0] * lx + rp[1] * ly + rp[2] * lz + src->center[0];
         *py = rp[3] * lx + rp[4] * ly + rp[5] * lz + src->center[1];
         *pz = rp[6] * lx + rp[7] * ly + rp[8] * lz + src->center[2];
@@ -1274,6 +1308,11 @@ TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, uint6
     *dx = rd[0] * ax + rd[1] * ay + rd[2] * az;
     *dy = rd[3] * ax + rd[4] * ay + rd[5] * az;
     *dz = rd[6] * ax + rd[7] * ay + rd[8] * az;
+}
+
+TRC_HD void trc_source_ray(const trc_source_desc *src, const double *buie, const double *aur, uint64_t seed, uint64_t rid,
+                           double *px, double *py, double *pz, double *dx, double *dy, double *dz) {
+    trc_source_ray_t<-1>(src, buie, aur, seed, rid, px, py, pz, dx, dy, dz);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -501,12 +501,13 @@ __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *re
 }
 
 // fresh ray for a lane: from the source descriptor or from the given bundle
+template <int KIND = -1>
 __device__ __forceinline__ void fast_new_ray(const FastParams &P, const double *buie, long long id, double &px, double &py,
                                              double &pz, double &dx, double &dy, double &dz, double &e, double &ref, double &wl,
                                              unsigned long long &rid) {
     rid = P.rid ? P.rid[id] : (P.ray_offset + (unsigned long long)id);
     if (P.src) {
-        trc_source_ray(P.src, buie, P.seed, rid, &px, &py, &pz, &dx, &dy, &dz);
+        trc_source_ray_t<KIND>(P.src, buie, buie ? buie + TRC_BUIE_TABLE : nullptr, P.seed, rid, &px, &py, &pz, &dx, &dy, &dz);
         e = P.src->energy; ref = 1.0; wl = 0.0;
     } else {
         px = P.x[id]; py = P.y[id]; pz = P.z[id];
@@ -545,10 +546,12 @@ __global__ __launch_bounds__(THREADS) void k_trace_fast(FastParams P) {
     }
     const double *buie = nullptr;
     if (P.src) {
-        const int NB = 3 * (TRC_BUIE_NELEM + 1) + 6;
-        double *l_buie = cursor; cursor += NB;
-        if (P.src->kind == TRC_SRC_BUIE_DISK || P.src->kind == TRC_SRC_BUIE_RECT)
+        const int NB = TRC_BUIE_TABLE;
+        double *l_buie = cursor; cursor += TRC_BUIE_STAGED;
+        if (P.src->kind == TRC_SRC_BUIE_DISK || P.src->kind == TRC_SRC_BUIE_RECT) {
             for (int i = tid; i < NB; i += THREADS) l_buie[i] = P.src->buie[i];
+            if (tid == 0) trc_buie_aureole_consts(P.src->buie, l_buie + NB);
+        }
         buie = l_buie;
     }
     double *l_tally = cursor;
@@ -651,10 +654,12 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
     double *cursor = lds;
     const double *buie = nullptr;
     if (P.src) {
-        const int NB = 3 * (TRC_BUIE_NELEM + 1) + 6;
-        double *l_buie = cursor; cursor += NB;
-        if (P.src->kind == TRC_SRC_BUIE_DISK || P.src->kind == TRC_SRC_BUIE_RECT)
+        const int NB = TRC_BUIE_TABLE;
+        double *l_buie = cursor; cursor += TRC_BUIE_STAGED;
+        if (P.src->kind == TRC_SRC_BUIE_DISK || P.src->kind == TRC_SRC_BUIE_RECT) {
             for (int i = tid; i < NB; i += THREADS) l_buie[i] = P.src->buie[i];
+            if (tid == 0) trc_buie_aureole_consts(P.src->buie, l_buie + NB);
+        }
         buie = l_buie;
     }
     double *l_tally = cursor;
@@ -870,14 +875,15 @@ __global__ __launch_bounds__(256) void k_source_generate(const trc_source_desc *
                                                          unsigned long long seed, unsigned long long offset,
                                                          double *x, double *y, double *z, double *dx, double *dy,
                                                          double *dz, double *e, uint64_t *rid) {
-    __shared__ double l_buie[3 * (TRC_BUIE_NELEM + 1) + 6];
-    for (int i = threadIdx.x; i < 3 * (TRC_BUIE_NELEM + 1) + 6; i += blockDim.x) l_buie[i] = src->buie[i];
+    __shared__ double l_buie[TRC_BUIE_STAGED];
+    for (int i = threadIdx.x; i < TRC_BUIE_TABLE; i += blockDim.x) l_buie[i] = src->buie[i];
+    if (threadIdx.x == 0 && (src->kind == TRC_SRC_BUIE_DISK || src->kind == TRC_SRC_BUIE_RECT)) trc_buie_aureole_consts(src->buie, l_buie + TRC_BUIE_TABLE);
     __syncthreads();
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         unsigned long long r = offset + (unsigned long long)i;
         double px, py, pz, qx, qy, qz;
-        trc_source_ray(src, l_buie, seed, r, &px, &py, &pz, &qx, &qy, &qz);
+        trc_source_ray(src, l_buie, l_buie + TRC_BUIE_TABLE, seed, r, &px, &py, &pz, &qx, &qy, &qz);
         x[i] = px; y[i] = py; z[i] = pz;
         dx[i] = qx; dy[i] = qy; dz[i] = qz;
         e[i] = src->energy;
@@ -1700,7 +1706,7 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
             for (int i = 0; i < S; ++i) if (sc->surfs[i].flags & TRC_SURF_CAPTURE_HITS) P.capture = 1;
 
         const bool accel = sc->has_kd && (flags & TRC_TRACE_ACCEL);
-        size_t b_buie = src ? (size_t)(3 * (TRC_BUIE_NELEM + 1) + 6) * 8 : 0;
+        size_t b_buie = src ? (size_t)TRC_BUIE_STAGED * 8 : 0;
         size_t b_tally = (size_t)(3 * S + 2) * 8;
         static int threads_env = -1, mode_env = -1;
         if (threads_env < 0) { const char *ev = getenv("TRC_FAST_THREADS"); threads_env = ev ? atoi(ev) : 0; }
@@ -1755,7 +1761,7 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
                 memset(sc->stream_ws, 0, sizeof(StreamWs));
             }
             double segd = 0, hitd = 0;
-            if ((st = stream_trace(sc, P, want_accel, *sc->stream_ws, &s, &segd, &hitd))) break;
+            if ((st = stream_trace(sc, P, want_accel, src ? src->kind : -1, *sc->stream_ws, &s, &segd, &hitd))) break;
         } else {
         void (*kern)(FastParams) = nullptr;
         if (m32) kern = threads == 1024 ? k_trace_coop<1024> : (threads == 768 ? k_trace_coop<768> : (threads == 512 ? k_trace_coop<512> : k_trace_coop<256>));
