@@ -52,3 +52,7 @@ dev2.set_kdtree(kd)
 dev2.set_fluxmap(218, ue, ve)
 dev2.set_hit_capacity(int(0.08 * n * 4) + 4096)
 run('g. nsttf kd, fused, fluxmap + hit capture', dev2, srcb, True)
+dev3 = DeviceScene(cs, ctx)
+dev3.set_kdtree(kd)
+dev3.set_fluxmap(218, ue, ve)
+run('h. nsttf kd, fused, fluxmap only', dev3, srcb, True)

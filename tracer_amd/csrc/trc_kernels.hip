@@ -109,6 +109,7 @@ struct DScene {
     // tallies: [absorbed S | received S | count S | segments, hits | flux bins ...]
     double *tally;
     // flux maps
+    int32_t n_fm, n_fm_edges;   // flux maps and the total length of their edge arrays
     const int32_t *fm_of_surf;  // n_surf, -1 = none
     const FluxMapDev *fms;
     const double *fm_edges;
@@ -142,7 +143,7 @@ struct trc_scene {
     int32_t *d_a_unbounded;
     uint16_t *d_a_bleaf;
     uint16_t *d_a_goff, *d_a_glist;
-    struct StreamWs *stream_ws;   // workspace of the streaming fast engine (trc_stream.inc), allocated on first use
+    struct StreamEngine *stream_eng;   // slots of the streaming fast engine (trc_stream.inc), allocated on first use
     double *d_tally;
     int64_t tally_n;
     std::vector<FluxMapDev> fms_h;
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
 #include "trc_stream.inc"
 
 static void scene_free_stream_ws(trc_scene *sc) {
-    if (sc->stream_ws) { stream_ws_free(*sc->stream_ws); delete sc->stream_ws; sc->stream_ws = nullptr; }
+    if (sc->stream_eng) { stream_engine_free(sc->stream_eng); sc->stream_eng = nullptr; }
 }
 
 // ================================================================================================
@@ -1586,6 +1587,7 @@ static DScene make_dscene(trc_scene *sc) {
     for (int i = 0; i < 3; ++i) { d.a_cen[i] = sc->accel.cen[i]; d.a_slo[i] = sc->accel.slo[i]; d.a_shi[i] = sc->accel.shi[i]; }
     d.tally = sc->d_tally;
     d.fm_of_surf = sc->d_fm_of_surf; d.fms = sc->d_fms; d.fm_edges = sc->d_fm_edges;
+    d.n_fm = (int32_t)sc->fms_h.size(); d.n_fm_edges = (int32_t)sc->fm_edges_h.size();
     d.counters = sc->d_counters; d.energy_left = sc->d_energy_left;
     d.hit_cap = sc->hit_cap; d.h_surf = sc->d_h_surf;
     d.h_eabs = sc->d_h[0]; d.h_ein = sc->d_h[1]; d.h_px = sc->d_h[2]; d.h_py = sc->d_h[3]; d.h_pz = sc->d_h[4];
@@ -1755,13 +1757,13 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         const bool force_mega = (flags & TRC_TRACE_MEGAKERNEL) || stream_env == 0;
         const bool use_stream = stream_ok && (force_stream || (!force_mega && n >= TRC_STREAM_MIN_RAYS));
         if (use_stream) {
-            if (!sc->stream_ws) {
-                sc->stream_ws = new (std::nothrow) StreamWs();
-                if (!sc->stream_ws) { st = trc_fail(TRC_ERR_NOMEM, "out of host memory"); break; }
-                memset(sc->stream_ws, 0, sizeof(StreamWs));
+            if (!sc->stream_eng) {
+                sc->stream_eng = new (std::nothrow) StreamEngine();
+                if (!sc->stream_eng) { st = trc_fail(TRC_ERR_NOMEM, "out of host memory"); break; }
+                memset(sc->stream_eng, 0, sizeof(StreamEngine));
             }
             double segd = 0, hitd = 0;
-            if ((st = stream_trace(sc, P, want_accel, src ? src->kind : -1, *sc->stream_ws, &s, &segd, &hitd))) break;
+            if ((st = stream_trace(sc, P, want_accel, src ? src->kind : -1, *sc->stream_eng, &s, &segd, &hitd))) break;
         } else {
         void (*kern)(FastParams) = nullptr;
         if (m32) kern = threads == 1024 ? k_trace_coop<1024> : (threads == 768 ? k_trace_coop<768> : (threads == 512 ? k_trace_coop<512> : k_trace_coop<256>));
