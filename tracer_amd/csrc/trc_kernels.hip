@@ -154,7 +154,9 @@ struct trc_scene {
     double *d_fm_edges;
     unsigned long long *d_counters;
     double *d_energy_left;
-    int64_t hit_cap;
+    int64_t hit_cap;      // entries allocated: the capacity asked for + TRC_HIT_SLACK
+    int64_t hit_cap_user;
+    uint32_t hit_epoch;   // bumped whenever the cursor is reset: chunks left open by earlier launches are stale
     int32_t *d_h_surf;
     double *d_h[8];
 };
@@ -223,11 +225,77 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Queue append without a hot atomic: a wave reserves CHUNK entries at a time from the global counter (one atomic per
+// chunk; a single word sustains only ~88 returning atomics per microsecond) and fills them; what is left of a chunk
+// when the wave moves on is marked invalid and skipped by the consumers.  base/used are wave-uniform.
+#define SQ_CHUNK 256
+#define SQ_INVALID 0xFFFFFFFFu
+
+struct WaveChunk {
+    unsigned long long base;
+    unsigned used;
+    unsigned open;
+};
+
+__device__ __forceinline__ WaveChunk chunk_init() {
+    WaveChunk c;
+    c.base = 0; c.used = SQ_CHUNK; c.open = 0;
+    return c;
+}
+
+// after a chunk_append made by a subset of the lanes: every lane takes the state of `lane` (one that took part)
+__device__ __forceinline__ void chunk_rebroadcast(WaveChunk &c, int lane) {
+    c.base = __shfl(c.base, lane, 64);
+    c.used = (unsigned)__shfl((int)c.used, lane, 64);
+    c.open = (unsigned)__shfl((int)c.open, lane, 64);
+}
+
+// marks the unused tail of the current chunk invalid (wave-uniform call)
+__device__ __forceinline__ void chunk_close(WaveChunk &c, uint32_t *tag, long long cap) {
+    if (c.open) {
+        for (unsigned k = c.used + lane_id(); k < SQ_CHUNK; k += 64)
+            if ((long long)(c.base + k) < cap) tag[c.base + k] = SQ_INVALID;
+    }
+    c.open = 0;
+    c.used = SQ_CHUNK;
+}
+
+// returns this lane's index in the queue (meaningful when `want`).  Call it with the whole wave, or -- inside a
+// divergent region -- re-broadcast the chunk afterwards from a lane that took part (chunk_rebroadcast).  A request that does not fit the
+// open chunk fills it up and continues in a new one, so entries are only wasted at the end of a kernel (< CHUNK per wave).
+__device__ __forceinline__ unsigned long long chunk_append(unsigned long long *counter, WaveChunk &c, bool want, uint32_t *tag,
+                                                           long long cap) {
+    unsigned long long m = __ballot(want);
+    if (!m) return 0;
+    const unsigned need = (unsigned)__popcll(m);
+    const unsigned rank = (unsigned)__popcll(m & ((1ull << lane_id()) - 1ull));
+    unsigned long long idx;
+    if (c.used + need > SQ_CHUNK) {
+        const unsigned rem = c.open ? SQ_CHUNK - c.used : 0u;
+        const unsigned long long old_pos = c.base + c.used;
+        const int leader = __ffsll((long long)m) - 1;          // a lane that is certainly active here
+        unsigned long long b = 0;
+        if ((int)lane_id() == leader) b = atomicAdd(counter, (unsigned long long)SQ_CHUNK);
+        c.base = __shfl(b, leader, 64);
+        c.used = need - rem;
+        c.open = 1;
+        idx = rank < rem ? old_pos + rank : c.base + (rank - rem);
+    } else {
+        idx = c.base + c.used + rank;
+        c.used += need;
+    }
+    (void)tag; (void)cap;
+    return idx;
+}
+
+#define SHADE_MAX_WAVES 4096     /* waves of one k_s_shade launch (at most n_cu * 4 workgroups of 4 waves, n_cu <= 256) */
+#define TRC_HIT_SLACK (4ll * SHADE_MAX_WAVES * SQ_CHUNK + 64)   /* unused entries the open chunks of two slots can hold */
+
 // per-hit bookkeeping shared by both engines: tallies, flux map, hit capture
 template <bool LDS_TALLY>
 __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, int s, double e_in,
                                            double e_abs, double hx, double hy, double hz, double dx,
-                                           double dy, double dz, bool capture_enabled) {
+                                           double dy, double dz, bool capture_enabled, WaveChunk *hc = nullptr) {
     const int S = sc.n_surf;
     if (LDS_TALLY) {
         atomicAdd(&lds_tally[s], e_abs);
@@ -247,7 +315,22 @@ __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, 
         int iv = trc_bin_index(sc.fm_edges + m.edges_v, m.nv, v);
         if (iu >= 0 && iv >= 0) atomicAdd(&sc.tally[m.bins + (int64_t)iu * m.nv + iv], e_abs);
     }
-    if (capture_enabled) {
+    if (capture_enabled && hc) {
+        // chunked append (streaming engine): one atomic per 256 captured hits instead of one per wave and iteration --
+        // the cursor of the hit buffer is a single word, and a word sustains only ~88 returning atomics per microsecond
+        bool want = (sc.sflags[s] & TRC_SURF_CAPTURE_HITS) != 0;
+        unsigned long long slot = chunk_append(&sc.counters[0], *hc, want, nullptr, 0);
+        if (want) {
+            if ((long long)slot < sc.hit_cap) {
+                sc.h_surf[slot] = s;
+                sc.h_eabs[slot] = e_abs; sc.h_ein[slot] = e_in;
+                sc.h_px[slot] = hx; sc.h_py[slot] = hy; sc.h_pz[slot] = hz;
+                sc.h_dx[slot] = dx; sc.h_dy[slot] = dy; sc.h_dz[slot] = dz;
+            } else {
+                atomicAdd(&sc.counters[1], 1ull);
+            }
+        }
+    } else if (capture_enabled) {
         // wave-aggregated append: one atomic per wave per iteration
         bool want = (sc.sflags[s] & TRC_SURF_CAPTURE_HITS) != 0;
         unsigned long long mask = __ballot(want);
@@ -469,7 +552,7 @@ __device__ __forceinline__ void coop_drain_leaves(const trc_accel_view &A, const
 template <bool LDS_TALLY>
 __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *recs, double *l_tally, double t, int s, double &px,
                                            double &py, double &pz, double &dx, double &dy, double &dz, double &e, double &ref,
-                                           double wl, unsigned long long rid, int &bounce) {
+                                           double wl, unsigned long long rid, int &bounce, WaveChunk *hc = nullptr) {
     const DScene &sc = P.sc;
     bounce += 1;
     const double *rec = recs + (size_t)s * sc.stride;
@@ -481,7 +564,7 @@ __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *re
                           rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, nx, ny, nz, P.seed, rid, (uint32_t)bounce, out);
     (void)n_out;  // scenes whose optics split rays are routed to the ordered engine by the host
     double e_abs = e - out[0].e;
-    record_hit<LDS_TALLY>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0);
+    record_hit<LDS_TALLY>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0, hc);
     px = hx; py = hy; pz = hz;
     dx = out[0].dx; dy = out[0].dy; dz = out[0].dz;
     e = out[0].e; ref = out[0].ref;
@@ -1466,10 +1549,25 @@ extern "C" int trc_scene_set_hit_capacity(trc_scene *sc, int64_t capacity) {
     dev_free(sc->d_h_surf);
     for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
     sc->hit_cap = 0;
+    sc->hit_cap_user = 0;
+    sc->hit_epoch += 1;
+    HIP_TRY(hipMemset(sc->d_counters, 0, 2 * sizeof(unsigned long long)));
     if (capacity == 0) return TRC_OK;
-    TRC_TRY(dev_alloc(&sc->d_h_surf, (size_t)capacity));
-    for (int i = 0; i < 8; ++i) TRC_TRY(dev_alloc(&sc->d_h[i], (size_t)capacity));
-    sc->hit_cap = capacity;
+    // the streaming engine appends in chunks that stay open between launches: room for what they can leave unused
+    const int64_t slack = (4 * capacity + 4096 < TRC_HIT_SLACK) ? 4 * capacity + 4096 : TRC_HIT_SLACK;   // small buffers see few waves
+    const int64_t alloc = capacity + slack;
+    TRC_TRY(dev_alloc(&sc->d_h_surf, (size_t)alloc));
+    for (int i = 0; i < 8; ++i) TRC_TRY(dev_alloc(&sc->d_h[i], (size_t)alloc));
+    HIP_TRY(hipMemset(sc->d_h_surf, 0xFF, (size_t)alloc * sizeof(int32_t)));     // surface -1: entry not written
+    sc->hit_cap = alloc;
+    sc->hit_cap_user = capacity;
+    return TRC_OK;
+}
+
+// forget the captured hits: cursor to zero, every entry unwritten, open chunks of the streaming engine stale
+static int scene_reset_hit_buffer(trc_scene *sc) {
+    sc->hit_epoch += 1;
+    if (sc->hit_cap > 0) HIP_TRY(hipMemset(sc->d_h_surf, 0xFF, (size_t)sc->hit_cap * sizeof(int32_t)));
     return TRC_OK;
 }
 
@@ -1478,7 +1576,7 @@ extern "C" int trc_scene_clear_hits(trc_scene *sc) {
     HIP_TRY(hipSetDevice(sc->ctx->device));
     HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
     HIP_TRY(hipMemset(sc->d_counters, 0, 2 * sizeof(unsigned long long)));
-    return TRC_OK;
+    return scene_reset_hit_buffer(sc);
 }
 
 extern "C" int trc_scene_reset_tallies(trc_scene *sc) {
@@ -1488,7 +1586,7 @@ extern "C" int trc_scene_reset_tallies(trc_scene *sc) {
     HIP_TRY(hipMemset(sc->d_tally, 0, (size_t)sc->tally_n * sizeof(double)));
     HIP_TRY(hipMemset(sc->d_counters, 0, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(sc->d_energy_left, 0, sizeof(double)));
-    return TRC_OK;
+    return scene_reset_hit_buffer(sc);
 }
 
 extern "C" int trc_scene_get_tallies(trc_scene *sc, double *absorbed, double *received, int64_t *hits) {
@@ -1524,14 +1622,27 @@ extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, doub
     HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
     unsigned long long c[2];
     HIP_TRY(hipMemcpy(c, sc->d_counters, sizeof(c), hipMemcpyDeviceToHost));
-    int64_t cnt = (int64_t)c[0];
-    if (cnt > sc->hit_cap) cnt = sc->hit_cap;
+    int64_t reserved = (int64_t)c[0];
+    if (reserved > sc->hit_cap) reserved = sc->hit_cap;
+    *n = 0;
+    if (reserved == 0) return TRC_OK;
+    // the reserved range holds unwritten entries (surface -1) where the streaming engine's chunks are still open:
+    // the caller gets the written ones, in buffer order
+    std::vector<int32_t> hs((size_t)reserved);
+    HIP_TRY(hipMemcpy(hs.data(), sc->d_h_surf, (size_t)reserved * 4, hipMemcpyDeviceToHost));
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < reserved; ++i) cnt += hs[(size_t)i] >= 0 ? 1 : 0;
     *n = cnt;
-    if (cnt == 0) return TRC_OK;
     double *dst[8] = {e_abs, e_in, px, py, pz, dx, dy, dz};
-    if (surf) HIP_TRY(hipMemcpy(surf, sc->d_h_surf, (size_t)cnt * 4, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; ++i)
-        if (dst[i]) HIP_TRY(hipMemcpy(dst[i], sc->d_h[i], (size_t)cnt * 8, hipMemcpyDeviceToHost));
+    if (surf) { int64_t m = 0; for (int64_t i = 0; i < reserved; ++i) if (hs[(size_t)i] >= 0) surf[m++] = hs[(size_t)i]; }
+    std::vector<double> col;
+    for (int k2 = 0; k2 < 8; ++k2) {
+        if (!dst[k2]) continue;
+        col.resize((size_t)reserved);
+        HIP_TRY(hipMemcpy(col.data(), sc->d_h[k2], (size_t)reserved * 8, hipMemcpyDeviceToHost));
+        int64_t m = 0;
+        for (int64_t i = 0; i < reserved; ++i) if (hs[(size_t)i] >= 0) dst[k2][m++] = col[(size_t)i];
+    }
     return TRC_OK;
 }
 
