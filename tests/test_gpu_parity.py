@@ -370,6 +370,29 @@ def test_kd_accel_equals_brute_and_reference(ctx):
     finally:
         del os.environ['TRC_STREAM_Q3_ENTRIES']
     assert N.array_equal(h_s, tl_b[2]) and N.allclose(a_s, tl_b[0], rtol=1e-12, atol=1e-9) and st_small.segments == st.segments
+    # hit capture of the streaming form: chunks of the hit buffer stay open between launches; repeated calls append,
+    # clearing forgets, and what comes back is what the tallies counted (receiver = surface 30 captures)
+    dev = DeviceScene(cs, ctx)
+    dev.set_kdtree(kd)
+    dev.set_hit_capacity(4 * v.shape[1])
+    bundle = lambda: RayBundle(vertices=v, directions=d, energy=e)
+    dev.trace_fast(bundle(), 100, 1e-10, 1, accel=True, stream=True)
+    h1 = dev.get_hits()
+    dev.trace_fast(bundle(), 100, 1e-10, 1, accel=True, stream=True)
+    dev.trace_fast(bundle(), 100, 1e-10, 1, accel=True, stream=False)        # the megakernel appends behind the chunks
+    h3 = dev.get_hits()
+    n_cap = int(tl_b[2][30])
+    assert len(h1['surf']) == n_cap and N.all(h1['surf'] == 30) and N.isclose(h1['e_abs'].sum(), tl_b[0][30], rtol=1e-12)
+    assert len(h3['surf']) == 3 * n_cap and N.isclose(h3['e_abs'].sum(), 3 * tl_b[0][30], rtol=1e-12)
+    key = lambda h: N.sort(N.round(h['points'][0] * 1e6) + 1e3 * N.round(h['points'][1] * 1e6))
+    assert N.array_equal(key(h3)[::3], key(h1))                             # the same hit points three times
+    _cabi_check = __import__('tracer_amd')._cabi.check
+    _cabi_check(dev.lib.trc_scene_clear_hits(dev.handle))
+    assert len(dev.get_hits()['surf']) == 0
+    dev.trace_fast(bundle(), 100, 1e-10, 1, accel=True, stream=True)
+    h4 = dev.get_hits()
+    assert len(h4['surf']) == n_cap and N.array_equal(key(h4), key(h1))
+    dev.close()
     for accel in (True, False):      # streaming engine, with the tree and with the single-leaf brute form
         dev = DeviceScene(cs, ctx)
         dev.set_kdtree(kd)

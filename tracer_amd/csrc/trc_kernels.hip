@@ -872,7 +872,7 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
                 }
                 coop_push_exact(W, ecount, hit, me | (uint32_t)A.always[k], ray, recs, stride, extra, lane);
             }
-            bool walk = searching && walking && !(P.flags & 0x100);   // 0x100, 0x200: timing experiments only
+            bool walk = searching && walking;
             uint32_t node = 0;
             int sp = 0;
             unsigned cnt = 0;     // leaves listed since the last drain
@@ -908,11 +908,11 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
                     }
                 }
                 if (__ballot(cnt >= COOP_LEAFCAP)) {    // some lane's list is full: everybody drains
-                    if (!(P.flags & 0x200)) coop_drain_leaves(A, W, cnt, ecount, r, ray, recs, stride, extra, lane);
+                    coop_drain_leaves(A, W, cnt, ecount, r, ray, recs, stride, extra, lane);
                     cnt = 0;
                 }
             }
-            if (!(P.flags & 0x200)) coop_drain_leaves(A, W, cnt, ecount, r, ray, recs, stride, extra, lane);
+            coop_drain_leaves(A, W, cnt, ecount, r, ray, recs, stride, extra, lane);
         }
         coop_drain_exact(W, ecount, ray, recs, stride, extra, lane);
 
@@ -1824,7 +1824,6 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         static int threads_env = -1, mode_env = -1;
         if (threads_env < 0) { const char *ev = getenv("TRC_FAST_THREADS"); threads_env = ev ? atoi(ev) : 0; }
         if (mode_env < 0) { const char *ev = getenv("TRC_FAST_GENERIC"); mode_env = (ev && atoi(ev)) ? 1 : 0; }
-        { const char *ev = getenv("TRC_DEBUG_SKIP"); if (ev) P.flags |= (atoi(ev) & 3) << 8; }
         // preferred: single-precision conservative search with everything it needs in LDS (up to 160 KiB per CU)
         bool m32 = sc->accel_ok && !mode_env && S <= 65535 &&
                    (!accel || (sc->accel_kd_ok && sc->kd_nodes <= COOP_MAX_NODES && sc->accel.kd_depth <= COOP_MAX_DEPTH));
