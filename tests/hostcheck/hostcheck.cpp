@@ -175,7 +175,14 @@ int hc_nearest_grid(int n_surf, const trc_surface_desc *surfs, const double *ext
             trc_ray32 r;
             double t0;
             float tmin, tmax;
-            if (trc_ray32_prepare(H.slo, H.shi, H.cen, vx, vy, vz, dx, dy, dz, &r, &t0) && trc_kd32_root(H.brute_root, r, &tmin, &tmax)) {
+            const bool in = trc_ray32_prepare(H.slo, H.shi, H.cen, vx, vy, vz, dx, dy, dz, &r, &t0);
+            if (in)
+                for (size_t k = 0; k < H.grid_apart.size(); ++k) {       // surfaces set apart from the grid
+                    int sidx = H.grid_apart[k];
+                    stats[1] += 1.0;
+                    if (trc_box_hit32(H.sbox.data() + 6 * (size_t)sidx, r)) { stats[2] += 1.0; TRC_TEST_EXACT(sidx); }
+                }
+            if (in && trc_kd32_root(H.grid_root, r, &tmin, &tmax)) {
                 trc_dda s;
                 trc_dda_start(G, r, tmin, &s);
                 do {

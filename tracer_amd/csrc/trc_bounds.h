@@ -99,6 +99,8 @@ struct trc_accel_host {
     float grid_lo[3], grid_cs[3], grid_inv[3];
     std::vector<uint16_t> grid_off;    // cells + 1
     std::vector<uint16_t> grid_list;
+    std::vector<int32_t> grid_apart;   // bounded surfaces kept out of the grid: their boxes are tested for every ray
+    float grid_root[6];                // box of the surfaces in the grid, relative, rounded outwards
 };
 
 // surfaces -> boxes, scene box, centre, delta
@@ -153,10 +155,56 @@ static inline void trc_accel_build_grid(trc_accel_host &A, int n_surf) {
     A.grid_ok = false;
     A.grid_off.clear();
     A.grid_list.clear();
-    const size_t nb = A.brute_leaf.size();
-    if (nb == 0 || n_surf > 65535) return;
-    double lo[3], ext[3];
-    for (int k = 0; k < 3; ++k) { lo[k] = (double)A.brute_root[k]; ext[k] = (double)A.brute_root[3 + k] - lo[k]; }
+    A.grid_apart.clear();
+    if (A.brute_leaf.empty() || n_surf > 65535) return;
+    // Surfaces that stand far from the rest (the receiver on its tower above a heliostat field) would stretch the grid over
+    // mostly empty space that every ray then has to step through.  Up to 8 of them (and at most a quarter of the scene) are
+    // set apart while leaving one out shrinks the box of the others by more than 30 %: their boxes are tested for every ray.
+    std::vector<uint16_t> members(A.brute_leaf);
+    auto box_of = [&](const std::vector<uint16_t> &m, int skip, double *blo, double *bhi) {
+        for (int k = 0; k < 3; ++k) { blo[k] = INFINITY; bhi[k] = -INFINITY; }
+        for (size_t j = 0; j < m.size(); ++j) {
+            if ((int)j == skip) continue;
+            const float *b = &A.sbox[6 * (size_t)m[j]];
+            for (int k = 0; k < 3; ++k) { blo[k] = std::fmin(blo[k], (double)b[k]); bhi[k] = std::fmax(bhi[k], (double)b[3 + k]); }
+        }
+    };
+    auto volume = [](const double *blo, const double *bhi) {
+        double e[3], emax = 0.0;
+        for (int k = 0; k < 3; ++k) { e[k] = bhi[k] - blo[k]; emax = std::fmax(emax, e[k]); }
+        double v = 1.0;
+        for (int k = 0; k < 3; ++k) v *= std::fmax(e[k], 1e-3 * emax);     // flat axes do not make the volume vanish
+        return v;
+    };
+    while (A.grid_apart.size() < 8 && members.size() > 4 && A.grid_apart.size() * 4 < A.brute_leaf.size()) {
+        double blo[3], bhi[3];
+        box_of(members, -1, blo, bhi);
+        const double v_all = volume(blo, bhi);
+        int best = -1;
+        double v_best = v_all;
+        for (size_t j = 0; j < members.size(); ++j) {
+            const float *b = &A.sbox[6 * (size_t)members[j]];
+            bool on_face = false;              // only a surface that touches a face of the box can shrink it
+            for (int k = 0; k < 3; ++k) on_face = on_face || (double)b[k] <= blo[k] || (double)b[3 + k] >= bhi[k];
+            if (!on_face) continue;
+            double l2[3], h2[3];
+            box_of(members, (int)j, l2, h2);
+            const double v = volume(l2, h2);
+            if (v < v_best) { v_best = v; best = (int)j; }
+        }
+        if (best < 0 || !(v_best < 0.7 * v_all)) break;
+        A.grid_apart.push_back((int32_t)members[(size_t)best]);
+        members.erase(members.begin() + best);
+    }
+    const size_t nb = members.size();
+    double lo[3], hi[3], ext[3];
+    box_of(members, -1, lo, hi);
+    for (int k = 0; k < 3; ++k) {
+        A.grid_root[k] = trc_f32_down(lo[k] - 2.0 * (double)A.delta);
+        A.grid_root[3 + k] = trc_f32_up(hi[k] + 2.0 * (double)A.delta);
+        lo[k] = (double)A.grid_root[k];
+        ext[k] = (double)A.grid_root[3 + k] - lo[k];
+    }
 #ifndef TRC_GRID_DENSITY
 #define TRC_GRID_DENSITY 2.0
 #endif
@@ -189,7 +237,7 @@ static inline void trc_accel_build_grid(trc_accel_host &A, int n_surf) {
         std::vector<int> range(6 * nb);
         size_t total = 0;
         for (size_t j = 0; j < nb; ++j) {
-            const float *b = &A.sbox[6 * (size_t)A.brute_leaf[j]];
+            const float *b = &A.sbox[6 * (size_t)members[j]];
             size_t c = 1;
             for (int k = 0; k < 3; ++k) {
                 int a = (int)std::floor(((double)b[k] - pad - lo[k]) / (double)cs[k]);
@@ -215,7 +263,7 @@ static inline void trc_accel_build_grid(trc_accel_host &A, int n_surf) {
             for (int z = range[6 * j + 2]; z <= range[6 * j + 5]; ++z)
                 for (int y = range[6 * j + 1]; y <= range[6 * j + 4]; ++y)
                     for (int x = range[6 * j]; x <= range[6 * j + 3]; ++x)
-                        A.grid_list[cur[((size_t)z * dim[1] + y) * dim[0] + x]++] = A.brute_leaf[j];
+                        A.grid_list[cur[((size_t)z * dim[1] + y) * dim[0] + x]++] = members[j];
         for (int k = 0; k < 3; ++k) { A.grid_dim[k] = dim[k]; A.grid_lo[k] = (float)lo[k]; A.grid_cs[k] = cs[k]; A.grid_inv[k] = inv[k]; }
         A.grid_ok = true;
         return;

@@ -104,8 +104,9 @@ struct DScene {
     double a_cen[3], a_slo[3], a_shi[3];
     // uniform grid (streaming engine)
     const uint16_t *a_goff, *a_glist;
-    int32_t a_g_ok, a_g_ncell, a_g_nlist, a_gdim[3];
-    float a_glo[3], a_gcs[3], a_ginv[3];
+    const int32_t *a_gapart;    // bounded surfaces kept out of the grid (box-tested for every ray)
+    int32_t a_g_ok, a_g_ncell, a_g_nlist, a_g_napart, a_gdim[3];
+    float a_glo[3], a_gcs[3], a_ginv[3], a_groot[6];
     // tallies: [absorbed S | received S | count S | segments, hits | flux bins ...]
     double *tally;
     // flux maps
@@ -143,6 +144,7 @@ struct trc_scene {
     int32_t *d_a_unbounded;
     uint16_t *d_a_bleaf;
     uint16_t *d_a_goff, *d_a_glist;
+    int32_t *d_a_gapart;
     struct StreamEngine *stream_eng;   // slots of the streaming fast engine (trc_stream.inc), allocated on first use
     double *d_tally;
     int64_t tally_n;
@@ -1353,9 +1355,12 @@ static int scene_upload_surfaces(trc_scene *sc) {
     if (!sc->accel.unbounded.empty())
         HIP_TRY(hipMemcpy(sc->d_a_unbounded, sc->accel.unbounded.data(), sc->accel.unbounded.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     trc_accel_build_grid(sc->accel, sc->n_surf);
-    dev_free(sc->d_a_goff); dev_free(sc->d_a_glist);
-    sc->d_a_goff = nullptr; sc->d_a_glist = nullptr;
+    dev_free(sc->d_a_goff); dev_free(sc->d_a_glist); dev_free(sc->d_a_gapart);
+    sc->d_a_goff = nullptr; sc->d_a_glist = nullptr; sc->d_a_gapart = nullptr;
     if (sc->accel.grid_ok) {
+        TRC_TRY(dev_alloc(&sc->d_a_gapart, sc->accel.grid_apart.size()));
+        if (!sc->accel.grid_apart.empty())
+            HIP_TRY(hipMemcpy(sc->d_a_gapart, sc->accel.grid_apart.data(), sc->accel.grid_apart.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         TRC_TRY(dev_alloc(&sc->d_a_goff, sc->accel.grid_off.size()));
         TRC_TRY(dev_alloc(&sc->d_a_glist, sc->accel.grid_list.size()));
         HIP_TRY(hipMemcpy(sc->d_a_goff, sc->accel.grid_off.data(), sc->accel.grid_off.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -1434,7 +1439,7 @@ extern "C" int trc_scene_destroy(trc_scene *sc) {
     dev_free(sc->d_recs); dev_free(sc->d_opt); dev_free(sc->d_extra); dev_free(sc->d_sflags);
     dev_free(sc->d_kd_a); dev_free(sc->d_kd_b); dev_free(sc->d_kd_leaf); dev_free(sc->d_kd_always);
     dev_free(sc->d_a_sbox); dev_free(sc->d_a_nodes); dev_free(sc->d_a_leaf); dev_free(sc->d_a_unbounded); dev_free(sc->d_a_bleaf);
-    dev_free(sc->d_a_goff); dev_free(sc->d_a_glist);
+    dev_free(sc->d_a_goff); dev_free(sc->d_a_glist); dev_free(sc->d_a_gapart);
     dev_free(sc->d_kd_split); dev_free(sc->d_tally); dev_free(sc->d_fm_of_surf); dev_free(sc->d_fms);
     dev_free(sc->d_fm_edges); dev_free(sc->d_counters); dev_free(sc->d_energy_left); dev_free(sc->d_h_surf);
     for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
@@ -1687,7 +1692,9 @@ static DScene make_dscene(trc_scene *sc) {
     d.a_ok = sc->accel_ok ? 1 : 0; d.a_kd_ok = sc->accel_kd_ok ? 1 : 0;
     for (int i = 0; i < 6; ++i) d.a_root[i] = sc->accel.root[i];
     d.a_delta = sc->accel.delta;
-    d.a_goff = sc->d_a_goff; d.a_glist = sc->d_a_glist;
+    d.a_goff = sc->d_a_goff; d.a_glist = sc->d_a_glist; d.a_gapart = sc->d_a_gapart;
+    d.a_g_napart = sc->accel.grid_ok ? (int32_t)sc->accel.grid_apart.size() : 0;
+    for (int i = 0; i < 6; ++i) d.a_groot[i] = sc->accel.grid_ok ? sc->accel.grid_root[i] : 0.0f;
     d.a_g_ok = sc->accel.grid_ok ? 1 : 0;
     d.a_g_ncell = sc->accel.grid_ok ? (int32_t)sc->accel.grid_off.size() - 1 : 0;
     d.a_g_nlist = sc->accel.grid_ok ? (int32_t)sc->accel.grid_list.size() : 0;
