@@ -230,18 +230,23 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Queue append without a hot atomic: a wave reserves CHUNK entries at a time from the global counter (one atomic per
 // chunk; a single word sustains only ~88 returning atomics per microsecond) and fills them; what is left of a chunk
 // when the wave moves on is marked invalid and skipped by the consumers.  base/used are wave-uniform.
+#ifndef SQ_CHUNK
 #define SQ_CHUNK 256
+#endif
 #define SQ_INVALID 0xFFFFFFFFu
+
+#define SQ_CHUNK_MAX 1024        /* large launches reserve more per atomic; queue slack is sized for this */
 
 struct WaveChunk {
     unsigned long long base;
     unsigned used;
     unsigned open;
+    unsigned size;      // entries reserved per atomic (SQ_CHUNK, or up to SQ_CHUNK_MAX in the largest launches)
 };
 
-__device__ __forceinline__ WaveChunk chunk_init() {
+__device__ __forceinline__ WaveChunk chunk_init(unsigned size = SQ_CHUNK) {
     WaveChunk c;
-    c.base = 0; c.used = SQ_CHUNK; c.open = 0;
+    c.base = 0; c.used = size; c.open = 0; c.size = size;
     return c;
 }
 
@@ -250,16 +255,17 @@ __device__ __forceinline__ void chunk_rebroadcast(WaveChunk &c, int lane) {
     c.base = __shfl(c.base, lane, 64);
     c.used = (unsigned)__shfl((int)c.used, lane, 64);
     c.open = (unsigned)__shfl((int)c.open, lane, 64);
+    c.size = (unsigned)__shfl((int)c.size, lane, 64);
 }
 
 // marks the unused tail of the current chunk invalid (wave-uniform call)
 __device__ __forceinline__ void chunk_close(WaveChunk &c, uint32_t *tag, long long cap) {
     if (c.open) {
-        for (unsigned k = c.used + lane_id(); k < SQ_CHUNK; k += 64)
+        for (unsigned k = c.used + lane_id(); k < c.size; k += 64)
             if ((long long)(c.base + k) < cap) tag[c.base + k] = SQ_INVALID;
     }
     c.open = 0;
-    c.used = SQ_CHUNK;
+    c.used = c.size;
 }
 
 // returns this lane's index in the queue (meaningful when `want`).  Call it with the whole wave, or -- inside a
@@ -272,12 +278,12 @@ __device__ __forceinline__ unsigned long long chunk_append(unsigned long long *c
     const unsigned need = (unsigned)__popcll(m);
     const unsigned rank = (unsigned)__popcll(m & ((1ull << lane_id()) - 1ull));
     unsigned long long idx;
-    if (c.used + need > SQ_CHUNK) {
-        const unsigned rem = c.open ? SQ_CHUNK - c.used : 0u;
+    if (c.used + need > c.size) {
+        const unsigned rem = c.open ? c.size - c.used : 0u;
         const unsigned long long old_pos = c.base + c.used;
         const int leader = __ffsll((long long)m) - 1;          // a lane that is certainly active here
         unsigned long long b = 0;
-        if ((int)lane_id() == leader) b = atomicAdd(counter, (unsigned long long)SQ_CHUNK);
+        if ((int)lane_id() == leader) b = atomicAdd(counter, (unsigned long long)c.size);
         c.base = __shfl(b, leader, 64);
         c.used = need - rem;
         c.open = 1;
