@@ -426,6 +426,15 @@ def test_full_size_properties(ctx):
     (a0, r0, h0, f0, s0), (a1, r1, h1, f1, s1) = out['brute'], out['accel']
     assert N.array_equal(h0, h1) and s0['segments'] == s1['segments']
     assert N.allclose(a0, a1, rtol=1e-10) and N.allclose(f0, f1, rtol=1e-9, atol=1e-9)
+    # the same rays handed over as a host bundle (two batches in flight index the caller's arrays by batch offset)
+    from tracer_amd.ray_bundle import RayBundle
+    lazy = scenes.nsttf_source(n, src, seed=31)
+    given = RayBundle(vertices=lazy.get_vertices(), directions=lazy.get_directions(), energy=lazy.get_energy())
+    eng.reset_tallies(); plant.reset_all_optics()
+    eng.ray_tracer(given, reps=100, min_energy=1e-10, tree=False, accel=True, seed=31)
+    a3, r3, h3 = eng.get_tallies()
+    assert N.array_equal(h3, h1) and N.allclose(a3, a1, rtol=1e-10) and eng.stats['segments'] == s1['segments']
+    del given, lazy
     a2, r2, h2, f2, s2 = out['mega']
     assert N.array_equal(h2, h1) and s2['segments'] == s1['segments'] and s2['launches'] == 1 and s1['launches'] > 1
     assert N.allclose(a2, a1, rtol=1e-10) and N.allclose(f2, f1, rtol=1e-9, atol=1e-9)
