@@ -457,6 +457,14 @@ def test_full_size_properties(ctx):
     # per-ray variance of the receiver power from the hit list -> standard error of this run
     se_gpu = N.sqrt(N.sum(hits[0] ** 2))
     assert abs(a1[218] - p_ref) <= 3. * N.sqrt(se_gpu ** 2 + se_ref ** 2), (a1[218], p_ref, se_gpu, se_ref)
+    # flux map against the reference's own flux maps (mean of its 10 runs), in 5 x 5 groups of bins: configs[2] "flux map vs
+    # reference".  Standard error here from the per-hit energies, there from the scatter of the runs (a 10-run estimate, so 5 sigma)
+    grp = lambda m: m.reshape(10, 5, 10, 5).sum(axis=(1, 3))
+    var_gpu = N.histogram2d(loc[0], loc[1], bins=[ue, ve], weights=hits[0] ** 2)[0]
+    se_map = N.sqrt(grp(var_gpu) + grp(mc['nsttf_flux_se'] ** 2))
+    dev_map = N.abs(grp(f1) - grp(mc['nsttf_flux_mean']))
+    assert N.all(dev_map <= 5. * se_map + 1e-9), float((dev_map / N.maximum(se_map, 1e-30)).max())
+    assert N.corrcoef(grp(f1).ravel(), grp(mc['nsttf_flux_mean']).ravel())[0, 1] > 0.995
     frac_ref, frac_se = mc['nsttf_bounce_fractions_mean'], mc['nsttf_bounce_fractions_se']
     frac = N.array([h1[:218].sum() / n, h1[218] / n])
     assert N.all(N.abs(frac - frac_ref) <= 4. * N.sqrt(frac_se ** 2 + frac * (1 - frac) / n)), (frac, frac_ref)
