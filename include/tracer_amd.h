@@ -199,7 +199,9 @@ typedef struct trc_scene trc_scene;
 typedef struct trc_result trc_result;
 
 /* trace flags */
-#define TRC_TRACE_ACCEL 0x1        /* use the Kd-tree set on the scene (ray_tracer(accel=...)) */
+#define TRC_TRACE_ACCEL 0x1        /* accelerated candidate search (ray_tracer(accel=...)): the Kd-tree set on the scene
+                                      (ordered engine, megakernel) or the library's own uniform grid (streaming form,
+                                      no tree needed); results equal brute force either way */
 #define TRC_TRACE_KEEP_LAST 0x2    /* fast engine: keep rays still alive after `reps` bounces */
 #define TRC_TRACE_STREAM 0x4       /* fast engine: always run the phases as separate kernels connected by HBM queues
                                       (the default for calls of 4194304 rays and more); same results */

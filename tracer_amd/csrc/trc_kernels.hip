@@ -1784,7 +1784,7 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
     if ((in == nullptr) == (src == nullptr)) return trc_fail(TRC_ERR_INVALID, "exactly one of `in` and `src` must be given");
     if (n < 0 || reps < 0) return trc_fail(TRC_ERR_INVALID, "n and reps must be >= 0");
     if (sc->splits) return trc_fail(TRC_ERR_UNSUPPORTED, "the scene has ray-splitting optics: use trc_trace_ordered");
-    if ((flags & TRC_TRACE_ACCEL) && !sc->has_kd) return trc_fail(TRC_ERR_INVALID, "TRC_TRACE_ACCEL without a Kd-tree on the scene");
+    // TRC_TRACE_ACCEL without a Kd-tree: the streaming form searches its own grid; the megakernel tests every box
     trc_ctx *ctx = sc->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     DevRays dr;
