@@ -37,6 +37,8 @@ class TracerEngine(object):
         self._dev = None
         self._dev_sig = None
         self._fluxmap_requests = {}
+        self._kd_on_device = None
+        self._auto_kd = None
         self.stats = {}
 
     # -- device scene management ------------------------------------------------------------------
@@ -49,6 +51,7 @@ class TracerEngine(object):
             self._dev = DeviceScene(compiled)
             self._dev_sig = sig
             self._kd_on_device = None
+            self._auto_kd = None
             for si, (u, v) in self._fluxmap_requests.items():
                 self._dev.set_fluxmap(si, u, v)
         else:
@@ -115,7 +118,11 @@ class TracerEngine(object):
                 logging.log(self.loglevel, 'Maximum Kd tree depth %i' % max_depth)
                 kw = dict(kwargs)
                 kw.setdefault('min_leaf', 1)
-                self.Kd_Tree = KdTree(self._asm, max_depth, loglevel=self.loglevel, fast=(accel == 'fast'), **kw)
+                # the tree only depends on the scene and on these arguments: repeated calls (Monte-Carlo loops) reuse it
+                key = (self._dev_sig, accel == 'fast', tuple(sorted(kw.items())))
+                if self._auto_kd is None or self._auto_kd[0] != key:
+                    self._auto_kd = (key, KdTree(self._asm, max_depth, loglevel=self.loglevel, fast=(accel == 'fast'), **kw))
+                self.Kd_Tree = self._auto_kd[1]
             else:
                 self.Kd_Tree = Kd_Tree
             if self._kd_on_device is not self.Kd_Tree:
