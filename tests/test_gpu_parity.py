@@ -590,3 +590,76 @@ def test_cavity_spectral_engines_vs_oracle(ctx):
     a, r, h = dev.get_tallies()
     dev.close()
     assert N.array_equal(h, ref['hits']) and N.allclose(a, ref['absorbed'], rtol=1e-9, atol=1e-9) and st.segments == ref['segments']
+
+
+def test_random_scenes_all_searches_agree(ctx):
+    """
+    Scenes of 60 surfaces of mixed kinds at random poses -- clustered, with a few far outliers and two infinite planes --
+    traced with every candidate search of the fast engine: brute force on the megakernel (the reference's default
+    semantics), brute force and the uniform grid on the streaming kernels.  Per-surface hit counts must be identical and
+    energies equal to rounding: the single-precision searches may only ever add candidates, never lose one.
+    """
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM, RoundPlateGM, FlatGeometryManager
+    from tracer_amd.triangular_face import TriangularFace
+    from tracer_amd.paraboloid import ParabolicDishGM, RectangularParabolicDishGM
+    from tracer_amd.sphere_surface import SphericalGM, HemisphereGM, CutSphereGM
+    from tracer_amd.boundary_shape import BoundaryPlane
+    from tracer_amd.cylinder import FiniteCylinder
+    from tracer_amd.cone import FiniteCone, ConicalFrustum
+    from tracer_amd.ellipsoid import EllipsoidGM
+    from tracer_amd.spatial_geometry import general_axis_rotation
+    from tracer_amd import optics_callables as opt
+    from tracer_amd.scene import compile_scene, DeviceScene
+    from tracer_amd.ray_bundle import RayBundle
+
+    makers = [lambda r: RectPlateGM(r.uniform(0.5, 3.), r.uniform(0.5, 3.)),
+              lambda r: RoundPlateGM(r.uniform(0.5, 2.)),
+              lambda r: TriangularFace(N.array([[r.uniform(1, 2), 0.], [r.uniform(-0.5, 0.5), r.uniform(1, 2)], [0., 0.]])),
+              lambda r: ParabolicDishGM(r.uniform(1., 3.), r.uniform(1., 4.)),
+              lambda r: RectangularParabolicDishGM(r.uniform(1., 2.), r.uniform(1., 2.), r.uniform(2., 5.)),
+              lambda r: SphericalGM(r.uniform(0.3, 1.5)),
+              lambda r: HemisphereGM(r.uniform(0.5, 1.5)),
+              lambda r: CutSphereGM(2., BoundaryPlane(location=N.r_[0., 0., r.uniform(0.5, 1.5)])),
+              lambda r: FiniteCylinder(r.uniform(0.5, 2.), r.uniform(0.5, 3.)),
+              lambda r: FiniteCone(r.uniform(0.3, 1.), r.uniform(0.5, 2.)),
+              lambda r: ConicalFrustum(0., r.uniform(0.3, 1.), r.uniform(0.5, 2.), r.uniform(1.1, 2.)),
+              lambda r: EllipsoidGM(r.uniform(0.5, 1.5), r.uniform(0.5, 1.5), r.uniform(0.5, 1.5), zlim=[-0.5, 0.4])]
+    for seed in (1, 2, 3):
+        r = N.random.RandomState(seed)
+        objs = []
+        for k in range(60):
+            gm = makers[k % len(makers)](r)
+            optics = opt.Reflective(0.3) if k % 3 else opt.Lambertian(0.5)
+            axis = r.normal(size=3)
+            axis /= N.linalg.norm(axis)
+            # most surfaces in a 24 m cube, every 20th far away (set apart from the grid or stretching it)
+            centre = r.uniform(-12., 12., size=3) if k % 20 else r.uniform(-1., 1., size=3) * 25. + N.r_[0., 0., 90.]
+            objs.append(AssembledObject(surfs=[Surface(gm, optics)], transform=N.vstack((
+                N.hstack((general_axis_rotation(axis, r.uniform(0, 2 * N.pi)), centre[:, None])), N.r_[[0., 0., 0., 1.]]))))
+        for z, a in ((-14., 1.), (110., 0.6)):         # two unbounded planes closing the scene below and above
+            objs.append(AssembledObject(surfs=[Surface(FlatGeometryManager(), opt.Reflective(a))],
+                                        transform=N.vstack((N.hstack((N.eye(3), N.c_[[0., 0., z]])), N.r_[[0., 0., 0., 1.]]))))
+        cs = compile_scene(Assembly(objects=objs))
+        n = 300000
+        o = r.normal(size=(3, n))
+        o = o / N.sqrt((o ** 2).sum(axis=0)) * 40.
+        tgt = r.uniform(-14., 14., size=(3, n))
+        d = tgt - o
+        d /= N.sqrt((d ** 2).sum(axis=0))
+        d[:, :3] = N.eye(3)                          # axis-parallel rays too
+        e = N.ones(n)
+        res = {}
+        for key, accel, stream in (('mega_brute', False, False), ('stream_brute', False, True), ('stream_grid', True, True)):
+            dev = DeviceScene(cs, ctx)
+            st, _ = dev.trace_fast(RayBundle(vertices=o, directions=d, energy=e), 12, 1e-6, 5, accel=accel, stream=stream)
+            res[key] = dev.get_tallies() + (st.segments,)
+            dev.close()
+        a0, r0, h0, s0 = res['mega_brute']
+        assert h0.sum() > n and (h0[:60] > 0).sum() > 40          # the scene is actually hit, many bounces
+        for key in ('stream_brute', 'stream_grid'):
+            a1, r1, h1, s1 = res[key]
+            assert N.array_equal(h1, h0) and s1 == s0, (seed, key, N.nonzero(h1 != h0)[0][:5])
+            assert N.allclose(a1, a0, rtol=1e-9, atol=1e-9) and N.allclose(r1, r0, rtol=1e-9, atol=1e-9), (seed, key)
