@@ -663,3 +663,33 @@ def test_random_scenes_all_searches_agree(ctx):
             a1, r1, h1, s1 = res[key]
             assert N.array_equal(h1, h0) and s1 == s0, (seed, key, N.nonzero(h1 != h0)[0][:5])
             assert N.allclose(a1, a0, rtol=1e-9, atol=1e-9) and N.allclose(r1, r0, rtol=1e-9, atol=1e-9), (seed, key)
+
+
+def test_streaming_edge_scenes(ctx):
+    """the streaming form on scenes without any bounded surface, with a single bounded surface, reps=1 and odd ray counts"""
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM, FlatGeometryManager
+    from tracer_amd.spatial_geometry import translate, rotx
+    from tracer_amd import optics_callables as opt
+    from tracer_amd.scene import compile_scene, DeviceScene
+    from tracer_amd.ray_bundle import RayBundle
+    r = N.random.RandomState(4)
+    planes = [AssembledObject(surfs=[Surface(FlatGeometryManager(), opt.Reflective(0.1))], transform=translate(0, 0, -1.)),
+              AssembledObject(surfs=[Surface(FlatGeometryManager(), opt.Reflective(0.1))], transform=N.dot(translate(0, 0, 1.), rotx(N.pi)))]
+    plate = AssembledObject(surfs=[Surface(RectPlateGM(1., 1.), opt.Reflective(0.5))])
+    for objs, n, reps in ((planes, 1001, 7), (planes + [plate], 777, 5), ([plate], 130, 1), ([plate], 64, 3)):
+        cs = compile_scene(Assembly(objects=objs))
+        o = N.vstack((r.uniform(-2, 2, n), r.uniform(-2, 2, n), r.uniform(-0.9, 0.9, n)))
+        d = r.normal(size=(3, n))
+        d /= N.sqrt((d ** 2).sum(axis=0))
+        res = []
+        for accel, stream in ((False, False), (True, True), (False, True)):
+            dev = DeviceScene(cs, ctx)
+            st, last = dev.trace_fast(RayBundle(vertices=o, directions=d, energy=N.ones(n)), reps, 1e-3, 9, accel=accel, stream=stream, keep_last=True)
+            res.append(dev.get_tallies() + (st.segments, st.rays_left, N.sort(last[6]) if st.rays_left else N.zeros(0)))
+            dev.close()
+        for k in (1, 2):
+            assert N.array_equal(res[k][2], res[0][2]) and res[k][3] == res[0][3] and res[k][4] == res[0][4], (len(objs), n, reps, k)
+            assert N.allclose(res[k][0], res[0][0], rtol=1e-12) and N.allclose(res[k][5], res[0][5], rtol=1e-12)
