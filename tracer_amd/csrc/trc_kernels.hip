@@ -250,6 +250,16 @@ __device__ __forceinline__ WaveChunk chunk_init(unsigned size = SQ_CHUNK) {
     return c;
 }
 
+// The first chunk of a wave can be handed out without an atomic: chunk number `wave` of a queue whose counter the host
+// starts at (number of waves) * size.  Every wave of a launch reserving its first chunk at the same moment is otherwise
+// thousands of atomics on one word before any work starts (~88 per microsecond).  A wave that never appends leaves the
+// whole chunk marked invalid (chunk_close).
+__device__ __forceinline__ WaveChunk chunk_init_static(unsigned size, unsigned long long wave) {
+    WaveChunk c;
+    c.base = wave * size; c.used = 0; c.open = 1; c.size = size;
+    return c;
+}
+
 // after a chunk_append made by a subset of the lanes: every lane takes the state of `lane` (one that took part)
 __device__ __forceinline__ void chunk_rebroadcast(WaveChunk &c, int lane) {
     c.base = __shfl(c.base, lane, 64);
