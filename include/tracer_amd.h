@@ -204,7 +204,7 @@ typedef struct trc_result trc_result;
                                       no tree needed); results equal brute force either way */
 #define TRC_TRACE_KEEP_LAST 0x2    /* fast engine: keep rays still alive after `reps` bounces */
 #define TRC_TRACE_STREAM 0x4       /* fast engine: always run the phases as separate kernels connected by HBM queues
-                                      (the default for calls of 4194304 rays and more); same results */
+                                      (the default for calls of 1048576 rays and more); same results */
 #define TRC_TRACE_MEGAKERNEL 0x8   /* fast engine: always run the persistent single-launch kernel (the default for
                                       smaller calls); same results */
 

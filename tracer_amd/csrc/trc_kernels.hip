@@ -963,7 +963,7 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
     }
 }
 
-#define TRC_STREAM_MIN_RAYS 4194304
+#define TRC_STREAM_MIN_RAYS 1048576
 #include "trc_stream.inc"
 
 static void scene_free_stream_ws(trc_scene *sc) {
