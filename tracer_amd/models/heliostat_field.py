@@ -23,6 +23,16 @@ class RotationAxis(AssembledObject):
         return N.dot(self.get_rotation()[:3, :3], self.axis)
 
 
+def _unit_rows(vectors):
+    """rows scaled to unit length, in place (the reference normalises its aim arrays in place too)"""
+    vectors /= N.sqrt(N.sum(vectors ** 2, axis=1)[:, None])
+    return vectors
+
+
+def _in_limits(angle, limits):
+    return limits[0] <= angle <= limits[1]
+
+
 class HeliostatField(Assembly):
     def __init__(self, positions, width, height, absorptivity, sigma, bi_var=True, focal_lengths=None,
                  quad_params=None, MCRT_option='fast',
@@ -34,33 +44,32 @@ class HeliostatField(Assembly):
         Each heliostat is Assembly[primary axis, facet Assembly[mirror, secondary axis]] and carries a
         thin BoundaryBox for the Kd-tree (heliostat_field.py:61-77).
         """
-        n = positions.shape[0]
+        count = positions.shape[0]
         self._pos = positions
-        if focal_lengths is None:
-            focal_lengths = [None] * n
-        if quad_params is None:
-            quad_params = [None] * n
-        if not hasattr(absorptivity, '__len__'):
-            absorptivity = N.ones(n) * absorptivity
-        self._heliostats = []
         self.rotation_axes_pos = rotation_axes_pos
-        offset = rotation_axes_pos[1] - rotation_axes_pos[0]
-        for p in range(n):
-            primary = RotationAxis(axis=rotation_axes_vec[0])
-            secondary = RotationAxis(axis=rotation_axes_vec[1])
-            assert not ((focal_lengths[p] is not None) and (quad_params[p] is not None))
-            box = BoundaryBox(N.array([[-width / 2., width / 2.], [-height / 2., height / 2.], [-1e-6, 1e-6]]).T)
-            if focal_lengths[p] is None and quad_params[p] is None:
-                mirror = rect_one_sided_mirror(width, height, absorptivity[p], sigma, bi_var, MCRT_option, bounds=box)
-            elif focal_lengths[p] is not None:
-                mirror = rect_para_one_sided_mirror(width, height, focal_lengths[p], absorptivity[p], sigma, bi_var,
-                                                    MCRT_option, bounds=box)
-            else:
-                mirror = flat_quad_one_sided_mirror(width, height, quad_params[p], absorptivity[p], sigma, bi_var,
-                                                    MCRT_option, bounds=box)
-            mirror.set_location(offset)
-            facet = Assembly(objects=[mirror, secondary], location=rotation_axes_pos[0])
-            self._heliostats.append(Assembly(objects=[primary], subassemblies=[facet], location=positions[p]))
+        alphas = absorptivity if hasattr(absorptivity, '__len__') else N.ones(count) * absorptivity
+        focals = focal_lengths if focal_lengths is not None else [None] * count
+        quads = quad_params if quad_params is not None else [None] * count
+        half = N.array([width, height]) / 2.
+
+        def mirror_for(k):
+            """flat, paraboloidal or quadric facet of heliostat k, with its thin bounding box"""
+            assert focals[k] is None or quads[k] is None
+            box = BoundaryBox(N.array([[-half[0], -half[1], -1e-6], [half[0], half[1], 1e-6]]))
+            common = (alphas[k], sigma, bi_var, MCRT_option)
+            if focals[k] is not None:
+                return rect_para_one_sided_mirror(width, height, focals[k], *common, bounds=box)
+            if quads[k] is not None:
+                return flat_quad_one_sided_mirror(width, height, quads[k], *common, bounds=box)
+            return rect_one_sided_mirror(width, height, *common, bounds=box)
+
+        self._heliostats = []
+        for k in range(count):
+            axis_1, axis_2 = RotationAxis(axis=rotation_axes_vec[0]), RotationAxis(axis=rotation_axes_vec[1])
+            mirror = mirror_for(k)
+            mirror.set_location(rotation_axes_pos[1] - rotation_axes_pos[0])
+            facet = Assembly(objects=[mirror, axis_2], location=rotation_axes_pos[0])
+            self._heliostats.append(Assembly(objects=[axis_1], subassemblies=[facet], location=positions[k]))
         Assembly.__init__(self, subassemblies=self._heliostats)
 
     def get_heliostats(self):
@@ -76,61 +85,46 @@ class HeliostatField(Assembly):
         is reflected towards its aim point (or along its aim vector).  NB: like the reference
         (heliostat_field.py:114-115) `aim_points` is modified in place.
         """
-        sun_vec = solar_vector(azimuth, zenith)
-        if aim_points is None:
-            if aim_vectors is None:
-                raise ValueError('aim-points or aiming vectors have to be set')
-            aim = aim_vectors
-            aim /= N.sqrt(N.sum(aim ** 2, axis=1)[:, None])
-        else:
+        if aim_points is not None:
             aim_points -= self._pos + N.sum(self.rotation_axes_pos, axis=0)
-            aim_points /= N.sqrt(N.sum(aim_points ** 2, axis=1)[:, None])
-            aim = aim_points
-        trac = sun_vec + aim
-        trac /= N.sqrt(N.sum(trac ** 2, axis=1)[:, None])
+            aim = _unit_rows(aim_points)
+        elif aim_vectors is not None:
+            aim = _unit_rows(aim_vectors)
+        else:
+            raise ValueError('aim-points or aiming vectors have to be set')
+        # mirror normals: bisectors of the sun and aim directions
+        normals = _unit_rows(solar_vector(azimuth, zenith) + aim)
+        lim_1 = tracking_limits_primary_axis if tracking_limits_primary_axis is not None else [-N.pi, N.pi]
+        lim_2 = tracking_limits_secondary_axis if tracking_limits_secondary_axis is not None else [-N.pi, N.pi]
+        count = self._pos.shape[0]
+        # pointing errors, two draws per heliostat in heliostat order (as the reference draws them)
+        errors = N.zeros((count, 2)) if tracking_error is None else N.random.normal(scale=tracking_error, size=(count, 2))
 
-        if tracking_limits_primary_axis is None:
-            tracking_limits_primary_axis = [-N.pi, N.pi]
-        if tracking_limits_secondary_axis is None:
-            tracking_limits_secondary_axis = [-N.pi, N.pi]
-        err1 = err2 = 0.
         if tracking == 'azimuth_elevation':
-            az = N.arctan2(trac[:, 1], trac[:, 0])
-            ze = N.arccos(trac[:, 2])
-            for h in range(self._pos.shape[0]):
-                if tracking_error is not None:
-                    err1 = N.random.normal(scale=tracking_error)
-                    err2 = N.random.normal(scale=tracking_error)
-                ang_az = az[h] + err1
-                ang_ze = ze[h] + err2
-                if ang_az < -N.pi:
-                    ang_az += N.pi
-                if ang_az > N.pi:
-                    ang_az -= N.pi
-                if not (tracking_limits_primary_axis[0] <= ang_az <= tracking_limits_primary_axis[1]):
-                    print(ang_az, 'is outside of tracking limits')
-                    continue
-                if not (tracking_limits_secondary_axis[0] <= ang_ze <= tracking_limits_secondary_axis[1]):
-                    print(ang_ze, 'is outside of tracking limits')
-                    continue
-                facet = self._heliostats[h].get_assemblies()[0]
-                primary = self._heliostats[h].get_local_objects()[0]
-                facet.set_rotation(general_axis_rotation(primary.get_rotation_axis(), N.pi / 2. + ang_az))
-                mirror, secondary = facet.get_objects()
-                mirror.set_rotation(general_axis_rotation(secondary.get_rotation_axis(), ang_ze))
+            first = N.arctan2(normals[:, 1], normals[:, 0]) + errors[:, 0]
+            second = N.arccos(normals[:, 2]) + errors[:, 1]
+            for k, heliostat in enumerate(self._heliostats):
+                a_az, a_ze = first[k], second[k]
+                if a_az < -N.pi:          # as in the reference (:147-150): half a turn, not a full one
+                    a_az += N.pi
+                if a_az > N.pi:
+                    a_az -= N.pi
+                for angle, limits in ((a_az, lim_1), (a_ze, lim_2)):
+                    if not _in_limits(angle, limits):
+                        print(angle, 'is outside of tracking limits')
+                        break
+                else:
+                    facet = heliostat.get_assemblies()[0]
+                    axis_1 = heliostat.get_local_objects()[0]
+                    facet.set_rotation(general_axis_rotation(axis_1.get_rotation_axis(), N.pi / 2. + a_az))
+                    mirror, axis_2 = facet.get_objects()
+                    mirror.set_rotation(general_axis_rotation(axis_2.get_rotation_axis(), a_ze))
         elif tracking == 'tilt_roll':
-            tilt = N.arctan2(trac[:, 1], trac[:, 2])
-            roll = N.arcsin(trac[:, 0])
-            for h in range(self._pos.shape[0]):
-                if tracking_error is not None:
-                    err1 = N.random.normal(scale=tracking_error)
-                    err2 = N.random.normal(scale=tracking_error)
-                a_t, a_r = tilt[h] + err1, roll[h] + err2
-                if not (tracking_limits_primary_axis[0] <= a_t <= tracking_limits_primary_axis[1]):
-                    continue
-                if not (tracking_limits_secondary_axis[0] <= a_r <= tracking_limits_secondary_axis[1]):
-                    continue
-                self._heliostats[h].set_rotation(N.dot(rotx(-a_t)[:3, :3], roty(a_r)[:3, :3]))
+            first = N.arctan2(normals[:, 1], normals[:, 2]) + errors[:, 0]
+            second = N.arcsin(normals[:, 0]) + errors[:, 1]
+            for k, heliostat in enumerate(self._heliostats):
+                if _in_limits(first[k], lim_1) and _in_limits(second[k], lim_2):
+                    heliostat.set_rotation(N.dot(rotx(-first[k])[:3, :3], roty(second[k])[:3, :3]))
         # re-run the frame propagation from the root (the reference re-initialises for the same reason, :192)
         Assembly.__init__(self, subassemblies=self._heliostats)
 
