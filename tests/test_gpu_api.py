@@ -421,3 +421,43 @@ def test_view_factors_of_a_cylindrical_cavity():
     sigma = N.sqrt(exact * (1. - exact) / n)
     assert N.all(N.abs(a[:2] - exact) <= 4. * sigma), (a, exact)
     assert N.isclose(a.sum(), 1., atol=1e-4)
+
+
+def test_sun_tracking_updates_frames_on_the_device():
+    """a heliostat field re-aimed for another sun position: the engine sends new frames to the scene it already has on the
+    device (trc_scene_update_frames) -- same results as an engine that compiles the re-aimed field from scratch"""
+    from tracer_amd import scenes
+    from tracer_amd.models.heliostat_field import solar_vector
+    plant, field, rec, src = scenes.nsttf_field(n_heliostats=30)
+    eng = TracerEngine(plant)
+    ue, ve = scenes.nsttf_fluxmap_edges()
+    eng.set_fluxmap(30, ue, ve)                   # the receiver does not move: its flux map survives the update
+    n = 200000
+    eng.ray_tracer(scenes.nsttf_source(n, src, seed=8), reps=20, min_energy=1e-10, tree=False, accel=True, seed=8)
+    first_dev = eng._dev
+    a0, _, h0 = eng.get_tallies()
+    # afternoon sun: re-aim the field at the same aim point, new source direction
+    az, zen = N.radians(60.), N.radians(50.)
+    aim = N.tile(N.r_[0., 0., 60.], (30, 1))
+    field.track_sun(az, zen, aim_points=aim)
+    sun = solar_vector(az, zen)
+    src2 = dict(src, center=N.vstack(300. * sun + N.r_[0., 90., 0.]), direction=-sun)
+    eng.reset_tallies(); plant.reset_all_optics()
+    eng.ray_tracer(scenes.nsttf_source(n, src2, seed=9), reps=20, min_energy=1e-10, tree=False, accel=True, seed=9)
+    assert eng._dev is first_dev                   # updated in place
+    a1, _, h1 = eng.get_tallies()
+    f1 = eng.get_fluxmap(30).copy()
+    fresh = TracerEngine(plant)
+    fresh.set_fluxmap(30, ue, ve)
+    plant.reset_all_optics()
+    fresh.ray_tracer(scenes.nsttf_source(n, src2, seed=9), reps=20, min_energy=1e-10, tree=False, accel=True, seed=9)
+    a2, _, h2 = fresh.get_tallies()
+    assert N.array_equal(h1, h2) and N.allclose(a1, a2, rtol=1e-12) and N.allclose(f1, fresh.get_fluxmap(30), rtol=1e-12)
+    assert not N.array_equal(h0, h1) and h1[30] > 0
+    # and the ordered engine after an update (the Kd-tree is rebuilt for the new poses)
+    plant.reset_all_optics()
+    eng.reset_tallies()
+    eng.ray_tracer(scenes.nsttf_source(20000, src2, seed=9), reps=20, min_energy=1e-10, tree=True, accel=True, seed=9)
+    fresh.reset_tallies()
+    fresh.ray_tracer(scenes.nsttf_source(20000, src2, seed=9), reps=20, min_energy=1e-10, tree=True, accel=True, seed=9)
+    assert N.array_equal(eng.get_tallies()[2], fresh.get_tallies()[2])

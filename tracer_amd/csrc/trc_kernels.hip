@@ -1468,6 +1468,7 @@ extern "C" int trc_scene_update_frames(trc_scene *sc, int32_t n_surf, const doub
     HIP_TRY(hipSetDevice(sc->ctx->device));
     HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
     for (int i = 0; i < n_surf; ++i) memcpy(sc->surfs[i].frame, frames12 + 12 * (size_t)i, 12 * sizeof(double));
+    sc->has_kd = false;        // a Kd-tree set before described the old poses: the caller sets a new one (or does without)
     return scene_upload_surfaces(sc);
 }
 

@@ -65,6 +65,15 @@ class CompiledScene(object):
         """Bytes that identify everything uploaded to the device."""
         return bytes(self.descs) + self.extra.tobytes()
 
+    def signature_without_frames(self):
+        """The same with the surface frames left out: equal for two states of a scene that only moved (a heliostat field
+        following the sun) -- then DeviceScene.update_frames is enough."""
+        parts = []
+        for d in self.descs:
+            parts.append(bytes(N.array([d.gm_kind, d.optics_kind, d.flags, d.extra_off, d.extra_len], dtype=N.int32)))
+            parts.append(bytes(N.array(list(d.gm) + list(d.opt))))
+        return b''.join(parts) + self.extra.tobytes()
+
     def frames12(self):
         fr = N.empty((self.n_surf, 12))
         for i, s in enumerate(self.surfaces):
@@ -139,6 +148,14 @@ class DeviceScene(object):
             self.close()
         except Exception:
             pass
+
+    def update_frames(self, compiled):
+        """New poses for the same surfaces (trc_scene_update_frames): boxes and grid are rebuilt by the library, a Kd-tree
+        set before is dropped (it described the old poses); tallies, flux maps and the hit buffer stay."""
+        fr = _cabi.f64(compiled.frames12())
+        _cabi.check(self.lib.trc_scene_update_frames(self.handle, compiled.n_surf, _cabi.ptr(fr)))
+        self.compiled = compiled
+        self._kd_keep = None
 
     # -- acceleration ---------------------------------------------------------------------------
     def set_kdtree(self, tree):

@@ -36,6 +36,8 @@ class TracerEngine(object):
         self.loglevel = loglevel
         self._dev = None
         self._dev_sig = None
+        self._dev_static_sig = None
+        self._dev_frames = None
         self._fluxmap_requests = {}
         self._kd_on_device = None
         self._auto_kd = None
@@ -45,18 +47,30 @@ class TracerEngine(object):
     def _device_scene(self):
         compiled = compile_scene(self._asm)
         sig = compiled.signature()
-        if self._dev is None or sig != self._dev_sig:
+        if self._dev is not None and sig == self._dev_sig:
+            self._dev.compiled = compiled   # same numbers, fresh Surface objects
+            return self._dev
+        if self._dev is not None and compiled.signature_without_frames() == self._dev_static_sig and \
+                self._fluxmaps_unmoved(compiled):
+            # the scene only moved (a heliostat field following the sun): new frames for the scene already on the device
+            self._dev.update_frames(compiled)
+        else:
             if self._dev is not None:
                 self._dev.close()
             self._dev = DeviceScene(compiled)
-            self._dev_sig = sig
-            self._kd_on_device = None
-            self._auto_kd = None
+            self._dev_static_sig = compiled.signature_without_frames()
             for si, (u, v) in self._fluxmap_requests.items():
                 self._dev.set_fluxmap(si, u, v)
-        else:
-            self._dev.compiled = compiled   # same numbers, fresh Surface objects
+        self._dev_sig = sig
+        self._dev_frames = compiled.frames12()      # a snapshot: the Surface objects themselves move with the scene
+        self._kd_on_device = None
+        self._auto_kd = None
         return self._dev
+
+    def _fluxmaps_unmoved(self, compiled):
+        """flux maps are binned in the frame their surface had when they were set: such a surface must not have moved"""
+        new = compiled.frames12()
+        return all(N.array_equal(self._dev_frames[si], new[si]) for si in self._fluxmap_requests)
 
     def set_fluxmap(self, surface, u_edges, v_edges):
         """
