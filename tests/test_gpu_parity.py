@@ -393,6 +393,17 @@ def test_kd_accel_equals_brute_and_reference(ctx):
     h4 = dev.get_hits()
     assert len(h4['surf']) == n_cap and N.array_equal(key(h4), key(h1))
     dev.close()
+    # the streaming kernels walking the caller's Kd-tree instead of the grid (TRC_STREAM_SEARCH=1)
+    os.environ['TRC_STREAM_SEARCH'] = '1'
+    try:
+        dev = DeviceScene(cs, ctx)
+        dev.set_kdtree(kd)
+        st_kd, _ = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e), 100, 1e-10, 1, accel=True, stream=True)
+        a_k, r_k, h_k = dev.get_tallies()
+        dev.close()
+    finally:
+        del os.environ['TRC_STREAM_SEARCH']
+    assert N.array_equal(h_k, tl_b[2]) and N.allclose(a_k, tl_b[0], rtol=1e-12, atol=1e-9) and st_kd.segments == st.segments
     for accel in (True, False):      # streaming engine, with the tree and with the single-leaf brute form
         dev = DeviceScene(cs, ctx)
         dev.set_kdtree(kd)
