@@ -224,7 +224,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                          'traffic': traffic,
                          'kernel': 'k_trace_coop<512>' if launches == 1 else
-                                   'fast engine, streaming form: k_s_gen + k_s_walk<256> + k_s_exact + k_s_shade per '
+                                   'fast engine, streaming form: k_s_gen + k_s_walk<256,grid> + k_s_exact + k_s_shade per '
                                    'bounce (%d launches per step)' % launches,
                          'kernel_ms_per_launch': kms / args.steps,
                          'algorithmic_bytes_per_launch': seg / args.steps * B_SEG},
