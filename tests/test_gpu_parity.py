@@ -704,3 +704,42 @@ def test_streaming_edge_scenes(ctx):
         for k in (1, 2):
             assert N.array_equal(res[k][2], res[0][2]) and res[k][3] == res[0][3] and res[k][4] == res[0][4], (len(objs), n, reps, k)
             assert N.allclose(res[k][0], res[0][0], rtol=1e-12) and N.allclose(res[k][5], res[0][5], rtol=1e-12)
+
+
+def test_many_surfaces_scene(ctx):
+    """1500 small plates: the per-workgroup tables of the streaming kernels need more than 64 KB of LDS (boxes, grid,
+    records, tallies); grid search == brute force on both forms of the fast engine"""
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM, RoundPlateGM
+    from tracer_amd.spatial_geometry import general_axis_rotation
+    from tracer_amd import optics_callables as opt
+    from tracer_amd.scene import compile_scene, DeviceScene
+    from tracer_amd.ray_bundle import RayBundle
+    r = N.random.RandomState(11)
+    objs = []
+    for k in range(1500):
+        gm = RectPlateGM(r.uniform(0.5, 2.), r.uniform(0.5, 2.)) if k % 2 else RoundPlateGM(r.uniform(0.4, 1.2))
+        axis = r.normal(size=3)
+        axis /= N.linalg.norm(axis)
+        tr = N.vstack((N.hstack((general_axis_rotation(axis, r.uniform(0, 2 * N.pi)), r.uniform(-30., 30., size=(3, 1)))), N.r_[[0., 0., 0., 1.]]))
+        objs.append(AssembledObject(surfs=[Surface(gm, opt.Reflective(0.4) if k % 5 else opt.Lambertian(0.6))], transform=tr))
+    cs = compile_scene(Assembly(objects=objs))
+    n = 200000
+    o = r.normal(size=(3, n))
+    o = o / N.sqrt((o ** 2).sum(axis=0)) * 70.
+    d = r.uniform(-30., 30., size=(3, n)) - o
+    d /= N.sqrt((d ** 2).sum(axis=0))
+    res = {}
+    for key, accel, stream in (('mega_brute', False, False), ('stream_grid', True, True), ('stream_brute', False, True)):
+        dev = DeviceScene(cs, ctx)
+        st, _ = dev.trace_fast(RayBundle(vertices=o, directions=d, energy=N.ones(n)), 6, 1e-6, 3, accel=accel, stream=stream)
+        res[key] = dev.get_tallies() + (st.segments, st.launches)
+        dev.close()
+    a0, r0, h0, s0, l0 = res['mega_brute']
+    assert h0.sum() > 0.25 * n and l0 == 1
+    for key in ('stream_grid', 'stream_brute'):
+        a1, r1, h1, s1, l1 = res[key]
+        assert l1 > 1 and N.array_equal(h1, h0) and s1 == s0, key
+        assert N.allclose(a1, a0, rtol=1e-9, atol=1e-9), key
