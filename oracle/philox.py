@@ -39,6 +39,15 @@ def uniform_pair(seed, rid, event, block):
     return u01(o[0], o[1]), u01(o[2], o[3])
 
 
+def uniform_quad(seed, rid, event, block):
+    """four uniforms in (0,1) with 32 random bits each from one block: the draws of a source ray (trc_uniform_quad)"""
+    rid = N.asarray(rid, dtype=N.uint64)
+    ones = N.ones(rid.shape, dtype=N.uint64)
+    o = philox4x32_10(rid & MASK32, rid >> N.uint64(32), ones * N.uint64(event), ones * N.uint64(block),
+                      int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
+    return tuple((w.astype(N.float64) + 0.5) * (1.0 / 4294967296.0) for w in o)
+
+
 def normal_pair(u0, u1):
     """Box-Muller"""
     r = N.sqrt(-2.0 * N.log(1.0 - u0))

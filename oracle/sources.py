@@ -83,8 +83,7 @@ def generate(src, n, seed, offset, uniforms=None):
     """
     rid = N.arange(n, dtype=N.uint64) + N.uint64(offset)
     if uniforms is None:
-        u0, u1 = philox.uniform_pair(seed, rid, 0, 0)
-        u2, u3 = philox.uniform_pair(seed, rid, 0, 1)
+        u0, u1, u2, u3 = philox.uniform_quad(seed, rid, 0, 0)
     else:
         u0, u1, u2, u3 = uniforms
     p = src['p']
