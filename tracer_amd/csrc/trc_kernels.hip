@@ -155,7 +155,8 @@ struct trc_scene {
     FluxMapDev *d_fms;
     double *d_fm_edges;
     unsigned long long *d_counters;
-    double *d_energy_left;
+    double *d_energy_left;     // = (double *)(d_counters + 5)
+    trc_source_desc *d_src_buf; // device copy of the source descriptor of the call in progress (kept between calls)
     int64_t hit_cap;      // entries allocated: the capacity asked for + TRC_HIT_SLACK
     int64_t hit_cap_user;
     uint32_t hit_epoch;   // bumped whenever the cursor is reset: chunks left open by earlier launches are stale
@@ -1432,14 +1433,13 @@ extern "C" int trc_scene_create(trc_ctx *ctx, int32_t n_surf, const trc_surface_
         if ((st = dev_alloc(&sc->d_extra, (size_t)n_extra))) break;
         if ((st = dev_alloc(&sc->d_fm_of_surf, (size_t)n_surf))) break;
         if ((st = dev_alloc(&sc->d_counters, 8))) break;
-        if ((st = dev_alloc(&sc->d_energy_left, 1))) break;
+        sc->d_energy_left = (double *)(sc->d_counters + 5);      // same 64-byte block as the counters: one read-back gets both
         if ((st = scene_upload_surfaces(sc))) break;
         if (n_extra > 0 && hipMemcpy(sc->d_extra, sc->extra_h.data(), (size_t)n_extra * sizeof(double),
                                      hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "extra upload failed"); break; }
         if (hipMemcpy(sc->d_fm_of_surf, sc->fm_of_surf_h.data(), (size_t)n_surf * sizeof(int32_t),
                       hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "upload failed"); break; }
-        if (hipMemset(sc->d_counters, 0, 8 * sizeof(unsigned long long)) != hipSuccess ||
-            hipMemset(sc->d_energy_left, 0, sizeof(double)) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memset failed"); break; }
+        if (hipMemset(sc->d_counters, 0, 8 * sizeof(unsigned long long)) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memset failed"); break; }
         if ((st = scene_alloc_tally(sc))) break;
     } while (0);
     if (st != TRC_OK) { trc_scene_destroy(sc); return st; }
@@ -1457,7 +1457,7 @@ extern "C" int trc_scene_destroy(trc_scene *sc) {
     dev_free(sc->d_a_sbox); dev_free(sc->d_a_nodes); dev_free(sc->d_a_leaf); dev_free(sc->d_a_unbounded); dev_free(sc->d_a_bleaf);
     dev_free(sc->d_a_goff); dev_free(sc->d_a_glist); dev_free(sc->d_a_gapart);
     dev_free(sc->d_kd_split); dev_free(sc->d_tally); dev_free(sc->d_fm_of_surf); dev_free(sc->d_fms);
-    dev_free(sc->d_fm_edges); dev_free(sc->d_counters); dev_free(sc->d_energy_left); dev_free(sc->d_h_surf);
+    dev_free(sc->d_fm_edges); dev_free(sc->d_counters); dev_free(sc->d_src_buf); dev_free(sc->d_h_surf);
     for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
     delete sc;
     return TRC_OK;
@@ -1807,10 +1807,19 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
     double tally_before[2] = {0, 0};
     unsigned long long cnt_before[4] = {0, 0, 0, 0};
     double eleft_before = 0;
+    double stream_seg = 0, stream_hits = 0;
+    bool stream_counts_known = false;
     const int S = sc->n_surf;
     do {
         if (in) { if ((st = check_rays(in, n, "trc_trace_fast")) || (st = stage_rays(in, n, true, &dr))) break; }
-        else if ((st = upload_source(src, &d_src))) break;
+        else {
+            // the scene keeps a device buffer for the descriptor of the call in progress (hipMalloc / hipFree per call
+            // cost more than the upload)
+            if (src->kind < TRC_SRC_PILLBOX_DISK || src->kind > TRC_SRC_VF_FRUSTUM) { st = trc_fail(TRC_ERR_UNSUPPORTED, "source kind %d is not in the native table", src->kind); break; }
+            if (!sc->d_src_buf && (st = dev_alloc(&sc->d_src_buf, 1))) break;
+            if (hipMemcpy(sc->d_src_buf, src, sizeof(trc_source_desc), hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "source upload failed"); break; }
+            d_src = sc->d_src_buf;
+        }
         int64_t last_cap = 0;
         if (flags & TRC_TRACE_KEEP_LAST) {
             if (!last || !last->x || !last->y || !last->z || !last->dx || !last->dy || !last->dz || !last->e || last->on_device) {
@@ -1820,11 +1829,13 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
             for (int i = 0; i < 7 && st == TRC_OK; ++i) st = dev_alloc(&d_last[i], (size_t)last_cap);
             if (st) break;
         }
-        if (hipMemcpy(tally_before, sc->d_tally + 3 * S, sizeof(tally_before), hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(cnt_before, sc->d_counters, sizeof(cnt_before), hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(&eleft_before, sc->d_energy_left, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+        // counters and the energy left live in one 64-byte block: one read before, one after
+        unsigned long long blk_before[8];
+        if (hipMemcpy(blk_before, sc->d_counters, sizeof(blk_before), hipMemcpyDeviceToHost) != hipSuccess) {
             st = trc_fail(TRC_ERR_DEVICE, "counter readback failed"); break;
         }
+        for (int i = 0; i < 4; ++i) cnt_before[i] = blk_before[i];
+        memcpy(&eleft_before, &blk_before[5], sizeof(double));
         // the `last` cursor restarts for every call
         unsigned long long zero = 0;
         if (hipMemcpy(sc->d_counters + 2, &zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
@@ -1896,9 +1907,10 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
                 if (!sc->stream_eng) { st = trc_fail(TRC_ERR_NOMEM, "out of host memory"); break; }
                 memset(sc->stream_eng, 0, sizeof(StreamEngine));
             }
-            double segd = 0, hitd = 0;
-            if ((st = stream_trace(sc, P, want_accel, src ? src->kind : -1, *sc->stream_eng, &s, &segd, &hitd))) break;
+            if ((st = stream_trace(sc, P, want_accel, src ? src->kind : -1, *sc->stream_eng, &s, &stream_seg, &stream_hits))) break;
+            stream_counts_known = true;
         } else {
+        if (hipMemcpy(tally_before, sc->d_tally + 3 * S, sizeof(tally_before), hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "counter readback failed"); break; }
         void (*kern)(FastParams) = nullptr;
         if (m32) kern = threads == 1024 ? k_trace_coop<1024> : (threads == 768 ? k_trace_coop<768> : (threads == 512 ? k_trace_coop<512> : k_trace_coop<256>));
         else kern = k_trace_fast<256>;
@@ -1930,16 +1942,24 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
             s.launches = 1;
         }
         }
-        double tally_after[2];
-        unsigned long long cnt_after[4];
+        unsigned long long blk_after[8], cnt_after[4];
         double eleft_after;
-        if (hipMemcpy(tally_after, sc->d_tally + 3 * S, sizeof(tally_after), hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(cnt_after, sc->d_counters, sizeof(cnt_after), hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(&eleft_after, sc->d_energy_left, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+        if (hipMemcpy(blk_after, sc->d_counters, sizeof(blk_after), hipMemcpyDeviceToHost) != hipSuccess) {
             st = trc_fail(TRC_ERR_DEVICE, "counter readback failed"); break;
         }
-        s.segments = (int64_t)(tally_after[0] - tally_before[0] + 0.5);
-        s.hits = (int64_t)(tally_after[1] - tally_before[1] + 0.5);
+        for (int i = 0; i < 4; ++i) cnt_after[i] = blk_after[i];
+        memcpy(&eleft_after, &blk_after[5], sizeof(double));
+        if (stream_counts_known) {              // the streaming form counted on the host
+            s.segments = (int64_t)(stream_seg + 0.5);
+            s.hits = (int64_t)(stream_hits + 0.5);
+        } else {
+            double tally_after[2];
+            if (hipMemcpy(tally_after, sc->d_tally + 3 * S, sizeof(tally_after), hipMemcpyDeviceToHost) != hipSuccess) {
+                st = trc_fail(TRC_ERR_DEVICE, "counter readback failed"); break;
+            }
+            s.segments = (int64_t)(tally_after[0] - tally_before[0] + 0.5);
+            s.hits = (int64_t)(tally_after[1] - tally_before[1] + 0.5);
+        }
         s.rays_left = (int64_t)(cnt_after[3] - cnt_before[3]);
         s.hits_dropped = (int64_t)(cnt_after[1] - cnt_before[1]);
         s.energy_left = eleft_after - eleft_before;
@@ -1954,7 +1974,6 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         }
     } while (0);
     dr.release();
-    dev_free(d_src);
     for (int i = 0; i < 7; ++i) dev_free(d_last[i]);
     if (stats) *stats = s;
     return st;

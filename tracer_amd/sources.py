@@ -67,20 +67,21 @@ class LazySourceBundle(RayBundle):
 def _fill_source(kind, center, rot_pos, rot_dir, params, energy, buie=None):
     s = _cabi.SourceDesc()
     s.kind = kind
-    c = N.ravel(N.asarray(center, dtype=float))
-    for i in range(3):
-        s.center[i] = c[i]
-    rp = N.ravel(N.asarray(rot_pos, dtype=float))
-    rd = N.ravel(N.asarray(rot_dir, dtype=float))
-    for i in range(9):
-        s.rot_pos[i] = rp[i]
-        s.rot_dir[i] = rd[i]
-    for i, p in enumerate(params):
-        s.p[i] = float(p)
+
+    def put(field, values):
+        # block copy into the ctypes array (element-wise assignment of the 639-entry Buie table was most of the
+        # cost of making a bundle)
+        a = N.ascontiguousarray(N.ravel(N.asarray(values, dtype=float)))
+        C.memmove(field, a.ctypes.data, a.nbytes)
+
+    put(s.center, center)
+    put(s.rot_pos, rot_pos)
+    put(s.rot_dir, rot_dir)
+    if len(params):
+        put(s.p, [float(p) for p in params])
     s.energy = float(energy)
     if buie is not None:
-        for i, b in enumerate(buie):
-            s.buie[i] = b
+        put(s.buie, buie)
     return s
 
 
@@ -237,7 +238,20 @@ def solar_disk_bundle(num_rays, center, direction, radius, ang_range, flux=None,
                        None, seed, ray_offset)
 
 
+_buie_tables = {}
+
+
 def buie_table(CSR, pre_process_CSR=True):
+    """the table of _buie_table, computed once per (CSR, pre_process_CSR): Monte-Carlo loops make one bundle per batch"""
+    key = (float(CSR), bool(pre_process_CSR))
+    if key not in _buie_tables:
+        if len(_buie_tables) > 64:
+            _buie_tables.clear()
+        _buie_tables[key] = _buie_table(*key)
+    return _buie_tables[key]
+
+
+def _buie_table(CSR, pre_process_CSR=True):
     """
     The Buie sunshape sampling table of the reference (sources.py:333-361): 211 polar angles up to
     4.65 mrad, g = phi*cos*sin with phi = cos(0.326 theta)/cos(0.308 theta) (theta in mrad), the

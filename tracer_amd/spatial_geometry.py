@@ -26,7 +26,16 @@ def rotation_to_z(vecs):
     perp = unit(v_y, -v_x, 0) or x-hat when v is along z (spatial_geometry.py:24-48).
     Accepts one vector (returns 3x3) or an (n,3) array (returns (n,3,3)).
     """
-    v = N.atleast_2d(N.asarray(vecs, dtype=float))
+    v = N.asarray(vecs, dtype=float)
+    if v.ndim == 1:         # one vector: the same arithmetic without the array machinery (this runs once per source bundle)
+        x, y, z = float(v[0]), float(v[1]), float(v[2])
+        px, py = y, -x
+        if px == 0. and py == 0.:
+            px, py = 1., 0.
+        norm = math.sqrt(px * px + py * py + 0.)
+        px, py = px / norm, py / norm
+        return N.array([[px, y * 0. - z * py, x], [py, z * px - x * 0., y], [0., x * py - y * px, z]])
+    v = N.atleast_2d(v)
     perp = N.zeros_like(v)
     perp[:, 0] = v[:, 1]
     perp[:, 1] = -v[:, 0]
