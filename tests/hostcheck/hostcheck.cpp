@@ -74,6 +74,21 @@ int hc_source(const trc_source_desc *src, long n, uint64_t seed, uint64_t offset
     return 0;
 }
 
+// the aureole's restricted power function against the library's
+int hc_pow_pos(long n, const double *x, const double *y, double *out) {
+    for (long i = 0; i < n; ++i) out[i] = trc_pow_pos(x[i], y[i]);
+    return 0;
+}
+
+// the LDS form of the Buie inversion (streaming generation kernel) and the plain one, same table, same uniforms
+int hc_buie_theta(const double *tab, long n, const double *Rv, double *plain, double *staged) {
+    static trc_buie_fast F;
+    trc_buie_fast_fill(tab, &F, 0, 0, 1);
+    trc_buie_fast_fill(tab, &F, 1, 0, 1);
+    for (long i = 0; i < n; ++i) { plain[i] = trc_buie_theta(tab, nullptr, Rv[i]); staged[i] = trc_buie_theta_fast(&F, Rv[i]); }
+    return 0;
+}
+
 // nearest hit over a whole scene, brute force and Kd-tree
 int hc_nearest(int n_surf, const trc_surface_desc *surfs, const double *extra, const trc_kdtree_desc *kd, long n, const double *x,
                const double *y, const double *z, const double *dx, const double *dy, const double *dz, double *t_brute,

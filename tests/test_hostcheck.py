@@ -109,6 +109,42 @@ def test_core_sources_vs_oracle(hc):
         assert N.allclose(d, do, rtol=1e-9, atol=1e-11), name
 
 
+def test_core_pow_pos_vs_libm(hc):
+    """trc_pow_pos (the aureole inversion's power function) against numpy's pow over and beyond the aureole's range"""
+    rng = N.random.RandomState(11)
+    x = N.ascontiguousarray(N.hstack((rng.uniform(0.05, 0.6, 200000), 10. ** rng.uniform(-6, 6, 200000),
+                                      [1., 2., 0.5, N.sqrt(2.), N.sqrt(0.5), 1. - 2 ** -53, 1. + 2 ** -52])))
+    y = N.ascontiguousarray(N.hstack((rng.uniform(2.5, 4., 200000), rng.uniform(-0.8, 0.8, 200000), rng.uniform(-3, 3, 7))))
+    out = N.empty_like(x)
+    hc.hc_pow_pos(C.c_long(len(x)), _p(x), _p(y), _p(out))
+    rel = N.abs(out / x ** y - 1.)
+    assert rel.max() < 1.5e-15, rel.max()
+
+
+def test_core_buie_staged_inversion_equals_plain(hc):
+    """the per-bin folded form of sources.py:364-377 used by the streaming generation kernel against the plain form, on the
+    Buie tables of the source fixtures (CSR 0.01 .. 0.3 and the CSR = 0 table) and on uniforms that cover every bin edge"""
+    s = load('sources.npz')
+    seen = 0
+    for i, name in enumerate(case_names(s)):
+        src = source_dict(s, 's%d_' % i)
+        tab = N.ascontiguousarray(src['buie'], dtype=float)
+        if not tab.any():
+            continue
+        seen += 1
+        ne = (len(tab) - 6) // 3 - 1
+        cdf = tab[2 * (ne + 1):3 * (ne + 1)]
+        rng = N.random.RandomState(i)
+        edges = N.hstack((cdf, N.nextafter(cdf, 0.), N.nextafter(cdf, 1.), N.arange(1024) / 1024., N.nextafter(N.arange(1, 1025) / 1024., 0.)))
+        Rv = N.ascontiguousarray(N.hstack((rng.uniform(size=300000), edges[(edges >= 0.) & (edges < 1.)])))
+        a, b = N.empty_like(Rv), N.empty_like(Rv)
+        hc.hc_buie_theta(_p(tab), C.c_long(len(Rv)), _p(Rv), _p(a), _p(b))
+        ok = N.isfinite(a)
+        assert N.array_equal(ok, N.isfinite(b)), name
+        assert N.allclose(a[ok], b[ok], rtol=1e-10, atol=1e-15), (name, N.abs(a[ok] - b[ok]).max())
+    assert seen >= 2
+
+
 def test_core_kd_traversal_equals_brute_force(hc):
     """the device traversal (front-to-back with early exit) returns the brute-force (t, surface) for every ray"""
     from tracer_amd import scenes, _cabi

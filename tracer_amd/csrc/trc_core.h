@@ -775,7 +775,16 @@ TRC_HD bool trc_ray32_prepare(const double *slo, const double *shi, const double
     const double v[3] = {vx, vy, vz}, d[3] = {dx, dy, dz};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the entry distance only places the single-precision origin inside the (inflated) box: a float reciprocal and
+        // one Newton step (4e-15 relative) instead of the ~28 instructions of an IEEE double division; 1/0 and 1/tiny
+        // stay infinite with their sign
+        float fi = __builtin_amdgcn_rcpf((float)d[i]);
+        double inv = (double)fi;
+        if (fabsf(fi) < 1e30f) inv = inv * (2.0 - d[i] * inv);
+#else
         double inv = 1.0 / d[i];
+#endif
         double a = (slo[i] - v[i]) * inv, b = (shi[i] - v[i]) * inv;
         t0 = fmax(t0, fmin(a, b));
         t1 = fmin(t1, fmax(a, b));
@@ -784,7 +793,11 @@ TRC_HD bool trc_ray32_prepare(const double *slo, const double *shi, const double
     r->oy = (float)(vy + t0 * dy - cen[1]);
     r->oz = (float)(vz + t0 * dz - cen[2]);
     r->dx = (float)dx; r->dy = (float)dy; r->dz = (float)dz;
+#if defined(__HIP_DEVICE_COMPILE__)
+    r->ix = __builtin_amdgcn_rcpf(r->dx); r->iy = __builtin_amdgcn_rcpf(r->dy); r->iz = __builtin_amdgcn_rcpf(r->dz);   // 1 ulp
+#else
     r->ix = 1.0f / r->dx; r->iy = 1.0f / r->dy; r->iz = 1.0f / r->dz;
+#endif
     *t_entry = t0;
     return t1 >= t0;
 }
@@ -1180,6 +1193,31 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
 // ---------------------------------------------------------------------------------------------
 // S1..S3 -- sources.  One ray from its four uniforms.
 // ---------------------------------------------------------------------------------------------
+// x^y for a positive normal x whose result is a normal number: log2 of the mantissa in [sqrt(1/2), sqrt(2)) by the atanh
+// series, 2^t by the Taylor series of e^(f ln 2) on |f| <= 1/2.  Relative error below 1.5e-15 for |y log2 x| < 16 (checked
+// against pow() in tests/hostcheck); ~70 instructions where the library pow(), with its special cases and its
+// extended-precision logarithm, is ~750 -- and a wave pays for it whenever one of its 64 rays falls in the aureole.
+TRC_HD double trc_pow_pos(double x, double y) {
+    uint64_t bits = __builtin_bit_cast(uint64_t, x);
+    int e = (int)(bits >> 52) - 1023;
+    double m = __builtin_bit_cast(double, (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);      // [1, 2)
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0), s2 = s * s;                   // ln m = 2 atanh(s), |s| <= 0.1716
+    double q = 1.0 / 23.0;
+    q = q * s2 + 1.0 / 21.0; q = q * s2 + 1.0 / 19.0; q = q * s2 + 1.0 / 17.0; q = q * s2 + 1.0 / 15.0;
+    q = q * s2 + 1.0 / 13.0; q = q * s2 + 1.0 / 11.0; q = q * s2 + 1.0 / 9.0;  q = q * s2 + 1.0 / 7.0;
+    q = q * s2 + 1.0 / 5.0;  q = q * s2 + 1.0 / 3.0;
+    double ln_m = 2.0 * s + 2.0 * s * s2 * q;
+    double l2m = ln_m * 1.4426950408889634;
+    double n = rint(y * ((double)e + l2m));                         // y log2 x = n + f, the exponent's part of f exactly
+    double z = (fma(y, (double)e, -n) + y * l2m) * 0.6931471805599453;      // |z| <= 0.347
+    double r = 1.0 / 6227020800.0;                                  // e^z, terms to z^13/13! (4e-18)
+    r = r * z + 1.0 / 479001600.0; r = r * z + 1.0 / 39916800.0; r = r * z + 1.0 / 3628800.0; r = r * z + 1.0 / 362880.0;
+    r = r * z + 1.0 / 40320.0; r = r * z + 1.0 / 5040.0; r = r * z + 1.0 / 720.0; r = r * z + 1.0 / 120.0;
+    r = r * z + 1.0 / 24.0; r = r * z + 1.0 / 6.0; r = r * z + 0.5; r = r * z + 1.0; r = r * z + 1.0;
+    return r * __builtin_bit_cast(double, (uint64_t)((int64_t)n + 1023) << 52);
+}
+
 // Buie sunshape polar angle from its uniform (sources.py:364-377).  tab: trc_source_desc.buie
 // ray-independent parts of the aureole inversion (:377); kernels compute them once per block
 TRC_HD void trc_buie_aureole_consts(const double *tab, double *c) {
@@ -1215,15 +1253,76 @@ TRC_HD double trc_buie_theta(const double *tab, const double *aur, double Rv) {
     if (aur) { c[0] = aur[0]; c[1] = aur[1]; c[2] = aur[2]; }
     else trc_buie_aureole_consts(tab, c);
     double base = (Rv - 1.0) * c[0] + Rv * c[1];
-    return pow(base, c[2]);
+    return trc_pow_pos(base, c[2]);
 }
 
-// buie: the table of the descriptor (or its LDS copy); aur: trc_buie_aureole_consts of it, or null.
+// The same inversion arranged for a kernel's LDS (the streaming engine's generation kernel): the bin is found from a
+// 1024-entry first guess over the uniform and a short forward scan instead of an 8-step bisection of dependent LDS
+// reads, and everything of :370-371 that does not depend on the ray is folded per bin into
+//     theta = a_i + k_i sqrt(w2_i + q_i (R - cdf_i)),   a_i = (A th_{i+1} - B th_i)/(A - B),  k_i = -1/(A - B),
+//     w2_i = ((th_i - th_{i+1}) A)^2,  q_i = 2 I_dni (th_{i+1} - th_i)(B - A)
+// -- the reference's expression with its division replaced by a multiplication (a few ulp apart; compared with
+// trc_buie_theta in tests/hostcheck).  122 -> ~45 VALU instructions per ray.
+#define TRC_BUIE_GUESS 1024
+struct trc_buie_fast {
+    double cdf[TRC_BUIE_NELEM + 1];
+    double rec[TRC_BUIE_NELEM][4];     // a, k, w2, q
+    double aur[3];                     // trc_buie_aureole_consts
+    double cdf_end;
+    int csr_pos;
+    uint8_t guess[TRC_BUIE_GUESS];     // largest bin i (<= NELEM-1) with cdf[i] <= k / TRC_BUIE_GUESS
+};
+static_assert(TRC_BUIE_NELEM <= 256, "bin numbers are stored in bytes");
+
+// cooperative fill: thread `tid` of `nth` (host: 0 of 1).  Phase 0 copies the cdf, phase 1 (after a barrier on the device)
+// derives the rest from it.
+TRC_HD void trc_buie_fast_fill(const double *tab, trc_buie_fast *F, int phase, int tid, int nth) {
+    const int NE = TRC_BUIE_NELEM;
+    const double *theta = tab, *g = tab + (NE + 1), *cdf = tab + 2 * (NE + 1), *sc = tab + 3 * (NE + 1);
+    if (phase == 0) {
+        for (int i = tid; i <= NE; i += nth) F->cdf[i] = cdf[i];
+        if (tid == 0) { trc_buie_aureole_consts(tab, F->aur); F->cdf_end = cdf[NE]; F->csr_pos = sc[5] != 0.0 ? 1 : 0; }
+        return;
+    }
+    const double I_dni = sc[0];
+    for (int i = tid; i < NE; i += nth) {
+        double A = g[i], B = g[i + 1], t0 = theta[i], t1 = theta[i + 1];
+        double w = (t0 - t1) * A;
+        F->rec[i][0] = (A * t1 - B * t0) / (A - B);
+        F->rec[i][1] = -1.0 / (A - B);
+        F->rec[i][2] = w * w;
+        F->rec[i][3] = 2.0 * I_dni * (t1 - t0) * (B - A);
+    }
+    for (int k = tid; k < TRC_BUIE_GUESS; k += nth) {
+        const double Rv = (double)k * (1.0 / TRC_BUIE_GUESS);
+        int lo = 0, hi = NE;                       // largest i in [0, NE-1] with cdf[i] <= Rv (cdf[0] = 0)
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (F->cdf[mid] <= Rv) lo = mid; else hi = mid;
+        }
+        F->guess[k] = (uint8_t)lo;
+    }
+}
+
+TRC_HD double trc_buie_theta_fast(const trc_buie_fast *F, double Rv) {
+    if (Rv < F->cdf_end) {
+        int i = F->guess[(int)(Rv * (double)TRC_BUIE_GUESS)];
+        while (F->cdf[i + 1] <= Rv) ++i;           // ends: cdf[NELEM] = cdf_end > Rv
+        const double *r = F->rec[i];
+        return r[0] + r[1] * sqrt(r[2] + r[3] * (Rv - F->cdf[i]));
+    }
+    if (!F->csr_pos) return 0.0;
+    return trc_pow_pos((Rv - 1.0) * F->aur[0] + Rv * F->aur[1], F->aur[2]);
+}
+
+// buie: the table of the descriptor (or its LDS copy); aur: trc_buie_aureole_consts of it, or null; bf: the
+// trc_buie_fast form of the table when the caller has staged one (then buie and aur are not read).
 // KIND >= 0 promises src->kind == KIND (the streaming engine compiles the Buie disc on its own: 158 instead of 237
 // VGPRs); KIND < 0 reads the kind from the descriptor.
 template <int KIND>
 TRC_HD void trc_source_ray_t(const trc_source_desc *src, const double *buie, const double *aur, uint64_t seed, uint64_t rid,
-                             double *px, double *py, double *pz, double *dx, double *dy, double *dz) {
+                             double *px, double *py, double *pz, double *dx, double *dy, double *dz,
+                             const trc_buie_fast *bf = nullptr) {
     double u0, u1, u2, u3;
     trc_uniform_quad(seed, rid, 0, 0, &u0, &u1, &u2, &u3);      // event 0 = source generation
     double lx, ly, lz = 0.0, ax, ay, az;
@@ -1286,7 +1385,7 @@ TRC_HD void trc_source_ray_t(const trc_source_desc *src, const double *buie, con
         double sph, cph, st, ct, sxi, cxi;
         trc_sincos_2pi(u1, &sph, &cph);
         lx = r * cph; ly = r * sph;
-        double th = trc_buie_theta(buie, aur, u2);
+        double th = bf ? trc_buie_theta_fast(bf, u2) : trc_buie_theta(buie, aur, u2);
         trc_sincos_small(th, &st, &ct);
         trc_sincos_2pi(u3, &sxi, &cxi);
         ax = cxi * st; ay = sxi * st; az = ct;
@@ -1300,7 +1399,7 @@ TRC_HD void trc_source_ray_t(const trc_source_desc *src, const double *buie, con
     }
     default: {                          // TRC_SRC_BUIE_RECT (sources.py:485-486)
         lx = p[0] * (u0 - 0.5); ly = p[1] * (u1 - 0.5);
-        double th = trc_buie_theta(buie, aur, u2);
+        double th = bf ? trc_buie_theta_fast(bf, u2) : trc_buie_theta(buie, aur, u2);
         double st, ct, sxi, cxi;
         trc_sincos_small(th, &st, &ct);
         trc_sincos_2pi(u3, &sxi, &cxi);

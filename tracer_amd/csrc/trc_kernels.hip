@@ -607,10 +607,10 @@ __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *re
 template <int KIND = -1>
 __device__ __forceinline__ void fast_new_ray(const FastParams &P, const double *buie, long long id, double &px, double &py,
                                              double &pz, double &dx, double &dy, double &dz, double &e, double &ref, double &wl,
-                                             unsigned long long &rid) {
+                                             unsigned long long &rid, const trc_buie_fast *bf = nullptr) {
     rid = P.rid ? P.rid[id] : (P.ray_offset + (unsigned long long)id);
     if (P.src) {
-        trc_source_ray_t<KIND>(P.src, buie, buie ? buie + TRC_BUIE_TABLE : nullptr, P.seed, rid, &px, &py, &pz, &dx, &dy, &dz);
+        trc_source_ray_t<KIND>(P.src, buie, buie ? buie + TRC_BUIE_TABLE : nullptr, P.seed, rid, &px, &py, &pz, &dx, &dy, &dz, bf);
         e = P.src->energy; ref = 1.0; wl = 0.0;
     } else {
         px = P.x[id]; py = P.y[id]; pz = P.z[id];
