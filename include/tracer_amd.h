@@ -257,6 +257,21 @@ int trc_scene_get_fluxmap(trc_scene *scene, int32_t surf, double *out /* nu*nv, 
 /* captured hits, in device arrival order. Query n first with all arrays NULL. */
 int trc_scene_get_hits(trc_scene *scene, int64_t *n, int32_t *surf, double *e_abs, double *e_in,
                        double *px, double *py, double *pz, double *dx, double *dy, double *dz);
+/* View-factor allocation (emissive_losses/view_factors_3D.py:239-356 and :598-674, `alloc_VF`): the absorbed energy of
+   the captured hits collected per element on the device instead of fetching every hit and looping over the elements on
+   the host.  Element j takes the hits of the surfaces surf_lo[j]..surf_hi[j] whose global azimuth atan2(y,x) (brought
+   to [0, 2 pi), :304-305), height z and radius sqrt(x^2+y^2) lie in ranges6[6j..6j+5] = {ang0, ang1, h0, h1, r0, r1}.
+   mode[j] bits: TRC_BIN_ANGLE / TRC_BIN_HEIGHT / TRC_BIN_RADIUS select the tests (closed ranges, so that a hit on a
+   shared edge counts in both elements, as in the reference); TRC_BIN_ROUND9 rounds height and radius to 9 decimals
+   first (numpy.around, :308 and :633-634); TRC_BIN_RADIUS_HALF_OPEN makes the radius test r0 <= r < r1 (cone elements,
+   :669).  out[n_bins] is overwritten.  The hit buffer is left as it is. */
+#define TRC_BIN_ANGLE 0x1
+#define TRC_BIN_HEIGHT 0x2
+#define TRC_BIN_RADIUS 0x4
+#define TRC_BIN_ROUND9 0x8
+#define TRC_BIN_RADIUS_HALF_OPEN 0x10
+int trc_scene_bin_hits(trc_scene *scene, int32_t n_bins, const int32_t *surf_lo, const int32_t *surf_hi,
+                       const double *ranges6, const int32_t *mode, double *out);
 /* the packed float64 tally buffer [absorbed S | received S | hits S | segments,hits | flux maps]
    for the single end-of-run reduce across GPUs (reference merge: tracer_engine_mp.py:44-119).
    export/import copy to/from a caller buffer (host, or device when on_device != 0) so the

@@ -741,6 +741,83 @@ def make_mc(ref):
     N.savez_compressed(os.path.join(HERE, 'mc_reference.npz'), **out)
 
 
+def make_emissive(out):
+    """
+    emissive_losses.  radiosity_RTVF is called as it is (emissive_losses.py imports under Python 3).
+    view_factors_3D.py is Python 2 (print statements, xrange) and cannot be imported; its class RTVF (lines 20-112: the
+    constructor and test_precision, plain NumPy) is valid Python 3, so that slice of the file is executed from where it
+    lies and driven with seeded pass matrices.  The view-factor matrices are the text-book values the reference keeps
+    in emissive_losses_test.py:12-15 and :38-42.
+    """
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_emissive_losses', os.path.join(REFERENCE, 'emissive_losses', 'emissive_losses.py'))
+    em = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(em)
+    vf_cyl2 = N.array([[0., 0.618, 0.210, 0.172], [0.309, 0.382, 0.204, 0.105], [0.105, 0.204, 0.382, 0.309], [0.172, 0.210, 0.618, 0.]])
+    vf_holman = N.array([[0., 0.63, 0.195, 0.075, 0.1], [0.315, 0.37, 0.2175, 0.06, 0.0375], [0.0975, 0.2175, 0.37, 0.2175, 0.0975],
+                         [0.0375, 0.06, 0.2175, 0.37, 0.315], [0.1, 0.075, 0.195, 0.63, 0.]])
+    out['vf_cyl2'] = vf_cyl2
+    out['vf_holman'] = vf_holman
+    nan = float('nan')
+    cases = [
+        ('holman_8_17', vf_holman, N.array([N.pi * 1e-4, 2 * N.pi * 1e-4, 2 * N.pi * 1e-4, 2 * N.pi * 1e-4, N.pi * 1e-4]), N.array([1., 0.6, 0.6, 0.6, 0.6]),
+         N.array([293.15, 1273.15, 1273.15, 1273.15, 1273.15]), None),
+        ('cyl2_temperatures', vf_cyl2, N.array([N.pi, 2. * N.pi, 2. * N.pi, N.pi]), N.array([1., 0.5, 0.5, 0.5]), N.array([300., 400., 500., 450.]), None),
+        ('cyl2_all_flux', vf_cyl2, N.array([N.pi, 2. * N.pi, 2. * N.pi, N.pi]), N.array([0.9, 0.5, 0.5, 0.5]), N.array([nan, nan, nan, nan]),
+         N.array([10., 2000., 1500., 1000.])),
+        ('cyl2_mixed', vf_cyl2, N.array([N.pi, 2. * N.pi, 2. * N.pi, N.pi]), N.array([1., 0.5, 0.5, 0.5]), N.array([300., 400., 500., nan]),
+         N.array([nan, nan, nan, 1000.])),
+    ]
+    out['rad_names'] = N.array([c[0] for c in cases])
+    for i, (name, VF, areas, eps, T, inc) in enumerate(cases):
+        pre = 'rad%d_' % i
+        out[pre + 'VF'], out[pre + 'areas'], out[pre + 'eps'], out[pre + 'T_in'] = VF, areas, eps, T.copy()
+        out[pre + 'has_inc'] = N.array(inc is not None)
+        if inc is not None:
+            out[pre + 'inc'] = inc.copy()
+        res = em.radiosity_RTVF(VF, areas, eps, T.copy(), None if inc is None else inc.copy())
+        for key, val in zip(('AA', 'bb', 'J', 'E', 'T', 'q', 'Q'), res):
+            out[pre + key] = N.asarray(val)
+
+    # RTVF.test_precision: the class as the reference wrote it, lines 20-112 of its file
+    with open(os.path.join(REFERENCE, 'emissive_losses', 'view_factors_3D.py')) as f:
+        lines = f.read().split('\n')
+    ns = {'N': N}
+    exec(compile('\n'.join(lines[19:112]), 'view_factors_3D.py[20:112]', 'exec'), ns)
+    RTVF = ns['RTVF']
+    rng = N.random.RandomState(123)
+    n_pass = 12
+    for ci, (option, VF_true, areas, num_rays, precision) in enumerate([
+            ('absolute', vf_cyl2, N.array([N.pi, 2. * N.pi, 2. * N.pi, N.pi]), 20000., 5e-5),
+            ('relative', vf_holman, N.array([N.pi * 1e-4, 2 * N.pi * 1e-4, 2 * N.pi * 1e-4, 2 * N.pi * 1e-4, N.pi * 1e-4]), 50000., 1.5e-4)]):
+        n = len(areas)
+        est = RTVF(num_rays=num_rays, precision=precision, precision_option=option)
+        est.areas = areas
+        est.VF = N.zeros((n, n)); est.VF_esperance = N.zeros((n, n)); est.Qsum = N.zeros((n, n))
+        est.stdev_VF = N.zeros((n, n)); est.p = N.zeros(n)
+        pre = 'tp%d_' % ci
+        out[pre + 'option'], out[pre + 'areas'], out[pre + 'precision'] = N.array(option), areas, N.array(precision)
+        passes, counts, esp, std, prog = [], [], [], [], []
+        for k in range(n_pass):
+            # a pass: multinomial estimate of every row; uneven ray counts from the 4th pass on (an emitter switched off once)
+            rc = N.ones(n) * num_rays
+            if k >= 3:
+                rc[k % n] = num_rays / 2.
+            if k == 5:
+                rc[1] = 0.
+            # (row 2 loses 2e-4 of its rays through the rim: the summation rule is exercised too)
+            VF = N.array([rng.multinomial(int(rc[i]), N.hstack((VF_true[i] / VF_true[i].sum() * (1. - 2e-4 * (i == 2)), 2e-4 * (i == 2))))[:n] / max(rc[i], 1.)
+                          for i in range(n)])
+            est.VF, est.ray_counts = VF, rc
+            est.p = est.p + rc
+            with N.errstate(all='ignore'):
+                est.test_precision()
+            passes.append(VF); counts.append(rc); esp.append(est.VF_esperance.copy()); std.append(est.stdev_VF.copy()); prog.append(est.progress.copy())
+        out[pre + 'VF'], out[pre + 'ray_counts'] = N.array(passes), N.array(counts)
+        out[pre + 'VF_esperance'], out[pre + 'stdev_VF'], out[pre + 'progress'] = N.array(esp), N.array(std), N.array(prog)
+
+
+
 def main():
     import_reference()
     if '--mc' in sys.argv:
@@ -750,7 +827,7 @@ def main():
     amd = NS('tracer_amd')
     only = [a[len('--only='):] for a in sys.argv if a.startswith('--only=')]
     for fname, maker in (('geometry.npz', make_geometry), ('optics.npz', make_optics), ('sources.npz', make_sources),
-                         ('engine.npz', make_engine)):
+                         ('engine.npz', make_engine), ('emissive.npz', lambda ref, amd, out: make_emissive(out))):
         if only and fname not in only:
             continue
         out = {}

@@ -20,6 +20,7 @@ BUIE_LEN = 3 * (TRC_BUIE_NELEM + 1) + 6
 # trace flags
 TRACE_ACCEL = 0x1
 TRACE_KEEP_LAST = 0x2
+BIN_ANGLE, BIN_HEIGHT, BIN_RADIUS, BIN_ROUND9, BIN_RADIUS_HALF_OPEN = 0x1, 0x2, 0x4, 0x8, 0x10      # trc_scene_bin_hits modes
 TRACE_STREAM = 0x4
 TRACE_MEGAKERNEL = 0x8
 # surface flags
@@ -100,6 +101,7 @@ SIGNATURES = {
     'trc_scene_get_tallies': (C.c_int, [_vp, _p_f64, _p_f64, _p_i64]),
     'trc_scene_get_fluxmap': (C.c_int, [_vp, C.c_int32, _p_f64]),
     'trc_scene_get_hits': (C.c_int, [_vp, _p_i64, _p_i32] + [_p_f64] * 8),
+    'trc_scene_bin_hits': (C.c_int, [_vp, C.c_int32, _p_i32, _p_i32, _p_f64, _p_i32, _p_f64]),
     'trc_scene_tally_size': (C.c_int, [_vp, _p_i64]),
     'trc_scene_export_tallies': (C.c_int, [_vp, _vp, C.c_int32]),
     'trc_scene_import_tallies': (C.c_int, [_vp, _vp, C.c_int32]),

@@ -1668,6 +1668,86 @@ extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, doub
     return TRC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// view-factor allocation: captured hits -> energy per (surface range, azimuth, height, radius) element
+#define BIN_TILE 256
+__global__ __launch_bounds__(256) void k_bin_hits(long long n_hits, const int32_t *h_surf, const double *h_e, const double *hx,
+                                                  const double *hy, const double *hz, int n_bins, const int32_t *surf_lo,
+                                                  const int32_t *surf_hi, const double *ranges6, const int32_t *mode, double *out) {
+    __shared__ double l_rng[BIN_TILE * 6];
+    __shared__ double l_sum[BIN_TILE];
+    __shared__ int32_t l_lo[BIN_TILE], l_hi[BIN_TILE], l_mode[BIN_TILE];
+    for (int i = threadIdx.x; i < n_bins; i += blockDim.x) {
+        l_lo[i] = surf_lo[i]; l_hi[i] = surf_hi[i]; l_mode[i] = mode[i]; l_sum[i] = 0.0;
+        for (int k = 0; k < 6; ++k) l_rng[6 * i + k] = ranges6[6 * i + k];
+    }
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_hits; i += (long long)gridDim.x * blockDim.x) {
+        const int s = h_surf[i];
+        if (s < 0) continue;                       // reserved but unwritten entry of an open chunk
+        const double x = hx[i], y = hy[i], z = hz[i], e = h_e[i];
+        double ang = atan2(y, x);
+        if (ang < 0.0) ang += TRC_TWO_PI;
+        const double rad = sqrt(x * x + y * y);
+        const double rad9 = rint(rad * 1e9) / 1e9, z9 = rint(z * 1e9) / 1e9;
+        for (int j = 0; j < n_bins; ++j) {
+            if (s < l_lo[j] || s > l_hi[j]) continue;
+            const int m = l_mode[j];
+            const double *g = l_rng + 6 * j;
+            const double hh = (m & TRC_BIN_ROUND9) ? z9 : z, rr = (m & TRC_BIN_ROUND9) ? rad9 : rad;
+            bool in = true;
+            if (m & TRC_BIN_ANGLE) in = in && ang >= g[0] && ang <= g[1];
+            if (m & TRC_BIN_HEIGHT) in = in && hh >= g[2] && hh <= g[3];
+            if (m & TRC_BIN_RADIUS) in = in && rr >= g[4] && ((m & TRC_BIN_RADIUS_HALF_OPEN) ? rr < g[5] : rr <= g[5]);
+            if (in) atomicAdd(&l_sum[j], e);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_bins; i += blockDim.x)
+        if (l_sum[i] != 0.0) atomicAdd(&out[i], l_sum[i]);
+}
+
+extern "C" int trc_scene_bin_hits(trc_scene *sc, int32_t n_bins, const int32_t *surf_lo, const int32_t *surf_hi,
+                                  const double *ranges6, const int32_t *mode, double *out) {
+    if (!sc || n_bins < 0 || (n_bins > 0 && (!surf_lo || !surf_hi || !ranges6 || !mode || !out))) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    if (n_bins == 0) return TRC_OK;
+    trc_ctx *ctx = sc->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long c[2];
+    HIP_TRY(hipMemcpy(c, sc->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    long long reserved = (long long)c[0];
+    if (reserved > sc->hit_cap) reserved = sc->hit_cap;
+    for (int i = 0; i < n_bins; ++i) out[i] = 0.0;
+    if (reserved == 0) return TRC_OK;
+    const size_t per_bin = 2 * sizeof(int32_t) + 6 * sizeof(double) + sizeof(int32_t) + sizeof(double);
+    char *d_buf = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_buf, (size_t)BIN_TILE * per_bin));
+    double *d_rng = (double *)d_buf, *d_out = d_rng + 6 * BIN_TILE;
+    int32_t *d_lo = (int32_t *)(d_out + BIN_TILE), *d_hi = d_lo + BIN_TILE, *d_mode = d_hi + BIN_TILE;
+    int st = TRC_OK;
+    unsigned grid = (unsigned)((reserved + 255) / 256);
+    if (grid > (unsigned)(ctx->n_cu * 8)) grid = (unsigned)(ctx->n_cu * 8);
+    for (int b0 = 0; b0 < n_bins && st == TRC_OK; b0 += BIN_TILE) {
+        const int nb = n_bins - b0 < BIN_TILE ? n_bins - b0 : BIN_TILE;
+        hipError_t e = hipMemcpyAsync(d_rng, ranges6 + 6 * (size_t)b0, (size_t)nb * 48, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_lo, surf_lo + b0, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_hi, surf_hi + b0, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_mode, mode + b0, (size_t)nb * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, (size_t)nb * 8, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_bin_hits, dim3(grid), dim3(256), 0, ctx->stream, reserved, sc->d_h_surf, sc->d_h[0], sc->d_h[2], sc->d_h[3],
+                               sc->d_h[4], nb, d_lo, d_hi, d_rng, d_mode, d_out);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out + b0, d_out, (size_t)nb * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) st = trc_fail(TRC_ERR_DEVICE, "trc_scene_bin_hits: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_buf);
+    return st;
+}
+
 extern "C" int trc_scene_tally_size(trc_scene *sc, int64_t *n_doubles) {
     if (!sc || !n_doubles) return trc_fail(TRC_ERR_INVALID, "bad arguments");
     *n_doubles = sc->tally_n;

@@ -233,6 +233,25 @@ class DeviceScene(object):
                                                     *[_cabi.ptr(c) for c in cols]))
         return dict(surf=surf, e_abs=cols[0], e_in=cols[1], points=N.vstack(cols[2:5]), directions=N.vstack(cols[5:8]))
 
+    def bin_hits(self, surf_lo, surf_hi, ranges, mode):
+        """
+        Absorbed energy of the captured hits per view-factor element (trc_scene_bin_hits; the device form of
+        emissive_losses/view_factors_3D.py `alloc_VF`).  surf_lo/surf_hi: inclusive surface index range per element;
+        ranges (n, 6): ang0, ang1, h0, h1, r0, r1; mode: _cabi.BIN_* bits per element.
+        """
+        lo = N.ascontiguousarray(surf_lo, dtype=N.int32)
+        hi = N.ascontiguousarray(surf_hi, dtype=N.int32)
+        rng = N.ascontiguousarray(ranges, dtype=float).reshape(-1, 6)
+        md = N.ascontiguousarray(mode, dtype=N.int32)
+        n = len(lo)
+        if not (len(hi) == n and len(rng) == n and len(md) == n):
+            raise ValueError('bin_hits: the four element arrays must have the same length')
+        out = N.zeros(n)
+        i32 = C.POINTER(C.c_int32)
+        _cabi.check(self.lib.trc_scene_bin_hits(self.handle, n, lo.ctypes.data_as(i32), hi.ctypes.data_as(i32), _cabi.ptr(rng),
+                                                md.ctypes.data_as(i32), _cabi.ptr(out)))
+        return out
+
     def tally_size(self):
         n = C.c_int64(0)
         _cabi.check(self.lib.trc_scene_tally_size(self.handle, C.byref(n)))

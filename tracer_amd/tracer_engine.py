@@ -92,6 +92,11 @@ class TracerEngine(object):
         """(absorbed, received, hits) per surface, accumulated on the device since the last reset."""
         return self._dev.get_tallies()
 
+    def bin_hits(self, surf_lo, surf_hi, ranges, mode):
+        """absorbed energy of the hits captured by the last fast trace per (surface range, azimuth, height, radius) element,
+        binned on the device (DeviceScene.bin_hits; the view-factor allocation of emissive_losses)"""
+        return self._dev.bin_hits(surf_lo, surf_hi, ranges, mode)
+
     def reset_tallies(self):
         if self._dev is not None:
             self._dev.reset_tallies()
@@ -109,6 +114,7 @@ class TracerEngine(object):
         seed = kwargs.pop('seed', None)
         hit_capacity = kwargs.pop('hit_capacity', None)
         fast_kernel = kwargs.pop('fast_kernel', 'auto')     # 'auto' | 'stream' | 'megakernel' (fast engine only)
+        feed = kwargs.pop('feed', True)     # False: captured hits stay on the device (bin_hits), accountants are not fed
         if seed is None:
             seed = rng.next_seed()
         self.reps = reps
@@ -146,13 +152,13 @@ class TracerEngine(object):
         if engine == 'auto':
             engine = 'ordered' if (tree or dev.compiled.splits) else 'fast'
         if engine == 'fast':
-            return self._trace_fast(dev, bundle, reps, min_energy, seed, bool(accel), hit_capacity, fast_kernel)
+            return self._trace_fast(dev, bundle, reps, min_energy, seed, bool(accel), hit_capacity, fast_kernel, feed)
         if engine == 'ordered':
             return self._trace_ordered(dev, bundle, reps, min_energy, seed, bool(accel), tree)
         raise ValueError("unknown engine %r" % (engine,))
 
     # -- fast engine --------------------------------------------------------------------------------
-    def _trace_fast(self, dev, bundle, reps, min_energy, seed, accel, hit_capacity, fast_kernel='auto'):
+    def _trace_fast(self, dev, bundle, reps, min_energy, seed, accel, hit_capacity, fast_kernel='auto', feed=True):
         n = bundle.get_num_rays()
         capture = any(dev.compiled.capture)
         if capture:
@@ -166,7 +172,7 @@ class TracerEngine(object):
         if stats.hits_dropped:
             raise RuntimeError("%d hits were not captured: the hit buffer holds %d; pass hit_capacity=..."
                                % (stats.hits_dropped, dev.hit_capacity))
-        if capture:
+        if capture and feed:
             h = dev.get_hits()
             feed_accountants(dev.compiled.surfaces, h['surf'], h['e_in'], h['e_in'] - h['e_abs'], h['points'],
                              h['directions'])
