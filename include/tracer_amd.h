@@ -272,7 +272,16 @@ int trc_scene_get_hits(trc_scene *scene, int64_t *n, int32_t *surf, double *e_ab
 #define TRC_BIN_RADIUS_HALF_OPEN 0x10
 int trc_scene_bin_hits(trc_scene *scene, int32_t n_bins, const int32_t *surf_lo, const int32_t *surf_hi,
                        const double *ranges6, const int32_t *mode, double *out);
-/* the packed float64 tally buffer [absorbed S | received S | hits S | segments,hits | flux maps]
+/* Surface-to-surface energy transfer of the fast engine: T[from][to] = energy carried by the segments that leave
+   surface `from` (row n_surf = the source) and land on surface `to`, (n_surf+1) x n_surf, row-major.  It replaces
+   the blocking / shading post-process of examples/Sandia_NSTTF_field example.py:229-290, which recovers the parent
+   heliostat of every blocked ray by comparing hit coordinates for equality, O(hits^2) on the host:
+   incoming[h] = T[source][h] (:283), blocking[h] = sum over heliostats h' of T[h][h'] (:277), and T[h][receiver] is
+   the contribution of heliostat h to the receiver.  Scenes of up to 1024 surfaces.  Enabling or disabling resets
+   the tallies; the matrix travels at the end of the packed tally buffer (one all-reduce covers it). */
+int trc_scene_enable_transfer(trc_scene *scene, int32_t on);
+int trc_scene_get_transfer(trc_scene *scene, double *out /* (n_surf+1)*n_surf */);
+/* the packed float64 tally buffer [absorbed S | received S | hits S | segments,hits | flux maps | transfer]
    for the single end-of-run reduce across GPUs (reference merge: tracer_engine_mp.py:44-119).
    export/import copy to/from a caller buffer (host, or device when on_device != 0) so the
    caller can run ncclAllReduce / torch.distributed.all_reduce on it. */

@@ -743,3 +743,60 @@ def test_many_surfaces_scene(ctx):
         a1, r1, h1, s1, l1 = res[key]
         assert l1 > 1 and N.array_equal(h1, h0) and s1 == s0, key
         assert N.allclose(a1, a0, rtol=1e-9, atol=1e-9), key
+
+
+@pytest.mark.gpu
+def test_transfer_matrix_equals_the_tree_of_the_oracle():
+    """
+    Surface-to-surface energy transfer (the blocking / shading post-process of the reference's NSTTF example,
+    examples/Sandia_NSTTF_field example.py:229-290): the matrix the fast engine accumulates while shading -- streaming form
+    and megakernel -- equals the one read off the oracle's ray tree (parents and producing surfaces) for the same Philox
+    streams, and the ordered engine's tree gives it too.  Then the example's per-heliostat quantities.
+    """
+    from oracle import engine as oeng
+    from tracer_amd import scenes
+    from tracer_amd.scene import compile_scene
+    from tracer_amd.tracer_engine import TracerEngine
+    from tracer_amd.models.heliostat_field import field_losses
+    plant, field, rec, src = scenes.nsttf_field()
+    cs = compile_scene(plant)
+    S = cs.n_surf
+    n = 200000
+    bundle = scenes.nsttf_source(n, src, seed=21)
+    ref = oeng.trace_from_compiled(cs, bundle.source_args(), 100, 1e-10)
+    T_ref = N.zeros((S + 1, S))
+    left = N.full(n, S)
+    for lv in range(1, len(ref['levels'])):
+        L, P = ref['levels'][lv], ref['levels'][lv - 1]
+        N.add.at(T_ref, (left[L['parents']], L['surf']), P['energy'][L['parents']])
+        left = L['surf']
+    assert N.isclose(T_ref.sum(), ref['received'].sum(), rtol=1e-12) and T_ref[S].sum() > 0 and T_ref[:S].sum() > 0
+
+    eng = TracerEngine(plant)
+    eng.enable_transfer_matrix()
+    for kernel in ('megakernel', 'stream'):
+        eng.reset_tallies()
+        eng.ray_tracer(scenes.nsttf_source(n, src, seed=21), reps=100, min_energy=1e-10, tree=False, accel=True, seed=21, fast_kernel=kernel)
+        T = eng.get_transfer_matrix()
+        assert T.shape == (S + 1, S)
+        assert N.array_equal(T != 0., T_ref != 0.), kernel
+        assert N.allclose(T, T_ref, rtol=1e-9, atol=1e-9), (kernel, N.abs(T - T_ref).max())
+        a, r, h = eng.get_tallies()
+        assert N.allclose(T.sum(axis=0), r, rtol=1e-9)                  # what lands on a surface is what it receives
+    eng.reset_tallies()
+    eng.ray_tracer(scenes.nsttf_source(n, src, seed=21), reps=100, min_energy=1e-10, tree=True, seed=21)
+    assert N.allclose(eng.get_transfer_matrix(), T_ref, rtol=1e-9, atol=1e-9)
+
+    # per-heliostat quantities of the example: every heliostat is one surface, the receiver is the last one
+    surfaces = plant.get_surfaces()
+    rec_idx = [surfaces.index(s) for s in rec.get_surfaces()] if hasattr(rec, 'get_surfaces') else [S - 1]
+    hel_idx = [i for i in range(S) if i not in rec_idx]
+    res = field_losses(T_ref, hel_idx, rec_idx, flux=1000., projected_areas=N.ones(len(hel_idx)))
+    assert res['incoming'].sum() == T_ref[S, hel_idx].sum() and (res['incoming'] > 0).sum() > 200
+    assert res['blocking'].sum() > 0 and res['blocking'].sum() < 0.05 * res['incoming'].sum()
+    assert N.isclose(res['to_receiver'].sum(), T_ref[:S, rec_idx].sum())
+    assert N.allclose(res['shading'], 1000. - res['incoming'])
+    # switching it off frees the rows: the plain tallies are unchanged by it
+    eng.enable_transfer_matrix(False)
+    with pytest.raises(ValueError):
+        eng.get_transfer_matrix()

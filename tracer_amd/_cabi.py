@@ -102,6 +102,8 @@ SIGNATURES = {
     'trc_scene_get_fluxmap': (C.c_int, [_vp, C.c_int32, _p_f64]),
     'trc_scene_get_hits': (C.c_int, [_vp, _p_i64, _p_i32] + [_p_f64] * 8),
     'trc_scene_bin_hits': (C.c_int, [_vp, C.c_int32, _p_i32, _p_i32, _p_f64, _p_i32, _p_f64]),
+    'trc_scene_enable_transfer': (C.c_int, [_vp, C.c_int32]),
+    'trc_scene_get_transfer': (C.c_int, [_vp, _p_f64]),
     'trc_scene_tally_size': (C.c_int, [_vp, _p_i64]),
     'trc_scene_export_tallies': (C.c_int, [_vp, _vp, C.c_int32]),
     'trc_scene_import_tallies': (C.c_int, [_vp, _vp, C.c_int32]),

@@ -107,8 +107,9 @@ struct DScene {
     const int32_t *a_gapart;    // bounded surfaces kept out of the grid (box-tested for every ray)
     int32_t a_g_ok, a_g_ncell, a_g_nlist, a_g_napart, a_gdim[3];
     float a_glo[3], a_gcs[3], a_ginv[3], a_groot[6];
-    // tallies: [absorbed S | received S | count S | segments, hits | flux bins ...]
+    // tallies: [absorbed S | received S | count S | segments, hits | flux bins ... | transfer (S+1) x S]
     double *tally;
+    long long tr_off;           // offset of the surface-to-surface transfer matrix in `tally`, -1 when it is not kept
     // flux maps
     int32_t n_fm, n_fm_edges;   // flux maps and the total length of their edge arrays
     const int32_t *fm_of_surf;  // n_surf, -1 = none
@@ -148,6 +149,8 @@ struct trc_scene {
     struct StreamEngine *stream_eng;   // slots of the streaming fast engine (trc_stream.inc), allocated on first use
     double *d_tally;
     int64_t tally_n;
+    bool transfer_on;          // keep the transfer matrix (trc_scene_enable_transfer)
+    int64_t tr_off;
     std::vector<FluxMapDev> fms_h;
     std::vector<double> fm_edges_h;
     std::vector<int32_t> fm_of_surf_h;
@@ -314,8 +317,10 @@ __device__ __forceinline__ unsigned long long chunk_append(unsigned long long *c
 template <bool LDS_TALLY>
 __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, int s, double e_in,
                                            double e_abs, double hx, double hy, double hz, double dx,
-                                           double dy, double dz, bool capture_enabled, WaveChunk *hc = nullptr) {
+                                           double dy, double dz, bool capture_enabled, int prev, WaveChunk *hc = nullptr) {
     const int S = sc.n_surf;
+    // energy carried from the surface the ray left (S = the source) to the one it lands on
+    if (sc.tr_off >= 0) atomicAdd(&sc.tally[sc.tr_off + (long long)prev * S + s], e_in);
     if (LDS_TALLY) {
         atomicAdd(&lds_tally[s], e_abs);
         atomicAdd(&lds_tally[S + s], e_in);
@@ -571,7 +576,7 @@ __device__ __forceinline__ void coop_drain_leaves(const trc_accel_view &A, const
 template <bool LDS_TALLY>
 __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *recs, double *l_tally, double t, int s, double &px,
                                            double &py, double &pz, double &dx, double &dy, double &dz, double &e, double &ref,
-                                           double wl, unsigned long long rid, int &bounce, WaveChunk *hc = nullptr) {
+                                           double wl, unsigned long long rid, int &bounce, int &prev, WaveChunk *hc = nullptr) {
     const DScene &sc = P.sc;
     bounce += 1;
     const double *rec = recs + (size_t)s * sc.stride;
@@ -583,7 +588,8 @@ __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *re
                           rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, nx, ny, nz, P.seed, rid, (uint32_t)bounce, out);
     (void)n_out;  // scenes whose optics split rays are routed to the ordered engine by the host
     double e_abs = e - out[0].e;
-    record_hit<LDS_TALLY>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0, hc);
+    record_hit<LDS_TALLY>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0, prev, hc);
+    prev = s;
     px = hx; py = hy; pz = hz;
     dx = out[0].dx; dy = out[0].dy; dz = out[0].dz;
     e = out[0].e; ref = out[0].ref;
@@ -691,6 +697,7 @@ __global__ __launch_bounds__(THREADS) void k_trace_fast(FastParams P) {
     double px = 0, py = 0, pz = 0, dx = 0, dy = 0, dz = 0, e = 0, ref = 1.0, wl = 0.0;
     unsigned long long rid = 0;
     int bounce = 0;
+    int prev = S;              // surface the ray left (transfer matrix); S = the source
     double nseg = 0.0, nhit = 0.0;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
@@ -702,6 +709,7 @@ __global__ __launch_bounds__(THREADS) void k_trace_fast(FastParams P) {
             if (!alive && id < end) {
                 fast_new_ray(P, buie, id, px, py, pz, dx, dy, dz, e, ref, wl, rid);
                 bounce = 0;
+                prev = S;
                 alive = true;
             }
             next += __popcll(need);
@@ -721,8 +729,8 @@ __global__ __launch_bounds__(THREADS) void k_trace_fast(FastParams P) {
         }
         if (s < 0) { alive = false; continue; }
         nhit += 1.0;
-        if (P.lds_tally) alive = fast_shade<true>(P, recs, l_tally, t, s, px, py, pz, dx, dy, dz, e, ref, wl, rid, bounce);
-        else alive = fast_shade<false>(P, recs, l_tally, t, s, px, py, pz, dx, dy, dz, e, ref, wl, rid, bounce);
+        if (P.lds_tally) alive = fast_shade<true>(P, recs, l_tally, t, s, px, py, pz, dx, dy, dz, e, ref, wl, rid, bounce, prev);
+        else alive = fast_shade<false>(P, recs, l_tally, t, s, px, py, pz, dx, dy, dz, e, ref, wl, rid, bounce, prev);
     }
 
     // ---- flush ----
@@ -814,6 +822,7 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
     double px = 0, py = 0, pz = 0, dx = 0, dy = 0, dz = 0, e = 0, ref = 1.0, wl = 0.0;
     unsigned long long rid = 0;
     int bounce = 0;
+    int prev = S;              // surface the ray left (transfer matrix); S = the source
     double nseg = 0.0, nhit = 0.0;
     double tb = TRC_INF;      // best hit among the surfaces tested inline (unbounded ones)
     int sb = -1;
@@ -835,6 +844,7 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
                 if (!alive && id < end) {
                     fast_new_ray(P, buie, id, px, py, pz, dx, dy, dz, e, ref, wl, rid);
                     bounce = 0;
+                    prev = S;
                     alive = true;
                     prepared = false;
                 }
@@ -947,7 +957,7 @@ __global__ __launch_bounds__(THREADS) void k_trace_coop(FastParams P) {
             if (s < 0) alive = false;
             else {
                 nhit += 1.0;
-                alive = fast_shade<true>(P, recs, l_tally, t, s, px, py, pz, dx, dy, dz, e, ref, wl, rid, bounce);
+                alive = fast_shade<true>(P, recs, l_tally, t, s, px, py, pz, dx, dy, dz, e, ref, wl, rid, bounce, prev);
             }
         }
         WAVE_SYNC();
@@ -1392,6 +1402,8 @@ static int scene_alloc_tally(trc_scene *sc) {
     dev_free(sc->d_tally);
     int64_t n = 3 * (int64_t)sc->n_surf + 2;
     for (auto &m : sc->fms_h) { m.bins = n; n += (int64_t)m.nu * m.nv; }
+    sc->tr_off = -1;
+    if (sc->transfer_on) { sc->tr_off = n; n += ((int64_t)sc->n_surf + 1) * sc->n_surf; }
     sc->tally_n = n;
     TRC_TRY(dev_alloc(&sc->d_tally, (size_t)n));
     HIP_TRY(hipMemset(sc->d_tally, 0, (size_t)n * sizeof(double)));
@@ -1748,6 +1760,29 @@ extern "C" int trc_scene_bin_hits(trc_scene *sc, int32_t n_bins, const int32_t *
     return st;
 }
 
+#define TRC_TRANSFER_MAX_SURF 1024      /* (S+1) x S doubles, kept in every private copy of the tally buffer too */
+extern "C" int trc_scene_enable_transfer(trc_scene *sc, int32_t on) {
+    if (!sc) return trc_fail(TRC_ERR_INVALID, "scene is NULL");
+    if (on && sc->n_surf > TRC_TRANSFER_MAX_SURF)
+        return trc_fail(TRC_ERR_CAPACITY, "the transfer matrix is offered up to %d surfaces (scene has %d)", TRC_TRANSFER_MAX_SURF, sc->n_surf);
+    HIP_TRY(hipSetDevice(sc->ctx->device));
+    HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+    if ((on != 0) == sc->transfer_on) return TRC_OK;
+    sc->transfer_on = on != 0;
+    TRC_TRY(scene_alloc_tally(sc));      // resets the tallies; flux-map bins keep their offsets (the matrix comes last)
+    if (!sc->fms_h.empty()) HIP_TRY(hipMemcpy(sc->d_fms, sc->fms_h.data(), sc->fms_h.size() * sizeof(FluxMapDev), hipMemcpyHostToDevice));
+    return TRC_OK;
+}
+
+extern "C" int trc_scene_get_transfer(trc_scene *sc, double *out) {
+    if (!sc || !out) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    if (!sc->transfer_on) return trc_fail(TRC_ERR_INVALID, "the transfer matrix is not enabled (trc_scene_enable_transfer)");
+    HIP_TRY(hipSetDevice(sc->ctx->device));
+    HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+    HIP_TRY(hipMemcpy(out, sc->d_tally + sc->tr_off, (size_t)(sc->n_surf + 1) * sc->n_surf * sizeof(double), hipMemcpyDeviceToHost));
+    return TRC_OK;
+}
+
 extern "C" int trc_scene_tally_size(trc_scene *sc, int64_t *n_doubles) {
     if (!sc || !n_doubles) return trc_fail(TRC_ERR_INVALID, "bad arguments");
     *n_doubles = sc->tally_n;
@@ -1802,6 +1837,7 @@ static DScene make_dscene(trc_scene *sc) {
     for (int i = 0; i < 3; ++i) { d.a_cen[i] = sc->accel.cen[i]; d.a_slo[i] = sc->accel.slo[i]; d.a_shi[i] = sc->accel.shi[i]; }
     d.tally = sc->d_tally;
     d.fm_of_surf = sc->d_fm_of_surf; d.fms = sc->d_fms; d.fm_edges = sc->d_fm_edges;
+    d.tr_off = sc->tr_off;
     d.n_fm = (int32_t)sc->fms_h.size(); d.n_fm_edges = (int32_t)sc->fm_edges_h.size();
     d.counters = sc->d_counters; d.energy_left = sc->d_energy_left;
     d.hit_cap = sc->hit_cap; d.h_surf = sc->d_h_surf;

@@ -147,3 +147,23 @@ def radial_stagger(start_ang, end_ang, az_space, rmin, rmax, r_space):
     xs = N.r_[N.outer(rs[::2], N.cos(angs[::2])).flatten(), N.outer(rs[1::2], N.cos(angs[1::2])).flatten()]
     ys = N.r_[N.outer(rs[::2], N.sin(angs[::2])).flatten(), N.outer(rs[1::2], N.sin(angs[1::2])).flatten()]
     return N.vstack((xs, ys)).T
+
+
+def field_losses(transfer, heliostat_surfaces, receiver_surfaces=(), flux=None, projected_areas=None):
+    """
+    The per-heliostat results of the reference's NSTTF example (examples/Sandia_NSTTF_field example.py:229-290) read off
+    the surface-to-surface transfer matrix of TracerEngine.get_transfer_matrix() (last row = the source):
+      incoming[h]    energy of the source rays whose first hit is heliostat h (:283),
+      blocking[h]    energy of the rays reflected by heliostat h that land on another heliostat (:277),
+      to_receiver[h] energy heliostat h delivers to the receiver surfaces,
+      shading[h]     flux * projected_areas[h] - incoming[h] when both are given (:288).
+    heliostat_surfaces / receiver_surfaces: surface indices in Assembly.get_surfaces() order.
+    """
+    T = N.asarray(transfer)
+    hel = N.asarray(heliostat_surfaces, dtype=int)
+    rec = N.asarray(receiver_surfaces, dtype=int)
+    res = dict(incoming=T[-1, hel].copy(), blocking=T[N.ix_(hel, hel)].sum(axis=1),
+               to_receiver=T[N.ix_(hel, rec)].sum(axis=1) if len(rec) else N.zeros(len(hel)))
+    if flux is not None and projected_areas is not None:
+        res['shading'] = flux * N.asarray(projected_areas, dtype=float) - res['incoming']
+    return res

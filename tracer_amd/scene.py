@@ -252,6 +252,16 @@ class DeviceScene(object):
                                                 md.ctypes.data_as(i32), _cabi.ptr(out)))
         return out
 
+    def enable_transfer(self, on=True):
+        """keep (or drop) the surface-to-surface transfer matrix of the fast engine; resets the tallies"""
+        _cabi.check(self.lib.trc_scene_enable_transfer(self.handle, 1 if on else 0))
+
+    def get_transfer(self):
+        """(n_surf + 1, n_surf): energy carried from surface `row` (last row: the source) to surface `column`"""
+        out = N.zeros((self.n_surf + 1, self.n_surf))
+        _cabi.check(self.lib.trc_scene_get_transfer(self.handle, _cabi.ptr(out)))
+        return out
+
     def tally_size(self):
         n = C.c_int64(0)
         _cabi.check(self.lib.trc_scene_tally_size(self.handle, C.byref(n)))

@@ -39,6 +39,8 @@ class TracerEngine(object):
         self._dev_static_sig = None
         self._dev_frames = None
         self._fluxmap_requests = {}
+        self._transfer = False
+        self._transfer_host = None      # contribution of ordered-engine runs (from the tree's parents)
         self._kd_on_device = None
         self._auto_kd = None
         self.stats = {}
@@ -61,6 +63,8 @@ class TracerEngine(object):
             self._dev_static_sig = compiled.signature_without_frames()
             for si, (u, v) in self._fluxmap_requests.items():
                 self._dev.set_fluxmap(si, u, v)
+            if self._transfer:
+                self._dev.enable_transfer(True)
         self._dev_sig = sig
         self._dev_frames = compiled.frames12()      # a snapshot: the Surface objects themselves move with the scene
         self._kd_on_device = None
@@ -97,7 +101,28 @@ class TracerEngine(object):
         binned on the device (DeviceScene.bin_hits; the view-factor allocation of emissive_losses)"""
         return self._dev.bin_hits(surf_lo, surf_hi, ranges, mode)
 
+    def enable_transfer_matrix(self, on=True):
+        """
+        Keep the surface-to-surface energy transfer of the following traces: get_transfer_matrix()[i, j] is the energy
+        carried by the ray segments that leave surface i (last row: the source bundle) and land on surface j.  This is
+        what the blocking / shading post-process of the reference's NSTTF example (examples/Sandia_NSTTF_field
+        example.py:229-290) recovers by matching hit coordinates on the host; here the fast engine accumulates it while
+        shading (models.heliostat_field.field_losses reads the example's quantities off it).  Resets the tallies.
+        """
+        self._transfer = bool(on)
+        self._transfer_host = None
+        if self._dev is not None:
+            self._dev.enable_transfer(self._transfer)
+
+    def get_transfer_matrix(self):
+        if not self._transfer:
+            raise ValueError('call enable_transfer_matrix() before tracing')
+        n = len(self._asm.get_surfaces())
+        T = self._dev.get_transfer() if self._dev is not None else N.zeros((n + 1, n))
+        return T if self._transfer_host is None else T + self._transfer_host
+
     def reset_tallies(self):
+        self._transfer_host = None
         if self._dev is not None:
             self._dev.reset_tallies()
 
@@ -192,6 +217,7 @@ class TracerEngine(object):
             if tree is True:
                 self.tree.append(bundle)
             prev = None
+            prev_surf = None
             last = None
             for lv in range(1, nlev):
                 L = res.level(lv, with_ref_index=True, with_wavelength=has_wl)
@@ -205,6 +231,13 @@ class TracerEngine(object):
                 feed_accountants(dev.compiled.surfaces, L['surf'][order], prev['energy'][po], L['energy'][order],
                                  L['vertices'][:, order], prev['directions'][:, po],
                                  None if prev['wavelengths'] is None else prev['wavelengths'][po])
+                if self._transfer:
+                    ns = dev.n_surf
+                    left = N.full(len(prev['energy']), ns) if prev_surf is None else prev_surf
+                    if self._transfer_host is None:
+                        self._transfer_host = N.zeros((ns + 1, ns))
+                    N.add.at(self._transfer_host, (left[par], L['surf']), prev['energy'][par])
+                prev_surf = L['surf']
                 kw = {}
                 if has_ref or dev.compiled.splits or _has_refractive(dev):
                     kw['ref_index'] = L['ref_index']
