@@ -74,7 +74,9 @@ typedef enum trc_gm_kind {
     TRC_GM_SPHERE_CUT = 28,        /* CutSphereGM                sphere_surface.py:168-204  gm: r, bound type (1 BoundaryPlane,
                                       2 BoundarySphere, 3 BoundaryCylinder; boundary_shape.py:89-162), bound rotation[9] and
                                       location[3] in the surface's frame, bound radius */
-    TRC_GM_KIND_COUNT = 29
+    TRC_GM_POLYGON = 29,           /* FlatSimplePolygonGM / PerforatedPolygonGM  polygon.py:8-53, :173-198  gm: n vertices, n holes,
+                                      xmin,xmax,ymin,ymax ; extra: xs[n], ys[n] (clockwise, not closed), then n holes * (cx,cy,r) */
+    TRC_GM_KIND_COUNT = 30
 } trc_gm_kind;
 
 /* ---- optics callables (reference: tracer/optics_callables.py) -------------- */

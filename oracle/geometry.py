@@ -52,6 +52,16 @@ def _flat(kind, frame, g, extra, v, d):
                 ex = N.asarray(extra).reshape(-1, 3)
                 dist = N.sqrt(N.sum((loc[:2, :, None] - ex[:, :2].T[:, None, :]) ** 2, axis=0))
                 t[N.any(dist < ex[:, 2], axis=1)] = N.inf
+        elif kind == GM_POLYGON:
+            nv, nh = int(g[0]), int(g[1])
+            ex = N.asarray(extra, dtype=float)
+            profile = N.vstack((ex[:nv], ex[nv:2 * nv]))
+            profile = N.concatenate((profile, profile[:, 0, None]), axis=1)            # polygon.py:23
+            t[~in_poly(loc[:2], profile)] = N.inf
+            if nh:                                                                      # :192-195
+                holes = ex[2 * nv:].reshape(-1, 3)
+                dist = N.sqrt(N.sum((loc[:2, :, None] - holes[:, :2].T[:, None, :]) ** 2, axis=0))
+                t[N.any(dist < holes[:, 2], axis=1)] = N.inf
         elif kind in (GM_ROUND, GM_ROUND_CUT):
             r2 = N.sum(loc[:2] ** 2., axis=0)
             t[r2 > g[0] ** 2.] = N.inf
@@ -223,6 +233,22 @@ def _quadric(kind, frame, g, v, d):
     sel = N.array(select[not_missed], dtype=N.int_)
     params[any_inters] = N.choose(sel, hits[:, not_missed])
     return params
+
+
+def in_poly(points, profile):
+    """FlatSimplePolygonGM.in_poly (polygon.py:30-53) with `intersect` (:55-63): boundary-crossing parity; profile closed."""
+    x_pos = (points[0] <= profile[0, :, None]).T
+    y_pos = (points[1] <= profile[1, :, None]).T
+    beyond_x = N.logical_and(x_pos[:, :-1], x_pos[:, 1:])
+    across_y = N.logical_xor(y_pos[:, :-1], y_pos[:, 1:])
+    inters = N.logical_and(beyond_x, across_y)
+    across_x = N.logical_xor(x_pos[:, :-1], x_pos[:, 1:])
+    rows, cols = N.nonzero(N.logical_and(across_x, across_y))
+    with N.errstate(all='ignore'):
+        x0, y0, x1, y1 = profile[0, cols], profile[1, cols], profile[0, cols + 1], profile[1, cols + 1]
+        a = (y1 - y0) / (x1 - x0)
+        inters[rows, cols] = (points[1, rows] - (y0 - a * x0)) / a >= points[0, rows]
+    return N.array(N.sum(inters, axis=1) % 2, dtype=bool)
 
 
 def intersect(kind, frame, g, extra, v, d):

@@ -94,6 +94,14 @@ def gm_cases():
         ('ellipsoid', 'ellipsoid', 'Ellipsoid', (1.2, 0.8, 1.5), {}, 1.5),
         ('ellipsoid_cut', 'ellipsoid', 'EllipsoidGM', (1.2, 0.8, 1.5), {'xlim': [-0.5, 1.0], 'ylim': None, 'zlim': [-1., 0.7]}, 1.5),
         ('ellipsoid_alllims', 'ellipsoid', 'EllipsoidGM', (1.2, 0.8, 1.5), {'xlim': [-0.5, 1.0], 'ylim': [-0.3, 0.3], 'zlim': [-1., 0.7]}, 1.5),
+        # polygons: a concave clockwise L with a notch (vertices level with random hits do not occur; edge rules are exercised by
+        # the vertical and horizontal edges), a convex pentagon, and the L with three circular perforations
+        ('polygon_L', 'polygon', 'FlatSimplePolygonGM', (N.array([[-1., -1., 0.2, 0.2, 0.6, 1.2, 1.2], [-0.8, 1., 1., 0.1, 0.3, 0.1, -0.8]]),), {}, 1.5),
+        ('polygon_pentagon', 'polygon', 'FlatSimplePolygonGM',
+         (N.array([[N.cos(-2. * N.pi * k / 5. + 0.3) for k in range(5)], [0.8 * N.sin(-2. * N.pi * k / 5. + 0.3) for k in range(5)]]),), {}, 1.2),
+        ('polygon_perforated', 'polygon', 'PerforatedPolygonGM',
+         (N.array([[-1., -1., 0.2, 0.2, 0.6, 1.2, 1.2], [-0.8, 1., 1., 0.1, 0.3, 0.1, -0.8]]),
+          N.array([[-0.5, 0.4], [0.7, -0.4], [-0.3, -0.5]]), N.array([0.3, 0.2, 0.15])), {}, 1.5),
         # CutSphereGM: the bounding volume is built per package (callable values get the package namespace)
         ('sphere_cut_plane', 'sphere_surface', 'CutSphereGM', (1.3,),
          {'bounding_volume': lambda pkg: pkg.boundary_shape.BoundaryPlane(location=N.r_[0.1, 0., 0.4], rotation=rot([1., 0.3, 0.], 0.5))}, 1.5),

@@ -461,3 +461,50 @@ def test_sun_tracking_updates_frames_on_the_device():
     fresh.reset_tallies()
     fresh.ray_tracer(scenes.nsttf_source(20000, src2, seed=9), reps=20, min_energy=1e-10, tree=True, accel=True, seed=9)
     assert N.array_equal(eng.get_tallies()[2], fresh.get_tallies()[2])
+
+
+def test_polygon_plates_and_triangulated_surface():
+    """
+    polygon.py (FlatSimplePolygonGM, PerforatedPolygonGM) and models/triangulated_surface.py: point-in-polygon on the device
+    against the host copy of the rule, absorbed power of an L-shaped plate = flux x its area, perforations remove theirs,
+    and two triangles of an indexed face set collect what the rectangle they tile collects.
+    """
+    from tracer_amd.polygon import FlatSimplePolygonGM, PerforatedPolygonGM
+    from tracer_amd.models.triangulated_surface import TriangulatedSurface
+    prof = N.array([[-1., -1., 0.2, 0.2, 0.6, 1.2, 1.2], [-0.8, 1., 1., 0.1, 0.3, 0.1, -0.8]])
+    gm = FlatSimplePolygonGM(prof)
+    rng = N.random.RandomState(4)
+    pts = N.vstack((rng.uniform(-1.3, 1.5, 5000), rng.uniform(-1., 1.2, 5000), N.ones(5000)))
+    t = gm.find_intersections(N.eye(4), RayBundle(pts, N.tile(N.c_[[0., 0., -1.]], (1, 5000))))
+    closed = N.concatenate((prof, prof[:, :1]), axis=1)
+    assert N.array_equal(N.isfinite(t), gm.in_poly(pts[:2], closed)) and 1500 < N.isfinite(t).sum() < 3500
+    with pytest.raises(ValueError):
+        FlatSimplePolygonGM(N.array([[0., 1.], [0., 1.]]))
+    # shoelace area of the clockwise profile
+    x, y = prof
+    area = 0.5 * abs(N.sum(x * N.roll(y, -1) - N.roll(x, -1) * y))
+    holes_c, holes_r = N.array([[-0.5, 0.4], [0.7, -0.4]]), N.array([0.3, 0.2])
+    n = 2000000
+    for geom, expect in ((FlatSimplePolygonGM(prof), area), (PerforatedPolygonGM(prof, holes_c, holes_r), area - N.pi * (0.3 ** 2 + 0.2 ** 2))):
+        asm = Assembly(objects=[AssembledObject(surfs=[Surface(geom, opt.Lambertian(1.))])])
+        src = sources.rect_bundle(n, N.c_[[0.1, 0.1, 2.]], N.r_[0., 0., -1.], 3., 2.6, 0., flux=1000., seed=8)
+        eng = TracerEngine(asm)
+        eng.ray_tracer(src, reps=1, min_energy=1e-10, tree=False, seed=8)
+        a, r, h = eng.get_tallies()
+        sigma = 1000. * 3. * 2.6 * N.sqrt((expect / 7.8) * (1. - expect / 7.8) / n)
+        assert abs(a[0] - 1000. * expect) < 4. * sigma, (a[0], 1000. * expect)
+    # the two triangles of a unit square, tilted and shifted, against the same square as a RectPlateGM
+    verts = N.array([[0., 0., 0.], [1., 0., 0.], [1., 1., 0.], [0., 1., 0.], [0.5, 0.5, 0.]])
+    faces = N.array([[0, 1, 2], [0, 2, 3], [0, 0, 1], [0, 4, 2]])           # one degenerate and one collinear face are dropped
+    frame = N.dot(translate(0.3, -0.2, 0.1), rotx(0.3))
+    mesh = TriangulatedSurface(verts, faces, opt.Lambertian(1.), transform=frame)
+    assert len(mesh.get_surfaces()) == 2
+    plate = AssembledObject(surfs=[Surface(RectPlateGM(1., 1.), opt.Lambertian(1.))], transform=N.dot(frame, translate(0.5, 0.5, 0.)))
+    got = []
+    for obj in (mesh, plate):
+        eng = TracerEngine(Assembly(objects=[obj]))
+        eng.ray_tracer(sources.rect_bundle(400000, N.c_[[0.8, 0.3, 3.]], N.r_[0., 0., -1.], 2.5, 2.5, 0.02, flux=10., seed=6), reps=1,
+                       min_energy=1e-10, tree=False, seed=6)
+        a, r, h = eng.get_tallies()
+        got.append((a.sum(), h.sum()))
+    assert got[0][1] == got[1][1] and N.isclose(got[0][0], got[1][0], rtol=1e-12)

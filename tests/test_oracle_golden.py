@@ -33,7 +33,7 @@ def test_geometry_all_kinds():
             nrm = geometry.normals(kind, g[pre + 'frame'], list(g[pre + 'gm']), g[pre + 'hits'], g[pre + 'd'][:, idx])
             ok = N.all(N.isclose(nrm, g[pre + 'normals'], **TOL) | (N.isnan(nrm) & N.isnan(g[pre + 'normals'])), axis=0)
             assert ok.all(), (names[ci], N.nonzero(~ok)[0][:5])
-    assert seen == set(range(29)), "every native geometry kind has a fixture"
+    assert seen == set(range(30)), "every native geometry kind has a fixture"
     assert sum(int(N.isfinite(g['g%d_t' % ci]).sum()) for ci in range(int(g['n_cases']))) > 5000
 
 

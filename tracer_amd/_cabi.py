@@ -31,7 +31,7 @@ SURF_CAPTURE_HITS = 0x1
  GM_PARABOLOID, GM_PARAB_DISH, GM_PARAB_HEX, GM_PARAB_RECT, GM_PARAB_RECT_OFFAXIS, GM_PARAB_CYL,
  GM_PARAB_TROUGH, GM_SPHERE, GM_HEMISPHERE, GM_SPHERE_RECT, GM_CYL_INF, GM_CYL_FINITE, GM_CYL_RECTCUT,
  GM_CONE_INF, GM_CONE_FINITE, GM_FRUSTUM, GM_FRUSTUM_RECTCUT, GM_QUADRATIC, GM_QUADRATIC_RECT,
- GM_ELLIPSOID, GM_ELLIPSOID_CUT, GM_SPHERE_CUT) = range(29)
+ GM_ELLIPSOID, GM_ELLIPSOID_CUT, GM_SPHERE_CUT, GM_POLYGON) = range(30)
 
 # enum trc_optics_kind
 (OPT_TRANSPARENT, OPT_REFLECTIVE, OPT_ONE_SIDED_REFLECTIVE, OPT_REAL_REFLECTIVE,

@@ -24,6 +24,8 @@ static inline bool trc_surface_bounds(const trc_surface_desc &s, double lo[3], d
     case TRC_GM_TRIANGLE:
         for (int i = 0; i < 3; ++i) { l[i] = std::fmin(0.0, std::fmin(g[i], g[3 + i])); h[i] = std::fmax(0.0, std::fmax(g[i], g[3 + i])); }
         break;
+    case TRC_GM_POLYGON:
+        l[0] = g[2]; h[0] = g[3]; l[1] = g[4]; h[1] = g[5]; l[2] = h[2] = 0.0; break;
     case TRC_GM_PARAB_DISH: {
         double rx = std::sqrt(g[2] / g[0]), ry = std::sqrt(g[2] / g[1]);
         l[0] = -rx; h[0] = rx; l[1] = -ry; h[1] = ry; l[2] = 0.0; h[2] = g[2]; break;

@@ -73,6 +73,7 @@ TRC_HD int trc_gm_nparams(int kind) {
     case TRC_GM_FRUSTUM_RECTCUT: return 6;
     case TRC_GM_QUADRATIC: return 6;
     case TRC_GM_QUADRATIC_RECT: return 8;
+    case TRC_GM_POLYGON: return 6;
     case TRC_GM_ELLIPSOID: return 3;
     case TRC_GM_ELLIPSOID_CUT: return 9;
     case TRC_GM_SPHERE_CUT: return 15;
@@ -259,6 +260,33 @@ TRC_HD double trc_intersect_flat(int kind, const double *rec, const double *extr
         if (kind == TRC_GM_ROUND_CUT && lx > g[2]) return TRC_INF;
         return t;
     }
+    case TRC_GM_POLYGON: {
+        // boundary-crossing count with the reference's segment rules (polygon.py:30-63): a segment wholly at x >= the point
+        // counts when it straddles the point's y; one that straddles both x and y counts when its crossing abscissa
+        // is >= the point's x; the rest do not.  "<=" puts a point level with a vertex on the vertex's lower-left side.
+        const int n = (int)g[0], nh = (int)g[1];
+        const double *xs = extra + trc_rec_extra_off(rec), *ys = xs + n;
+        unsigned crossings = 0;
+        for (int k = 0; k < n; ++k) {
+            const int k1 = (k + 1 == n) ? 0 : k + 1;
+            const double x0 = xs[k], y0 = ys[k], x1 = xs[k1], y1 = ys[k1];
+            const bool xp0 = lx <= x0, xp1 = lx <= x1, yp0 = ly <= y0, yp1 = ly <= y1;
+            if (yp0 == yp1) continue;
+            if (xp0 && xp1) crossings += 1u;
+            else if (xp0 != xp1) {
+                const double a = (y1 - y0) / (x1 - x0);              // :57-61
+                const double x_inter = (ly - (y0 - a * x0)) / a;
+                if (x_inter >= lx) crossings += 1u;
+            }
+        }
+        if (!(crossings & 1u)) return TRC_INF;
+        const double *hole = ys + n;                                  // circular perforations, :192-195
+        for (int k = 0; k < nh; ++k) {
+            double ex = lx - hole[3 * k], ey = ly - hole[3 * k + 1];
+            if (sqrt(ex * ex + ey * ey) < hole[3 * k + 2]) return TRC_INF;
+        }
+        return t;
+    }
     default:
         return TRC_INF;
     }
@@ -436,7 +464,7 @@ TRC_HD double trc_intersect_quadric(int kind, const double *rec, double vx, doub
     return sel ? t1 : t0;
 }
 
-TRC_HD bool trc_gm_is_flat(int kind) { return kind <= TRC_GM_TRIANGLE; }
+TRC_HD bool trc_gm_is_flat(int kind) { return kind <= TRC_GM_TRIANGLE || kind == TRC_GM_POLYGON; }
 
 // GeometryManager.find_intersections for one ray: parametric distance, +inf = miss
 TRC_HD double trc_intersect(const double *rec, const double *extra, double vx, double vy, double vz,
