@@ -95,7 +95,10 @@ typedef enum trc_optics_kind {
     TRC_OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL = 10, /* ..._piecewise_spectral :363-391
                                            extra: n_theta, n_lambda, theta[], lambda[], absorptance[n_theta][n_lambda] */
     TRC_OPT_FRESNEL_CONDUCTOR = 11,     /* FresnelConductorHomogenous :1523-1558  opt: n1 ; extra: lambda[n] | n[n] | k[n] */
-    TRC_OPT_KIND_COUNT = 12
+    TRC_OPT_SEMI_LAMBERTIAN = 12,       /* SemiLambertian          :506-531   opt: absorptivity,angular_range -- as the class
+                                           describes itself: mirror for incidence angles above angular_range, Lambertian
+                                           below (its __call__ indexes the direction array by rows, :525, and cannot run) */
+    TRC_OPT_KIND_COUNT = 13
 } trc_optics_kind;
 
 /* surface flags */

@@ -160,6 +160,17 @@ def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event):
         u0, u1 = philox.uniform_pair(seed, rid, event, 0)
         dirs = lambertian_directions(nrm, 2. * N.pi * u0, u1, opt[1])
         return [dict(sel=allsel, directions=dirs, energy=e * (1. - opt[0]), ref=ref.copy(), rid=rid)]
+    if opt_kind == OPT_SEMI_LAMBERTIAN:
+        # optics_callables.py:506-531 as the class describes itself (:507-509): mirror above `angular_range` of incidence,
+        # Lambertian below, specular block first (:531).  The reference's __call__ cannot run (:525 indexes the (3, n)
+        # direction array by ray number): parity unpinned, this is the evident intent.
+        angs = N.arccos(-N.sum(d * nrm, axis=0))
+        gl = angs > opt[1]
+        u0, u1 = philox.uniform_pair(seed, rid, event, 0)
+        ng = ~gl
+        return [dict(sel=allsel[gl], directions=reflections(d[:, gl], nrm[:, gl]), energy=e[gl] * (1. - opt[0]), ref=ref[gl].copy(), rid=rid[gl]),
+                dict(sel=allsel[ng], directions=lambertian_directions(nrm[:, ng], 2. * N.pi * u0[ng], u1[ng], opt[1]),
+                     energy=e[ng] * (1. - opt[0]), ref=ref[ng].copy(), rid=rid[ng])]
     if opt_kind == OPT_LAMBERTIAN_SPECULAR:                      # :561-585
         u0, u1 = philox.uniform_pair(seed, rid, event, 0)
         u2, _ = philox.uniform_pair(seed, rid, event, 1)

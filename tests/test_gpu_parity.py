@@ -547,10 +547,10 @@ def _cavity_scene():
     gm[3, :2] = 1.6, 1.0
     gm[4, :2] = 0.6, 0.2
     gm[5, :2] = 0.3, -1.
-    ok = [K.OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL, K.OPT_LAMBERTIAN_DIRECTIONAL, K.OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL, K.OPT_LAMBERTIAN,
+    ok = [K.OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL, K.OPT_LAMBERTIAN_DIRECTIONAL, K.OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL, K.OPT_SEMI_LAMBERTIAN,
           K.OPT_FRESNEL_CONDUCTOR, K.OPT_REFLECTIVE_SPECTRAL]
     opt = N.zeros((6, 8))
-    opt[3, :2] = 0.95, N.pi / 2.
+    opt[3, :2] = 0.6, 0.9           # the aperture annulus: mirror beyond 0.9 rad of incidence, Lambertian (into 0.9 rad) below
     opt[4, 0] = 1.0
     which = [1, 0, 1, -1, 2, 3]
     eoff = N.array([offs[w] if w >= 0 else -1 for w in which])
@@ -621,6 +621,7 @@ def test_random_scenes_all_searches_agree(ctx):
     from tracer_amd.cylinder import FiniteCylinder
     from tracer_amd.cone import FiniteCone, ConicalFrustum
     from tracer_amd.ellipsoid import EllipsoidGM
+    from tracer_amd.polygon import FlatSimplePolygonGM
     from tracer_amd.spatial_geometry import general_axis_rotation
     from tracer_amd import optics_callables as opt
     from tracer_amd.scene import compile_scene, DeviceScene
@@ -637,7 +638,8 @@ def test_random_scenes_all_searches_agree(ctx):
               lambda r: FiniteCylinder(r.uniform(0.5, 2.), r.uniform(0.5, 3.)),
               lambda r: FiniteCone(r.uniform(0.3, 1.), r.uniform(0.5, 2.)),
               lambda r: ConicalFrustum(0., r.uniform(0.3, 1.), r.uniform(0.5, 2.), r.uniform(1.1, 2.)),
-              lambda r: EllipsoidGM(r.uniform(0.5, 1.5), r.uniform(0.5, 1.5), r.uniform(0.5, 1.5), zlim=[-0.5, 0.4])]
+              lambda r: EllipsoidGM(r.uniform(0.5, 1.5), r.uniform(0.5, 1.5), r.uniform(0.5, 1.5), zlim=[-0.5, 0.4]),
+              lambda r: FlatSimplePolygonGM(N.array([[-1., -1., 0.2, 0.2, 1.2, 1.2], [-0.8, 1., 1., 0.1, 0.1, -0.8]]) * r.uniform(0.8, 2.))]
     for seed in (1, 2, 3):
         r = N.random.RandomState(seed)
         objs = []

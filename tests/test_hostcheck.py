@@ -145,6 +145,39 @@ def test_core_buie_staged_inversion_equals_plain(hc):
     assert seen >= 2
 
 
+def test_core_semi_lambertian_vs_oracle(hc):
+    """SemiLambertian (optics_callables.py:506-531 as documented): the core against the oracle on the same streams, the
+    mirror law for the glancing rays, the cone and the hemisphere for the others, specular block first"""
+    from oracle import optics
+    from tracer_amd import _cabi
+    o = load('optics.npz')
+    frame = o['frame']
+    nrm, d, e, wl = [N.ascontiguousarray(o[k]) for k in ('normals', 'dirs', 'energy', 'wavelengths')]
+    H = d.shape[1]
+    rid = N.arange(H, dtype=N.uint64) + N.uint64(77)
+    ref_in = N.ones(H)
+    extra = N.zeros(1)
+    ang_range, absorb = 0.8, 0.25
+    desc = _desc(0, frame, [], [], _cabi.OPT_SEMI_LAMBERTIAN, [absorb, ang_range])
+    out = [N.empty(2 * H) for _ in range(5)]
+    blk = N.empty(2 * H, dtype=N.int32)
+    hc.hc_shade(C.byref(desc), _p(extra), C.c_long(H), _p(d[0]), _p(d[1]), _p(d[2]), _p(e), _p(ref_in), _p(wl), _p(nrm[0]), _p(nrm[1]),
+                _p(nrm[2]), _p(rid, C.c_uint64), C.c_uint64(4242), 3, *[_p(a) for a in out], _p(blk, C.c_int32))
+    blocks = optics.shade(_cabi.OPT_SEMI_LAMBERTIAN, [absorb, ang_range], extra, frame[:3, 2], d, e, ref_in, wl, nrm, 4242, rid, 3)
+    slots = N.concatenate([N.nonzero(blk == b)[0] for b in (0, 1)])
+    assert N.array_equal(slots, N.hstack([b['sel'] for b in blocks]))
+    got = N.vstack([a[slots] for a in out[:3]])
+    assert N.allclose(got, N.hstack([b['directions'] for b in blocks]), rtol=1e-9, atol=1e-9)
+    assert N.allclose(out[3][slots], N.hstack([b['energy'] for b in blocks]), rtol=1e-12)
+    inc = N.arccos(-N.sum(d * nrm, axis=0))
+    gl = inc > ang_range
+    assert 0.1 * H < gl.sum() < 0.9 * H and N.array_equal(N.sort(blocks[0]['sel']), N.nonzero(gl)[0])
+    mirrored = d[:, gl] - 2. * N.sum(d[:, gl] * nrm[:, gl], axis=0) * nrm[:, gl]
+    assert N.allclose(blocks[0]['directions'], mirrored, atol=1e-12)
+    cosn = N.sum(blocks[1]['directions'] * nrm[:, ~gl], axis=0)
+    assert (cosn >= N.cos(ang_range) - 1e-9).all() and N.allclose(out[3][:H], e * (1. - absorb))
+
+
 def test_core_kd_traversal_equals_brute_force(hc):
     """the device traversal (front-to-back with early exit) returns the brute-force (t, surface) for every ray"""
     from tracer_amd import scenes, _cabi

@@ -1118,6 +1118,22 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
         out[0].e = e * (1.0 - opt[0]);
         return 1;
     }
+    case TRC_OPT_SEMI_LAMBERTIAN: {                                 // :514-531 as documented (:507-509)
+        // incidence angle from the oriented normal; glancing rays are mirrored (block 0), the others scattered (block 1):
+        // `outg = specular + diffuse` (:531)
+        double ang = acos(-(dx * nx + dy * ny + dz * nz));
+        if (ang > opt[1]) {
+            trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);
+        } else {
+            double u0, u1, ax, ay, az;
+            trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
+            trc_pillbox_dir(TRC_TWO_PI * u0, u1, opt[1], &ax, &ay, &az);
+            trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
+            out[0].blk = 1;
+        }
+        out[0].e = e * (1.0 - opt[0]);
+        return 1;
+    }
     case TRC_OPT_LAMBERTIAN_SPECULAR: {                             // :561-585
         double u0, u1, u2, u3;
         trc_uniform_pair(seed, rid, event, 0, &u0, &u1);

@@ -145,6 +145,20 @@ class LambertianSpecular(NativeOptics):
         return _cabi.OPT_LAMBERTIAN_SPECULAR, [self._abs, self.specularity], []
 
 
+class SemiLambertian(NativeOptics):
+    """
+    Mirror for rays arriving at more than `angular_range` from the normal, Lambertian reflector (into the same cone) for the
+    others (optics_callables.py:506-531, as its docstring and its two parent calls describe it; the reference's own
+    __call__ indexes the direction array by rows, :525, and raises).
+    """
+    def __init__(self, absorptivity=0., angular_range=N.pi / 2.):
+        self._abs = absorptivity
+        self._ang_range = angular_range
+
+    def _native(self):
+        return _cabi.OPT_SEMI_LAMBERTIAN, [self._abs, self._ang_range], []
+
+
 class Reflective_spectral(NativeOptics):
     """Mirror whose absorptance is interpolated on the ray wavelength (optics_callables.py:178-193)."""
     def __init__(self, absorptances, wavelengths):
