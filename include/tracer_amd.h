@@ -86,9 +86,11 @@ typedef enum trc_optics_kind {
     TRC_OPT_ONE_SIDED_REFLECTIVE = 2,   /* OneSidedReflective      :195-212   opt: absorptivity */
     TRC_OPT_REAL_REFLECTIVE = 3,        /* RealReflective          :214-269   opt: absorptivity,sigma,bi_var */
     TRC_OPT_ONE_SIDED_REAL_REFLECTIVE = 4, /* OneSidedRealReflective :492-504 opt: absorptivity,sigma,bi_var */
-    TRC_OPT_LAMBERTIAN = 5,             /* Lambertian              :143-176   opt: absorptivity,ang_range */
+    TRC_OPT_LAMBERTIAN = 5,             /* Lambertian              :143-176   opt: absorptivity,ang_range ; LambertianAbsorbant
+                                           :891-906 adds attenuation_coefficient (0: none), scaling */
     TRC_OPT_LAMBERTIAN_SPECULAR = 6,    /* LambertianSpecular      :553-585   opt: absorptivity,specularity */
-    TRC_OPT_REFRACTIVE_HOMOGENOUS = 7,  /* RefractiveHomogenous    :1186-1296 opt: n1,n2,single_ray,sigma(<0:none) */
+    TRC_OPT_REFRACTIVE_HOMOGENOUS = 7,  /* RefractiveHomogenous    :1186-1296 opt: n1,n2,single_ray,sigma(<0:none) ;
+                                           RefractiveTransmissiveHomogenous :1326-1348 adds a_c in n1, a_c in n2, scaling, 1 */
     TRC_OPT_REFLECTIVE_SPECTRAL = 8,    /* Reflective_spectral     :178-193   extra: lambda[n] | absorptance[n] */
     TRC_OPT_LAMBERTIAN_DIRECTIONAL = 9, /* Lambertian_directional_axisymmetric_piecewise :331-361
                                            extra: theta[n] | absorptance[n] */
@@ -342,7 +344,8 @@ int trc_gm_get_normals(trc_ctx *ctx, const trc_surface_desc *surf, int64_t n,
                        double *nx, double *ny, double *nz);
 /*
  * optics callable on n selected hits. in: incident rays (direction, energy, ref_index,
- * wavelength, rid) + hit points + oriented normals.  out: capacity 2n rays; out->n is set to the
+ * wavelength, rid; origins x,y,z when the optics attenuates along the path: Absorbant.attenuate
+ * :874-889) + hit points + oriented normals.  out: capacity 2n rays; out->n is set to the
  * number produced; out->parent[k] indexes the n inputs; block order as the reference's
  * (reflected block, then refracted block: optics_callables.py:1284-1294).
  */

@@ -70,7 +70,7 @@ def trace(scene, v, d, e, ref, wl, rid, reps, min_energy, seed):
             pts = v[:, sel] + tmin[sel][None, :] * d[:, sel]
             nrm = geometry.normals(s['kind'], s['frame'], s['gm'], pts, d[:, sel])
             blocks = optics.shade(s['opt_kind'], s['opt'], s['extra'], s['frame'][:3, 2], d[:, sel], e[sel], ref[sel], wl[sel],
-                                  nrm, seed, rid[sel], it + 1)
+                                  nrm, seed, rid[sel], it + 1, path=N.sqrt(N.sum((pts - v[:, sel]) ** 2, axis=0)))
             e_out = N.zeros(len(sel))
             for b in blocks:
                 N.add.at(e_out, b['sel'], b['energy'])

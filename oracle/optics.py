@@ -123,11 +123,11 @@ def fresnel_to_attenuating(n1, m2, theta1):
     return R_p, R_s, theta2
 
 
-def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event):
+def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event, path=None):
     """
     One optics call on H hits.  Returns a list of blocks (reflected block first, refracted second), each a dict
     with sel (indices into the H hits), directions (3,k), energy (k,), ref (k,), rid (k,).
-    Draw order = csrc/trc_core.h trc_shade.
+    Draw order = csrc/trc_core.h trc_shade.  path: distance travelled to the hit (Absorbant.attenuate, :874-889), or None.
     """
     H = d.shape[1]
     allsel = N.arange(H)
@@ -159,7 +159,10 @@ def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event):
     if opt_kind == OPT_LAMBERTIAN:                               # :154-176
         u0, u1 = philox.uniform_pair(seed, rid, event, 0)
         dirs = lambertian_directions(nrm, 2. * N.pi * u0, u1, opt[1])
-        return [dict(sel=allsel, directions=dirs, energy=e * (1. - opt[0]), ref=ref.copy(), rid=rid)]
+        eo = e * (1. - opt[0])
+        if len(opt) > 2 and opt[2] != 0.:                        # LambertianAbsorbant :898-906: attenuate, then absorb
+            eo = e * N.exp(-opt[2] * (path * opt[3])) * (1. - opt[0])
+        return [dict(sel=allsel, directions=dirs, energy=eo, ref=ref.copy(), rid=rid)]
     if opt_kind == OPT_SEMI_LAMBERTIAN:
         # optics_callables.py:506-531 as the class describes itself (:507-509): mirror above `angular_range` of incidence,
         # Lambertian below, specular block first (:531).  The reference's __call__ cannot run (:525 indexes the (3, n)
@@ -215,6 +218,8 @@ def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event):
             rots = rotation_to_z(nrm.T)
             for i in range(H):
                 nrm[:, i] = N.dot(rots[i], err[:, i])
+        if len(opt) > 7 and opt[7] != 0.:                        # RefractiveTransmissiveHomogenous :1345-1348, Absorbant :881-886
+            e = e * N.exp(-N.where(ref == nb, opt[5], opt[4]) * (path * opt[6]))
         n1 = ref
         n2 = N.where(n1 == na, nb, na)                           # :1217-1218
         refr, out_dirs = refractions(n1, n2, d, nrm)

@@ -241,13 +241,15 @@ def make_optics(ref, amd, out):
     oc = ref.optics_callables
     cases = []
 
-    def run(name, opt_ref, opt_amd, ref_index=None, draws=None, wavelengths=None):
+    def run(name, opt_ref, opt_amd, ref_index=None, draws=None, wavelengths=None, lengths=None):
         kw = {}
         if ref_index is not None:
             kw['ref_index'] = ref_index
         if wavelengths is not None:
             kw['wavelengths'] = wavelengths
-        bund = ref.ray_bundle.RayBundle(vertices=pts - d, directions=d.copy(), energy=e.copy(), **kw)
+        # ray origins: `lengths` behind the hit points (1 when the optics does not look at the path)
+        L = N.ones(H) if lengths is None else lengths
+        bund = ref.ray_bundle.RayBundle(vertices=pts - d * L, directions=d.copy(), energy=e.copy(), **kw)
         geo = FakeGeometry(frame, nrm, pts)
         N.random.seed(len(cases) + 5)
         with N.errstate(all='ignore'):
@@ -262,6 +264,7 @@ def make_optics(ref, amd, out):
         out[pre + 'opt'] = p8
         out[pre + 'extra'] = N.asarray(extra, dtype=float)
         out[pre + 'ref_in'] = N.ones(H) if ref_index is None else ref_index
+        out[pre + 'path'] = L
         out[pre + 'out_dirs'] = outg.get_directions()
         out[pre + 'out_energy'] = outg.get_energy()
         out[pre + 'out_parents'] = N.asarray(outg.get_parents())
@@ -301,6 +304,17 @@ def make_optics(ref, amd, out):
     run('refractive_split_sigma', oc.RefractiveHomogenous(1.0, 1.33, single_ray=False, sigma=2e-3),
         A.RefractiveHomogenous(1.0, 1.33, single_ray=False, sigma=2e-3), ref_index=N.ones(H),
         draws=lambda: dict(g0=N.random.normal(scale=2e-3, size=H), phi=N.random.uniform(low=0., high=2. * N.pi, size=H)))
+    # attenuating media (Absorbant.attenuate): path lengths between 0.2 and 3 (the coefficient of LambertianAbsorbant as a list:
+    # the reference takes len() of it, :883)
+    Lr = rng.uniform(0.2, 3., size=H)
+    run('lambertian_absorbant', oc.LambertianAbsorbant(0.3, [0.7], 1.2), A.LambertianAbsorbant(0.3, [0.7], 1.2), lengths=Lr,
+        draws=lambda: dict(xi1=N.random.uniform(low=0., high=2. * N.pi, size=H), xi2=N.random.uniform(size=H)))
+    run('lambertian_absorbant_scaled', oc.LambertianAbsorbant(0.1, [0.4], scaling=2.5), A.LambertianAbsorbant(0.1, [0.4], scaling=2.5), lengths=Lr,
+        draws=lambda: dict(xi1=N.random.uniform(low=0., high=2. * N.pi, size=H), xi2=N.random.uniform(size=H)))
+    run('refractive_transmissive_split', oc.RefractiveTransmissiveHomogenous(1.0, 1.5, [0.05, 0.9], single_ray=False),
+        A.RefractiveTransmissiveHomogenous(1.0, 1.5, [0.05, 0.9], single_ray=False), ref_index=n_in, lengths=Lr)
+    run('refractive_transmissive_one_coefficient', oc.RefractiveTransmissiveHomogenous(1.0, 1.5, [0.6], single_ray=False, scaling=0.5),
+        A.RefractiveTransmissiveHomogenous(1.0, 1.5, [0.6], single_ray=False, scaling=0.5), ref_index=n_in, lengths=Lr)
     lam = N.linspace(0.2e-6, 3e-6, 9)
     ab = N.array([0.1, 0.2, 0.15, 0.4, 0.9, 0.5, 0.3, 0.2, 0.25])
     run('reflective_spectral', oc.Reflective_spectral(ab, lam), A.Reflective_spectral(ab, lam), wavelengths=wl)

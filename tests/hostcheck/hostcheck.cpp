@@ -48,14 +48,16 @@ int hc_normals(const trc_surface_desc *s, long n, const double *hx, const double
 }
 
 // shade: outputs 2n slots (child 0 at i, child 1 at n+i), blk = -1 when empty
-int hc_shade(const trc_surface_desc *s, const double *extra, long n, const double *dx, const double *dy, const double *dz,
-             const double *e, const double *ref, const double *wl, const double *nx, const double *ny, const double *nz,
-             const uint64_t *rid, uint64_t seed, int event, double *odx, double *ody, double *odz, double *oe, double *oref,
-             int *oblk) {
+// path: distance travelled to the hit per ray (attenuating optics), or null for 0
+int hc_shade_path(const trc_surface_desc *s, const double *extra, long n, const double *dx, const double *dy, const double *dz,
+                  const double *e, const double *ref, const double *wl, const double *nx, const double *ny, const double *nz,
+                  const uint64_t *rid, uint64_t seed, int event, double *odx, double *ody, double *odz, double *oe, double *oref,
+                  int *oblk, const double *path) {
     for (long i = 0; i < n; ++i) {
         trc_ray_out out[2];
         int no = trc_shade(s->optics_kind, s->opt, extra, s->extra_off, s->extra_len, s->frame[2], s->frame[6], s->frame[10],
-                           dx[i], dy[i], dz[i], e[i], ref[i], wl[i], nx[i], ny[i], nz[i], seed, rid[i], (uint32_t)event, out);
+                           dx[i], dy[i], dz[i], e[i], ref[i], wl[i], path ? path[i] : 0.0, nx[i], ny[i], nz[i], seed, rid[i],
+                           (uint32_t)event, out);
         for (int c = 0; c < 2; ++c) {
             long slot = c == 0 ? i : n + i;
             if (c < no) {
@@ -65,6 +67,13 @@ int hc_shade(const trc_surface_desc *s, const double *extra, long n, const doubl
         }
     }
     return 0;
+}
+
+int hc_shade(const trc_surface_desc *s, const double *extra, long n, const double *dx, const double *dy, const double *dz,
+             const double *e, const double *ref, const double *wl, const double *nx, const double *ny, const double *nz,
+             const uint64_t *rid, uint64_t seed, int event, double *odx, double *ody, double *odz, double *oe, double *oref,
+             int *oblk) {
+    return hc_shade_path(s, extra, n, dx, dy, dz, e, ref, wl, nx, ny, nz, rid, seed, event, odx, ody, odz, oe, oref, oblk, nullptr);
 }
 
 int hc_source(const trc_source_desc *src, long n, uint64_t seed, uint64_t offset, double *x, double *y, double *z, double *dx,

@@ -508,3 +508,50 @@ def test_polygon_plates_and_triangulated_surface():
         a, r, h = eng.get_tallies()
         got.append((a.sum(), h.sum()))
     assert got[0][1] == got[1][1] and N.isclose(got[0][0], got[1][0], rtol=1e-12)
+
+
+def test_attenuating_media_in_the_engines():
+    """
+    Absorbant.attenuate (optics_callables.py:874-889) through the engines: a slab of glass (RefractiveTransmissiveHomogenous on both
+    faces) over a black Lambertian floor in an absorbing atmosphere (LambertianAbsorbant).  Normal incidence, known answer:
+    what reaches the floor is (1-R)^2 exp(-a_glass d) exp(-a_air h) of what enters, R = ((n-1)/(n+1))^2; ordered and fast
+    engines agree with the oracle ray by ray / tally by tally.
+    """
+    from oracle import engine as oeng
+    from tracer_amd.scene import compile_scene
+    n_glass, a_air, a_glass, thick, gap = 1.5, 0.2, 0.8, 0.3, 1.1
+    def scene(single_ray=False):
+        top = Surface(RectPlateGM(4., 4.), opt.RefractiveTransmissiveHomogenous(1., n_glass, [a_air, a_glass], single_ray=single_ray))
+        bottom = Surface(RectPlateGM(4., 4.), opt.RefractiveTransmissiveHomogenous(1., n_glass, [a_air, a_glass], single_ray=single_ray))
+        floor = Surface(RectPlateGM(6., 6.), opt.LambertianAbsorbant(1., a_air))
+        return Assembly(objects=[AssembledObject(surfs=[top], transform=translate(0, 0, gap + thick)),
+                                 AssembledObject(surfs=[bottom], transform=translate(0, 0, gap)),
+                                 AssembledObject(surfs=[floor])])
+    n = 20000
+    rng = N.random.RandomState(3)
+    pos = N.vstack((rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), N.ones(n) * (gap + thick + 0.5)))
+    dirs = N.tile(N.c_[[0., 0., -1.]], (1, n))
+    en = N.ones(n) / n
+    R = ((n_glass - 1.) / (n_glass + 1.)) ** 2
+    first_pass = N.exp(-a_air * 0.5) * (1. - R) * N.exp(-a_glass * thick) * (1. - R) * N.exp(-a_air * gap)
+    asm = scene()
+    eng = TracerEngine(asm)
+    eng.ray_tracer(RayBundle(pos, dirs, energy=en, ref_index=N.ones(n)), reps=1000, min_energy=1e-9 / n, tree=True, seed=4)
+    a, r, h = eng.get_tallies()
+    # the floor also receives the light that bounced inside the slab: geometric series in R^2 exp(-2 a_glass d)
+    series = first_pass / (1. - R * R * N.exp(-2. * a_glass * thick))
+    # (a surface's absorbed tally is E_in - E_out, AbsorptionAccountant :1638-1643: the attenuation over the last leg is
+    # booked on the surface the leg ends on, so the floor's tally is what left the slab downwards)
+    series /= N.exp(-a_air * gap)
+    assert N.isclose(a[2], series, rtol=1e-6), (a[2], series)
+    ref = oeng.trace_bundle(compile_scene(asm), pos, dirs, en, 1000, 1e-9 / n, 4, ref_index=N.ones(n))
+    assert N.array_equal(h, ref['hits']) and N.allclose(a, ref['absorbed'], rtol=1e-9, atol=1e-15)
+    assert [b.get_num_rays() for b in eng.tree._bunds] == [l['vertices'].shape[1] for l in ref['levels']]
+    # single-ray mode runs on the fast engine: same physics statistically, and equal to the oracle on the same streams
+    asm1 = scene(single_ray=True)
+    eng1 = TracerEngine(asm1)
+    eng1.ray_tracer(RayBundle(pos, dirs, energy=en, ref_index=N.ones(n)), reps=1000, min_energy=1e-9 / n, tree=False, seed=4)
+    a1, r1, h1 = eng1.get_tallies()
+    ref1 = oeng.trace_bundle(compile_scene(asm1), pos, dirs, en, 1000, 1e-9 / n, 4, ref_index=N.ones(n))
+    assert N.array_equal(h1, ref1['hits']) and N.allclose(a1, ref1['absorbed'], rtol=1e-9, atol=1e-15)
+    assert abs(a1[2] - series) < 5. * N.sqrt(series * (1. - series) / n)

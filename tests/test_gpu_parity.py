@@ -115,14 +115,15 @@ def test_geometry_vs_oracle_large_fans(ctx):
             assert close.all(), (kind, int((~close).sum()))
 
 
-def optics_apply(ctx, kind, opt, extra, frame, d, e, ref, wl, nrm, pts, seed, event):
+def optics_apply(ctx, kind, opt, extra, frame, d, e, ref, wl, nrm, pts, seed, event, path=None):
     from tracer_amd import _cabi
     desc = _desc(0, frame, [], extra, kind, opt)
     n = d.shape[1]
     d = _cabi.f64(d); e = _cabi.f64(e); ref = _cabi.f64(ref); wl = _cabi.f64(wl); nrm = _cabi.f64(nrm); pts = _cabi.f64(pts)
     extra = _cabi.f64(extra)
     rid = N.arange(n, dtype=N.uint64) + N.uint64(1000)
-    rin = _cabi.make_rays(n, dx=d[0], dy=d[1], dz=d[2], e=e, ref_index=ref, wavelength=wl, rid=rid)
+    org = _cabi.f64(pts - d * (N.ones(n) if path is None else path))      # ray origins: the attenuating optics measure the path
+    rin = _cabi.make_rays(n, org[0], org[1], org[2], dx=d[0], dy=d[1], dz=d[2], e=e, ref_index=ref, wavelength=wl, rid=rid)
     m = 2 * n
     o = dict((k, N.empty(m)) for k in ('x', 'y', 'z', 'dx', 'dy', 'dz', 'e', 'ref'))
     par = N.empty(m, dtype=N.int64)
@@ -144,15 +145,18 @@ def test_optics_vs_reference_and_oracle(ctx):
     for i, name in enumerate(names):
         pre = 'o%d_' % i
         kind, opt, extra, ref_in = int(o[pre + 'kind']), list(o[pre + 'opt']), o[pre + 'extra'], o[pre + 'ref_in']
-        dirs, en, par, ref, rid = optics_apply(ctx, kind, opt, extra, frame, d, e, ref_in, wl, nrm, pts, 4242, 3)
+        path = o[pre + 'path']
+        dirs, en, par, ref, rid = optics_apply(ctx, kind, opt, extra, frame, d, e, ref_in, wl, nrm, pts, 4242, 3, path=path)
         if name in ('transparent', 'reflective', 'one_sided_reflective', 'real_reflective_sigma0', 'reflective_spectral',
-                    'refractive_split', 'fresnel_conductor'):
+                    'refractive_split', 'fresnel_conductor', 'refractive_transmissive_split', 'refractive_transmissive_one_coefficient'):
             assert N.array_equal(par, o[pre + 'out_parents']), name
             assert N.allclose(dirs, o[pre + 'out_dirs'], rtol=RT, atol=1e-9), name
             assert N.allclose(en, o[pre + 'out_energy'], rtol=RT, atol=1e-12), name
             if (pre + 'out_ref') in o.files:
                 assert N.allclose(ref, o[pre + 'out_ref']), name
-        blocks = optics.shade(kind, opt, extra, up, d, e, ref_in, wl, nrm, 4242, rid, 3)
+        if name.startswith('lambertian_absorbant'):       # energies are deterministic: against the reference's own
+            assert N.allclose(en, o[pre + 'out_energy'], rtol=RT, atol=1e-12), name
+        blocks = optics.shade(kind, opt, extra, up, d, e, ref_in, wl, nrm, 4242, rid, 3, path=path)
         assert N.array_equal(par, N.hstack([b['sel'] for b in blocks])), name
         # trig of ~2*pi*u on the device vs numpy differ in the last bits; 1e-9 still holds
         assert N.allclose(dirs, N.hstack([b['directions'] for b in blocks]), rtol=RT, atol=1e-9), name

@@ -72,9 +72,10 @@ def test_core_optics_vs_oracle_same_streams(hc):
         desc = _desc(0, frame, [], extra, kind, opt)
         out = [N.empty(2 * H) for _ in range(5)]
         blk = N.empty(2 * H, dtype=N.int32)
-        hc.hc_shade(C.byref(desc), _p(extra), C.c_long(H), _p(d[0]), _p(d[1]), _p(d[2]), _p(e), _p(ref_in), _p(wl), _p(nrm[0]), _p(nrm[1]),
-                    _p(nrm[2]), _p(rid, C.c_uint64), C.c_uint64(987654321012), 2, *[_p(a) for a in out], _p(blk, C.c_int32))
-        blocks = optics.shade(kind, opt, extra, frame[:3, 2], d, e, ref_in, wl, nrm, 987654321012, rid, 2)
+        path = N.ascontiguousarray(o[pre + 'path'])
+        hc.hc_shade_path(C.byref(desc), _p(extra), C.c_long(H), _p(d[0]), _p(d[1]), _p(d[2]), _p(e), _p(ref_in), _p(wl), _p(nrm[0]), _p(nrm[1]),
+                         _p(nrm[2]), _p(rid, C.c_uint64), C.c_uint64(987654321012), 2, *([_p(a) for a in out] + [_p(blk, C.c_int32), _p(path)]))
+        blocks = optics.shade(kind, opt, extra, frame[:3, 2], d, e, ref_in, wl, nrm, 987654321012, rid, 2, path=path)
         slots = N.concatenate([N.nonzero(blk == b)[0] for b in (0, 1)])
         par = N.where(slots < H, slots, slots - H)
         assert N.array_equal(par, N.hstack([b['sel'] for b in blocks])), name

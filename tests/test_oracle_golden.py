@@ -87,6 +87,20 @@ def test_optics_variate_replay():
         pre = _optics_case(o, name)
         dirs = optics.lambertian_directions(nrm, o[pre + 'draw_xi1'], o[pre + 'draw_xi2'], o[pre + 'opt'][1])
         check(pre, dirs, e * (1. - o[pre + 'opt'][0]), N.arange(H))
+    # attenuating media (Absorbant.attenuate): energies are deterministic, the Lambertian wall replays its direction draws
+    for name in ('lambertian_absorbant', 'lambertian_absorbant_scaled'):
+        pre = _optics_case(o, name)
+        blocks = optics.shade(int(o[pre + 'kind']), list(o[pre + 'opt']), o[pre + 'extra'], up, d, e, o[pre + 'ref_in'], wl, nrm, 1, rid, 1,
+                              path=o[pre + 'path'])
+        dirs = optics.lambertian_directions(nrm, o[pre + 'draw_xi1'], o[pre + 'draw_xi2'], o[pre + 'opt'][1])
+        check(pre, dirs, blocks[0]['energy'], N.arange(H))
+        assert (blocks[0]['energy'] < e * (1. - o[pre + 'opt'][0]) * 0.95).all() and o[pre + 'path'].min() < 0.5 < 2.5 < o[pre + 'path'].max()
+    for name in ('refractive_transmissive_split', 'refractive_transmissive_one_coefficient'):
+        pre = _optics_case(o, name)
+        blocks = optics.shade(int(o[pre + 'kind']), list(o[pre + 'opt']), o[pre + 'extra'], up, d, e, o[pre + 'ref_in'], wl, nrm, 1, rid, 1,
+                              path=o[pre + 'path'])
+        check(pre, N.hstack([b['directions'] for b in blocks]), N.hstack([b['energy'] for b in blocks]), N.hstack([b['sel'] for b in blocks]),
+              N.hstack([b['ref'] for b in blocks]))
     # angle-dependent absorptance: energies are deterministic, directions replay the Lambertian draws
     for name in ('lambertian_directional', 'lambertian_directional_spectral'):
         pre = _optics_case(o, name)

@@ -1065,8 +1065,9 @@ TRC_HD double trc_fresnel_conductor(double cos_abs, double n1, double n2, double
 // Returns the number of outgoing rays (1 or 2) in out[].
 TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int extra_off, int extra_len,
                      double ux, double uy, double uz, double dx, double dy, double dz, double e, double ref,
-                     double wl, double nx, double ny, double nz, uint64_t seed, uint64_t rid,
+                     double wl, double path, double nx, double ny, double nz, uint64_t seed, uint64_t rid,
                      uint32_t event, trc_ray_out out[2]) {
+    // path: distance the ray travelled to this hit (Absorbant.attenuate, optics_callables.py:874-889: |hit - previous vertex|)
     out[0].ref = ref;
     out[0].blk = 0;
     out[1].blk = 1;
@@ -1115,7 +1116,8 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
         trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
         trc_pillbox_dir(TRC_TWO_PI * u0, u1, opt[1], &ax, &ay, &az);
         trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
-        out[0].e = e * (1.0 - opt[0]);
+        if (opt[2] != 0.0) out[0].e = e * exp(-opt[2] * (path * opt[3])) * (1.0 - opt[0]);      // LambertianAbsorbant :895-906
+        else out[0].e = e * (1.0 - opt[0]);
         return 1;
     }
     case TRC_OPT_SEMI_LAMBERTIAN: {                                 // :514-531 as documented (:507-509)
@@ -1197,6 +1199,9 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
             trc_rotation_to_z_apply(nx, ny, nz, ex, ey, ez, &rx, &ry, &rz);
             nx = rx; ny = ry; nz = rz;
         }
+        // attenuation in the medium the ray arrives through (RefractiveTransmissiveHomogenous :1326-1348 on Absorbant.attenuate
+        // :874-889): coefficient opt[4] in the medium of index n1 = opt[0], opt[5] in the other, path scaled by opt[6]
+        if (opt[7] != 0.0) e *= exp(-((ref == nb) ? opt[5] : opt[4]) * (path * opt[6]));
         double n1 = ref;
         double n2 = (n1 == na) ? nb : na;                           // :1217-1218
         double eta = n2 / n1;

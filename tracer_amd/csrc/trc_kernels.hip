@@ -584,8 +584,9 @@ __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *re
     double nx, ny, nz;
     trc_normal(rec, hx, hy, hz, dx, dy, dz, &nx, &ny, &nz);
     trc_ray_out out[2];
+    const double path = sqrt((hx - px) * (hx - px) + (hy - py) * (hy - py) + (hz - pz) * (hz - pz));
     int n_out = trc_shade(trc_rec_opt_kind(rec), sc.opt + (size_t)s * 8, sc.extra, trc_rec_extra_off(rec), trc_rec_extra_len(rec),
-                          rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, nx, ny, nz, P.seed, rid, (uint32_t)bounce, out);
+                          rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, path, nx, ny, nz, P.seed, rid, (uint32_t)bounce, out);
     (void)n_out;  // scenes whose optics split rays are routed to the ordered engine by the host
     double e_abs = e - out[0].e;
     record_hit<LDS_TALLY>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0, prev, hc);
@@ -1050,8 +1051,9 @@ __global__ __launch_bounds__(256) void k_ord_bounce(OrdParams P) {
         double nx, ny, nz;
         trc_normal(rec, hx, hy, hz, dx, dy, dz, &nx, &ny, &nz);
         trc_ray_out out[2];
+        const double path = sqrt((hx - px) * (hx - px) + (hy - py) * (hy - py) + (hz - pz) * (hz - pz));
         int n_out = trc_shade(trc_rec_opt_kind(rec), sc.opt + (size_t)s * 8, sc.extra, trc_rec_extra_off(rec),
-                              trc_rec_extra_len(rec), rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, nx, ny,
+                              trc_rec_extra_len(rec), rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, path, nx, ny,
                               nz, P.seed, rid, (uint32_t)P.event, out);
         double e_out = out[0].e + (n_out > 1 ? out[1].e : 0.0);
         // tallies (no wave-aggregated capture here: lanes may have exited)
@@ -1233,6 +1235,7 @@ struct OpticsParams {
     const double *dx, *dy, *dz, *e, *ref, *wl;
     const uint64_t *rid;
     unsigned long long ray_offset;
+    const double *path;             // distance from the ray origin to the hit (null: 0)
     const double *nx, *ny, *nz;
     unsigned long long seed;
     int event;
@@ -1245,9 +1248,10 @@ __global__ __launch_bounds__(256) void k_optics_apply(OpticsParams P) {
     if (i >= P.n) return;
     trc_ray_out out[2];
     unsigned long long rid = P.rid ? P.rid[i] : (P.ray_offset + (unsigned long long)i);
+    const double path = P.path ? P.path[i] : 0.0;
     int n_out = trc_shade(trc_rec_opt_kind(P.rec), P.opt, P.extra, trc_rec_extra_off(P.rec),
                           trc_rec_extra_len(P.rec), P.rec[2], P.rec[5], P.rec[8], P.dx[i], P.dy[i], P.dz[i],
-                          P.e[i], P.ref ? P.ref[i] : 1.0, P.wl ? P.wl[i] : 0.0, P.nx[i], P.ny[i], P.nz[i], P.seed,
+                          P.e[i], P.ref ? P.ref[i] : 1.0, P.wl ? P.wl[i] : 0.0, path, P.nx[i], P.ny[i], P.nz[i], P.seed,
                           rid, (uint32_t)P.event, out);
     for (int c = 0; c < 2; ++c) {
         long long slot = c == 0 ? i : P.n + i;
@@ -2495,6 +2499,7 @@ extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int3
     double *d_rec = nullptr, *d_opt = nullptr, *d_extra = nullptr;
     double *d_in[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // dx dy dz e ref wl nx ny nz
     uint64_t *d_rid = nullptr;
+    double *d_path = nullptr;
     double *d_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int32_t *d_blk = nullptr;
     int st = TRC_OK;
@@ -2507,6 +2512,15 @@ extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int3
             if (hipMemcpy(d_in[i], src[i], (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
         }
         if (st) break;
+        if (in->x && in->y && in->z) {      // path lengths for the attenuating optics (Absorbant.attenuate, :874-877)
+            std::vector<double> path((size_t)n);
+            for (int64_t i = 0; i < n; ++i) {
+                double ax = hx[i] - in->x[i], ay = hy[i] - in->y[i], az = hz[i] - in->z[i];
+                path[(size_t)i] = std::sqrt(ax * ax + ay * ay + az * az);
+            }
+            if ((st = dev_alloc(&d_path, (size_t)n))) break;
+            if (hipMemcpy(d_path, path.data(), (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        }
         if (in->rid) {
             if ((st = dev_alloc(&d_rid, (size_t)n))) break;
             if (hipMemcpy(d_rid, in->rid, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
@@ -2519,7 +2533,7 @@ extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int3
         P.rec = d_rec; P.opt = d_opt; P.extra = d_extra; P.n = n;
         P.dx = d_in[0]; P.dy = d_in[1]; P.dz = d_in[2]; P.e = d_in[3]; P.ref = d_in[4]; P.wl = d_in[5];
         P.rid = d_rid; P.ray_offset = 0;
-        P.nx = d_in[6]; P.ny = d_in[7]; P.nz = d_in[8];
+        P.nx = d_in[6]; P.ny = d_in[7]; P.nz = d_in[8]; P.path = d_path;
         P.seed = seed; P.event = bounce;
         P.odx = d_out[0]; P.ody = d_out[1]; P.odz = d_out[2]; P.oe = d_out[3]; P.oref = d_out[4]; P.oblk = d_blk;
         hipLaunchKernelGGL(k_optics_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, P);
@@ -2549,7 +2563,7 @@ extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int3
             }
         out->n = m;
     } while (0);
-    dev_free(d_rec); dev_free(d_opt); dev_free(d_extra); dev_free(d_rid); dev_free(d_blk);
+    dev_free(d_rec); dev_free(d_opt); dev_free(d_extra); dev_free(d_rid); dev_free(d_blk); dev_free(d_path);
     for (int i = 0; i < 9; ++i) dev_free(d_in[i]);
     for (int i = 0; i < 5; ++i) dev_free(d_out[i]);
     return st;

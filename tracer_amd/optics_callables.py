@@ -60,7 +60,8 @@ class NativeOptics(object):
         nrm = _cabi.f64(geometry.get_normals())
         hit = _cabi.f64(geometry.get_intersection_points_global())
         rid = N.arange(n, dtype=N.uint64)
-        rin = _cabi.make_rays(n, dx=d[0], dy=d[1], dz=d[2], e=e, ref_index=ri, wavelength=wl, rid=rid)
+        org = _cabi.f64(rays.get_vertices(selector))          # origins: path lengths of the attenuating optics
+        rin = _cabi.make_rays(n, org[0], org[1], org[2], dx=d[0], dy=d[1], dz=d[2], e=e, ref_index=ri, wavelength=wl, rid=rid)
         m = 2 * n
         o = dict((k, N.empty(m)) for k in ('x', 'y', 'z', 'dx', 'dy', 'dz', 'e', 'ref', 'wl'))
         par = N.empty(m, dtype=N.int64)
@@ -133,6 +134,22 @@ class Lambertian(NativeOptics):
 
     def _native(self):
         return _cabi.OPT_LAMBERTIAN, [self._abs, self._ang_range], []
+
+
+class LambertianAbsorbant(Lambertian):
+    """
+    Opaque Lambertian wall at the boundary of an absorbing volume (optics_callables.py:891-906 on Absorbant.attenuate
+    :874-889): the ray is attenuated by exp(-attenuation_coefficient * path * scaling) over the distance it travelled to the
+    wall, then loses `absorptivity` of what is left.
+    """
+    def __init__(self, absorptivity=0., attenuation_coefficient=0., ang_range=N.pi / 2., scaling=1.):
+        Lambertian.__init__(self, absorptivity, ang_range)
+        self.a_c = float(N.ravel(attenuation_coefficient)[0])
+        self._scaling = scaling
+
+    def _native(self):
+        kind, params, extra = Lambertian._native(self)
+        return kind, list(params[:2]) + [self.a_c, self._scaling], extra
 
 
 class LambertianSpecular(NativeOptics):
@@ -253,6 +270,37 @@ class RefractiveHomogenous(NativeOptics):
         return _cabi.OPT_REFRACTIVE_HOMOGENOUS, [self._ref_idxs[0], self._ref_idxs[1],
                                                  1. if self._single_ray else 0.,
                                                  -1. if self._sigma is None else self._sigma], []
+
+
+class RefractiveTransmissiveHomogenous(RefractiveHomogenous):
+    """
+    RefractiveHomogenous with Beer-Lambert attenuation in the media (optics_callables.py:1326-1348 on Absorbant.attenuate
+    :874-889): a ray arriving through the medium of index n1 is attenuated by exp(-attenuation_coefficients[0] * path * scaling),
+    through n2 by attenuation_coefficients[1] (a single coefficient applies to both), before it is reflected / refracted.
+    """
+    def __init__(self, n1, n2, attenuation_coefficients, single_ray=True, sigma=None, scaling=1.):
+        RefractiveHomogenous.__init__(self, n1, n2, single_ray, sigma)
+        a_c = N.ravel(N.array(attenuation_coefficients, dtype=float))
+        if len(a_c) not in (1, 2):
+            raise ValueError('one attenuation coefficient, or one per medium')
+        self.a_c = a_c
+        self._scaling = scaling
+
+    def _native(self):
+        kind, params, extra = RefractiveHomogenous._native(self)
+        return kind, list(params) + [self.a_c[0], self.a_c[-1], self._scaling, 1.], extra
+
+
+class RefractiveAbsorbantHomogenous(RefractiveTransmissiveHomogenous):
+    """
+    optics_callables.py:1298-1324.  The reference keeps the coefficients only when both are None (:1313-1316, and then
+    attenuates with the imaginary part of a complex refractive index, which the device rays do not carry); given
+    coefficients are what its docstring describes, and what is done here.
+    """
+    def __init__(self, m1, m2, single_ray=True, sigma=None, attenuation_coefficient_1=None, attenuation_coefficient_2=None, scaling=1.):
+        if attenuation_coefficient_1 is None or attenuation_coefficient_2 is None:
+            raise NotImplementedError('attenuation from complex refractive indices is outside the native path: give both coefficients')
+        RefractiveTransmissiveHomogenous.__init__(self, m1, m2, [attenuation_coefficient_1, attenuation_coefficient_2], single_ray, sigma, scaling)
 
 
 # --------------------------------------------------------------------------------------------------
