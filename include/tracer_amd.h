@@ -82,12 +82,12 @@ typedef enum trc_gm_kind {
 /* ---- optics callables (reference: tracer/optics_callables.py) -------------- */
 typedef enum trc_optics_kind {
     TRC_OPT_TRANSPARENT = 0,            /* Transparent             :93-113   */
-    TRC_OPT_REFLECTIVE = 1,             /* Reflective              :116-140   opt: absorptivity */
+    TRC_OPT_REFLECTIVE = 1,             /* Reflective              :116-140   opt: absorptivity ; Reflective_IAM :283-300 adds a_r (0: none), c */
     TRC_OPT_ONE_SIDED_REFLECTIVE = 2,   /* OneSidedReflective      :195-212   opt: absorptivity */
-    TRC_OPT_REAL_REFLECTIVE = 3,        /* RealReflective          :214-269   opt: absorptivity,sigma,bi_var */
+    TRC_OPT_REAL_REFLECTIVE = 3,        /* RealReflective          :214-269   opt: absorptivity,sigma,bi_var ; RealReflective_IAM :320-329 adds a_r, c */
     TRC_OPT_ONE_SIDED_REAL_REFLECTIVE = 4, /* OneSidedRealReflective :492-504 opt: absorptivity,sigma,bi_var */
     TRC_OPT_LAMBERTIAN = 5,             /* Lambertian              :143-176   opt: absorptivity,ang_range ; LambertianAbsorbant
-                                           :891-906 adds attenuation_coefficient (0: none), scaling */
+                                           :891-906 adds attenuation_coefficient (0: none), scaling ; Lambertian_IAM :302-318 then a_r (0: none), c */
     TRC_OPT_LAMBERTIAN_SPECULAR = 6,    /* LambertianSpecular      :553-585   opt: absorptivity,specularity */
     TRC_OPT_REFRACTIVE_HOMOGENOUS = 7,  /* RefractiveHomogenous    :1186-1296 opt: n1,n2,single_ray,sigma(<0:none) ;
                                            RefractiveTransmissiveHomogenous :1326-1348 adds a_c in n1, a_c in n2, scaling, 1 */

@@ -123,6 +123,15 @@ def fresnel_to_attenuating(n1, m2, theta1):
     return R_p, R_s, theta2
 
 
+def iam(opt, ia, ic, d, nrm):
+    """IAM.__call__ (optics_callables.py:276-281) as a factor on e (1 - abs); a_r = opt[ia] (0 or absent: 1), c = opt[ic]"""
+    if len(opt) <= ic or opt[ia] == 0.:
+        return 1.
+    vertical = N.sum(d * nrm, axis=0) * nrm
+    cos_aoi = N.sqrt(N.sum(vertical ** 2, axis=0))
+    return (1. - N.exp(-cos_aoi ** opt[ic] / opt[ia])) / (1. - N.exp(-1. / opt[ia]))
+
+
 def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event, path=None):
     """
     One optics call on H hits.  Returns a list of blocks (reflected block first, refracted second), each a dict
@@ -134,7 +143,7 @@ def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event, path=N
     if opt_kind == OPT_TRANSPARENT:                              # optics_callables.py:106-113
         return [dict(sel=allsel, directions=d.copy(), energy=e.copy(), ref=ref.copy(), rid=rid)]
     if opt_kind in (OPT_REFLECTIVE, OPT_ONE_SIDED_REFLECTIVE):   # :130-140, :201-212
-        eo = e * (1. - opt[0])
+        eo = e * (1. - opt[0]) * iam(opt, 1, 2, d, nrm)
         if opt_kind == OPT_ONE_SIDED_REFLECTIVE:
             eo = eo.copy()
             eo[N.sum(d * up[:, None], axis=0) > 0] = 0
@@ -151,7 +160,7 @@ def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event, path=N
             g0, g1 = philox.normal_pair(u0, u1)
             u2 = philox.uniform_pair(seed, rid, event, 1)[0] if not bi else N.zeros(H)
             real = slope_error_normals(nrm, sigma, bi, g0, g1, u2)
-        eo = e * (1 - opt[0])
+        eo = e * (1 - opt[0]) * iam(opt, 3, 4, d, nrm)
         if opt_kind == OPT_ONE_SIDED_REAL_REFLECTIVE:
             eo = eo.copy()
             eo[N.sum(d * up[:, None], axis=0) > 0] = 0
@@ -159,7 +168,7 @@ def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event, path=N
     if opt_kind == OPT_LAMBERTIAN:                               # :154-176
         u0, u1 = philox.uniform_pair(seed, rid, event, 0)
         dirs = lambertian_directions(nrm, 2. * N.pi * u0, u1, opt[1])
-        eo = e * (1. - opt[0])
+        eo = e * (1. - opt[0]) * iam(opt, 4, 5, d, nrm)
         if len(opt) > 2 and opt[2] != 0.:                        # LambertianAbsorbant :898-906: attenuate, then absorb
             eo = e * N.exp(-opt[2] * (path * opt[3])) * (1. - opt[0])
         return [dict(sel=allsel, directions=dirs, energy=eo, ref=ref.copy(), rid=rid)]

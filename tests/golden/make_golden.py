@@ -291,6 +291,14 @@ def make_optics(ref, amd, out):
     run('lambertian_narrow', oc.Lambertian(0.3, 0.4), A.Lambertian(0.3, 0.4),
         draws=lambda: dict(xi1=N.random.uniform(low=0., high=2. * N.pi, size=H), xi2=N.random.uniform(size=H)))
 
+    # Incidence Angle Modifier (IAM, :271-281) on the two siblings that run in the reference
+    run('lambertian_iam', oc.Lambertian_IAM(0.3, 0.16), A.Lambertian_IAM(0.3, 0.16),
+        draws=lambda: dict(xi1=N.random.uniform(low=0., high=2. * N.pi, size=H), xi2=N.random.uniform(size=H)))
+    run('lambertian_iam_c2', oc.Lambertian_IAM(0.1, 0.3, 2), A.Lambertian_IAM(0.1, 0.3, 2),
+        draws=lambda: dict(xi1=N.random.uniform(low=0., high=2. * N.pi, size=H), xi2=N.random.uniform(size=H)))
+    run('real_reflective_iam', oc.RealReflective_IAM(0.05, 0.2, 2e-3, True), A.RealReflective_IAM(0.05, 0.2, 2e-3, True),
+        draws=lambda: dict(g0=N.random.normal(scale=2e-3, size=H), g1=N.random.normal(scale=2e-3, size=H)))
+
     def ls_draws():
         u = N.random.rand(H)
         k = int(N.sum(~(u < 0.4)))

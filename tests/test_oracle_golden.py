@@ -71,22 +71,25 @@ def test_optics_variate_replay():
         assert N.allclose(o[pre + 'out_vertices'], pts[:, par], **TOL)
     # slope error: replay numpy's normal / uniform draws
     for name, bi, onesided in (('real_reflective_bivar', True, False), ('real_reflective_radial', False, False),
-                               ('one_sided_real_reflective', True, True)):
+                               ('one_sided_real_reflective', True, True), ('real_reflective_iam', True, False)):
         pre = _optics_case(o, name)
         absorb, sigma = o[pre + 'opt'][0], o[pre + 'opt'][1]
         g0 = o[pre + 'draw_g0'] / sigma
         g1 = o[pre + 'draw_g1'] / sigma if bi else N.zeros(H)
         u = o[pre + 'draw_phi'] / (2. * N.pi) if not bi else N.zeros(H)
         real = optics.slope_error_normals(nrm, sigma, bi, g0, g1, u)
-        en = e * (1. - absorb)
+        en = e * (1. - absorb) * optics.iam(list(o[pre + 'opt']), 3, 4, d, nrm)
         if onesided:
             en = en.copy()
             en[N.sum(d * up[:, None], axis=0) > 0] = 0
         check(pre, optics.reflections(d, real), en, N.arange(H))
-    for name in ('lambertian', 'lambertian_narrow'):
+    for name in ('lambertian', 'lambertian_narrow', 'lambertian_iam', 'lambertian_iam_c2'):
         pre = _optics_case(o, name)
         dirs = optics.lambertian_directions(nrm, o[pre + 'draw_xi1'], o[pre + 'draw_xi2'], o[pre + 'opt'][1])
-        check(pre, dirs, e * (1. - o[pre + 'opt'][0]), N.arange(H))
+        check(pre, dirs, e * (1. - o[pre + 'opt'][0]) * optics.iam(list(o[pre + 'opt']), 4, 5, d, nrm), N.arange(H))
+        if 'iam' in name:
+            f = optics.iam(list(o[pre + 'opt']), 4, 5, d, nrm)
+            assert f.min() < 0.5 and f.max() > 0.95
     # attenuating media (Absorbant.attenuate): energies are deterministic, the Lambertian wall replays its direction draws
     for name in ('lambertian_absorbant', 'lambertian_absorbant_scaled'):
         pre = _optics_case(o, name)

@@ -1063,6 +1063,16 @@ TRC_HD double trc_fresnel_conductor(double cos_abs, double n1, double n2, double
 //   opt_kind / opt[8]: trc_surface_desc;  (ux,uy,uz): GeometryManager.up() = frame z axis;
 //   (dx..), e, ref, wl: incident ray;  (nx..): oriented normal from trc_normal.
 // Returns the number of outgoing rays (1 or 2) in out[].
+// Incidence Angle Modifier of Martin and Ruiz (optics_callables.py:271-281): the reflected fraction (1 - absorptivity) is
+// scaled by (1 - exp(-cos(theta)^c / a_r)) / (1 - exp(-1 / a_r)), theta the angle of incidence.  a_r == 0: no modifier.
+TRC_HD double trc_iam(double a_r, double c, double dx, double dy, double dz, double nx, double ny, double nz) {
+    if (a_r == 0.0) return 1.0;
+    double dn = dx * nx + dy * ny + dz * nz;
+    double wx = dn * nx, wy = dn * ny, wz = dn * nz;
+    double cos_aoi = sqrt(wx * wx + wy * wy + wz * wz);
+    return (1.0 - exp(-pow(cos_aoi, c) / a_r)) / (1.0 - exp(-1.0 / a_r));
+}
+
 TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int extra_off, int extra_len,
                      double ux, double uy, double uz, double dx, double dy, double dz, double e, double ref,
                      double wl, double path, double nx, double ny, double nz, uint64_t seed, uint64_t rid,
@@ -1078,7 +1088,7 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
     case TRC_OPT_REFLECTIVE:
     case TRC_OPT_ONE_SIDED_REFLECTIVE: {                            // :130-140, :201-212
         trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);
-        double eo = e * (1.0 - opt[0]);
+        double eo = e * (1.0 - opt[0]) * trc_iam(opt[1], opt[2], dx, dy, dz, nx, ny, nz);       // Reflective_IAM :283-300
         if (opt_kind == TRC_OPT_ONE_SIDED_REFLECTIVE && (dx * ux + dy * uy + dz * uz) > 0.0) eo = 0.0;
         out[0].e = eo;
         return 1;
@@ -1106,7 +1116,7 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
             rx *= inv; ry *= inv; rz *= inv;
         }
         trc_reflect(dx, dy, dz, rx, ry, rz, &out[0].dx, &out[0].dy, &out[0].dz);
-        double eo = e * (1.0 - opt[0]);
+        double eo = e * (1.0 - opt[0]) * trc_iam(opt[3], opt[4], dx, dy, dz, nx, ny, nz);       // RealReflective_IAM :320-329 (ideal normal)
         if (opt_kind == TRC_OPT_ONE_SIDED_REAL_REFLECTIVE && (dx * ux + dy * uy + dz * uz) > 0.0) eo = 0.0;
         out[0].e = eo;
         return 1;
@@ -1117,7 +1127,7 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
         trc_pillbox_dir(TRC_TWO_PI * u0, u1, opt[1], &ax, &ay, &az);
         trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
         if (opt[2] != 0.0) out[0].e = e * exp(-opt[2] * (path * opt[3])) * (1.0 - opt[0]);      // LambertianAbsorbant :895-906
-        else out[0].e = e * (1.0 - opt[0]);
+        else out[0].e = e * (1.0 - opt[0]) * trc_iam(opt[4], opt[5], dx, dy, dz, nx, ny, nz);  // Lambertian_IAM :302-318
         return 1;
     }
     case TRC_OPT_SEMI_LAMBERTIAN: {                                 // :514-531 as documented (:507-509)

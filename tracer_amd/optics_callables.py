@@ -120,6 +120,18 @@ class RealReflective(NativeOptics):
         return _cabi.OPT_REAL_REFLECTIVE, [self._abs, self._sig, 1. if self.bi_var == True else 0.], []
 
 
+class RealReflective_IAM(RealReflective):
+    """RealReflective with the Incidence Angle Modifier on its reflected fraction, evaluated on the ideal normal
+    (optics_callables.py:320-329; c = 1)."""
+    def __init__(self, absorptivity, a_r, sigma, bi_var=False):
+        RealReflective.__init__(self, absorptivity, sigma, bi_var)
+        self.a_r, self.c = a_r, 1
+
+    def _native(self):
+        kind, params, extra = RealReflective._native(self)
+        return kind, list(params) + [self.a_r, self.c], extra
+
+
 class OneSidedRealReflective(RealReflective):
     """One-sided version of RealReflective (optics_callables.py:492-504)."""
     def _native(self):
@@ -134,6 +146,31 @@ class Lambertian(NativeOptics):
 
     def _native(self):
         return _cabi.OPT_LAMBERTIAN, [self._abs, self._ang_range], []
+
+
+class Reflective_IAM(Reflective):
+    """
+    Specular mirror whose reflected fraction follows the Incidence Angle Modifier of Martin and Ruiz
+    (optics_callables.py:271-300): E (1 - absorptivity) (1 - exp(-cos(theta)^c / a_r)) / (1 - exp(-1 / a_r)).  (The
+    reference's __call__ constructs a Reflective instead of calling it, :295; its Lambertian and RealReflective siblings
+    run, and this class does what they do.)
+    """
+    def __init__(self, absorptivity, a_r, c=1):
+        Reflective.__init__(self, absorptivity)
+        self.a_r, self.c = a_r, c
+
+    def _native(self):
+        return _cabi.OPT_REFLECTIVE, [self._abs, self.a_r, self.c], []
+
+
+class Lambertian_IAM(Lambertian):
+    """Lambertian reflector with the Incidence Angle Modifier on its reflected fraction (optics_callables.py:302-318)."""
+    def __init__(self, absorptivity, a_r, c=1):
+        Lambertian.__init__(self, absorptivity)
+        self.a_r, self.c = a_r, c
+
+    def _native(self):
+        return _cabi.OPT_LAMBERTIAN, [self._abs, self._ang_range, 0., 0., self.a_r, self.c], []
 
 
 class LambertianAbsorbant(Lambertian):
