@@ -93,7 +93,9 @@ typedef enum trc_optics_kind {
                                            RefractiveTransmissiveHomogenous :1326-1348 adds a_c in n1, a_c in n2, scaling, 1 */
     TRC_OPT_REFLECTIVE_SPECTRAL = 8,    /* Reflective_spectral     :178-193   extra: lambda[n] | absorptance[n] */
     TRC_OPT_LAMBERTIAN_DIRECTIONAL = 9, /* Lambertian_directional_axisymmetric_piecewise :331-361
-                                           extra: theta[n] | absorptance[n] */
+                                           extra: theta[n] | absorptance[n] ; opt[0] = 1: specular with probability opt[1]
+                                           (LambertianSpecular_directional_... :427-455); opt[0] = 2: with probability
+                                           extra[2n..3n) on the same angles (Lambertian_piecewise_Specular_... :457-487) */
     TRC_OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL = 10, /* ..._piecewise_spectral :363-391
                                            extra: n_theta, n_lambda, theta[], lambda[], absorptance[n_theta][n_lambda] */
     TRC_OPT_FRESNEL_CONDUCTOR = 11,     /* FresnelConductorHomogenous :1523-1558  opt: n1 ; extra: lambda[n] | n[n] | k[n] */

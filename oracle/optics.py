@@ -195,9 +195,10 @@ def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event, path=N
     if opt_kind in (OPT_LAMBERTIAN_DIRECTIONAL, OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL):   # :340-361, :373-391
         vertical = N.sum(d * nrm, axis=0) * nrm
         thetas_in = N.arccos(N.sqrt(N.sum(vertical ** 2, axis=0)))
+        mode = int(opt[0]) if (opt_kind == OPT_LAMBERTIAN_DIRECTIONAL and len(opt)) else 0
         if opt_kind == OPT_LAMBERTIAN_DIRECTIONAL:
-            k = len(extra) // 2
-            ang_abss = N.interp(thetas_in, extra[:k], extra[k:])
+            k = len(extra) // (3 if mode == 2 else 2)
+            ang_abss = N.interp(thetas_in, extra[:k], extra[k:2 * k])
         else:
             from scipy.interpolate import RegularGridInterpolator
             nt, nl = int(extra[0]), int(extra[1])
@@ -206,7 +207,15 @@ def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event, path=N
             pts = N.array([N.clip(thetas_in, ts[0], ts[-1]), N.clip(wl, ls[0], ls[-1])]).T
             ang_abss = RegularGridInterpolator((ts, ls), grid)(pts)
         u0, u1 = philox.uniform_pair(seed, rid, event, 0)
-        dirs = lambertian_directions(nrm, 2. * N.pi * u0, u1, N.pi / 2.)
+        if mode == 0:
+            dirs = lambertian_directions(nrm, 2. * N.pi * u0, u1, N.pi / 2.)
+        else:       # :427-455 constant specularity, :457-487 specularity interpolated on the incidence angle
+            spec = opt[1] if mode == 1 else N.interp(thetas_in, extra[:k], extra[2 * k:])
+            u2, _ = philox.uniform_pair(seed, rid, event, 1)
+            sp = u0 < spec
+            dirs = N.zeros(d.shape)
+            dirs[:, sp] = reflections(d[:, sp], nrm[:, sp])
+            dirs[:, ~sp] = lambertian_directions(nrm[:, ~sp], 2. * N.pi * u1[~sp], u2[~sp], N.pi / 2.)
         return [dict(sel=allsel, directions=dirs, energy=e * (1. - ang_abss), ref=ref.copy(), rid=rid)]
     if opt_kind == OPT_FRESNEL_CONDUCTOR:                        # :1536-1558 with optics.py:41-81
         k = len(extra) // 3

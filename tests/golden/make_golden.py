@@ -331,6 +331,20 @@ def make_optics(ref, amd, out):
     abth = N.array([0.9, 0.88, 0.85, 0.8, 0.7, 0.5, 0.1])
     run('lambertian_directional', oc.Lambertian_directional_axisymmetric_piecewise(ths, abth), A.Lambertian_directional_axisymmetric_piecewise(ths, abth),
         draws=lambda: dict(xi1=N.random.uniform(low=0., high=2. * N.pi, size=H), xi2=N.random.uniform(size=H)))
+    spth = N.array([0.05, 0.1, 0.2, 0.35, 0.5, 0.7, 0.95])
+
+    def spec_draws(prob):
+        def f():
+            u = N.random.rand(H)
+            k = int(N.sum(~(u < prob())))
+            return dict(u=u, xi1=N.random.uniform(low=0., high=2. * N.pi, size=k), xi2=N.random.uniform(size=k))
+        return f
+    th_in = N.arccos(N.abs(N.sum(d * nrm, axis=0)))
+    run('lambertian_specular_directional', oc.LambertianSpecular_directional_axisymmetric_piecewise(ths, abth, 0.35),
+        A.LambertianSpecular_directional_axisymmetric_piecewise(ths, abth, 0.35), draws=spec_draws(lambda: 0.35))
+    run('lambertian_piecewise_specular_directional', oc.Lambertian_piecewise_Specular_directional_axisymmetric_piecewise(ths, abth, spth),
+        A.Lambertian_piecewise_Specular_directional_axisymmetric_piecewise(ths, abth, spth),
+        draws=spec_draws(lambda: N.interp(th_in, ths, spth)))
     wls = N.linspace(0.25e-6, 2.6e-6, 5)
     grid = 0.2 + 0.7 * N.outer(N.cos(ths) ** 0.5, 1. / (1. + (wls * 1e6 - 1.) ** 2))
     run('lambertian_directional_spectral', oc.Lambertian_directional_axisymmetric_piecewise_spectral(ths, grid, wls),

@@ -110,6 +110,22 @@ def test_optics_variate_replay():
         blocks = optics.shade(int(o[pre + 'kind']), list(o[pre + 'opt']), o[pre + 'extra'], up, d, e, o[pre + 'ref_in'], wl, nrm, 1, rid, 1)
         dirs = optics.lambertian_directions(nrm, o[pre + 'draw_xi1'], o[pre + 'draw_xi2'], N.pi / 2.)
         check(pre, dirs, blocks[0]['energy'], N.arange(H))
+    # specular with a constant / an angle-dependent probability on top of the angle-dependent absorptance: replay the draws
+    for name in ('lambertian_specular_directional', 'lambertian_piecewise_specular_directional'):
+        pre = _optics_case(o, name)
+        opt_p, ex = list(o[pre + 'opt']), o[pre + 'extra']
+        th_in = N.arccos(N.sqrt(N.sum((N.sum(d * nrm, axis=0) * nrm) ** 2, axis=0)))
+        k = len(ex) // (3 if int(opt_p[0]) == 2 else 2)
+        prob = opt_p[1] if int(opt_p[0]) == 1 else N.interp(th_in, ex[:k], ex[2 * k:])
+        spec = o[pre + 'draw_u'] < prob
+        dirs = N.zeros((3, H))
+        dirs[:, spec] = optics.reflections(d[:, spec], nrm[:, spec])
+        dirs[:, ~spec] = optics.lambertian_directions(nrm[:, ~spec], o[pre + 'draw_xi1'], o[pre + 'draw_xi2'], N.pi / 2.)
+        check(pre, dirs, e * (1. - N.interp(th_in, ex[:k], ex[k:2 * k])), N.arange(H))
+        assert spec.any() and (~spec).any()
+        # and shade() itself draws the same decision from its own uniforms: energies are deterministic
+        blocks = optics.shade(int(o[pre + 'kind']), opt_p, ex, up, d, e, o[pre + 'ref_in'], wl, nrm, 1, rid, 1)
+        assert N.allclose(blocks[0]['energy'], o[pre + 'out_energy'], **TOL)
     pre = _optics_case(o, 'lambertian_specular')
     spec = o[pre + 'draw_u'] < o[pre + 'opt'][1]
     dirs = N.zeros((3, H))

@@ -999,8 +999,9 @@ TRC_HD double trc_fresnel(double cos_abs, double n1, double n2) {
 }
 
 // N.interp: piecewise linear with clamped ends; table = n x then n y
-TRC_HD double trc_interp(const double *tab, int n, double x) {
-    const double *xs = tab, *ys = tab + n;
+TRC_HD double trc_interp_xy(const double *xs, const double *ys, int n, double x);
+TRC_HD double trc_interp(const double *tab, int n, double x) { return trc_interp_xy(tab, tab + n, n, x); }
+TRC_HD double trc_interp_xy(const double *xs, const double *ys, int n, double x) {
     if (!(x > xs[0])) return ys[0];
     if (x >= xs[n - 1]) return ys[n - 1];
     int lo = 0, hi = n - 1;
@@ -1165,12 +1166,29 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
         double dn = dx * nx + dy * ny + dz * nz;
         double wx = dn * nx, wy = dn * ny, wz = dn * nz;             // "vertical" component of the incident direction
         double th = acos(sqrt(wx * wx + wy * wy + wz * wz));
-        double ab = (opt_kind == TRC_OPT_LAMBERTIAN_DIRECTIONAL) ? trc_interp(extra + extra_off, extra_len / 2, th)
+        // opt[0]: 0 Lambertian; 1 specular with probability opt[1] (LambertianSpecular_directional_..., :427-455); 2 with a
+        // probability tabulated on the incidence angle too, third column of the table (Lambertian_piecewise_Specular_..., :457-487)
+        const int mode = (opt_kind == TRC_OPT_LAMBERTIAN_DIRECTIONAL) ? (int)opt[0] : 0;
+        const int ncol = mode == 2 ? 3 : 2;
+        double ab = (opt_kind == TRC_OPT_LAMBERTIAN_DIRECTIONAL) ? trc_interp(extra + extra_off, extra_len / ncol, th)
                                                                   : trc_interp2(extra + extra_off, th, wl);
         double u0, u1, ax, ay, az;
         trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
-        trc_pillbox_dir(TRC_TWO_PI * u0, u1, 1.57079632679489661923, &ax, &ay, &az);
-        trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
+        if (mode == 0) {
+            trc_pillbox_dir(TRC_TWO_PI * u0, u1, 1.57079632679489661923, &ax, &ay, &az);
+            trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
+        } else {
+            const int n = extra_len / ncol;
+            const double spec = mode == 1 ? opt[1] : trc_interp_xy(extra + extra_off, extra + extra_off + 2 * n, n, th);
+            if (u0 < spec) {
+                trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);
+            } else {
+                double u2, u3;
+                trc_uniform_pair(seed, rid, event, 1, &u2, &u3);
+                trc_pillbox_dir(TRC_TWO_PI * u1, u2, 1.57079632679489661923, &ax, &ay, &az);
+                trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
+            }
+        }
         out[0].e = e * (1.0 - ab);
         return 1;
     }

@@ -239,6 +239,29 @@ class Lambertian_directional_axisymmetric_piecewise(NativeOptics):
         return _cabi.OPT_LAMBERTIAN_DIRECTIONAL, [], N.concatenate((th, ab)).tolist()
 
 
+class LambertianSpecular_directional_axisymmetric_piecewise(Lambertian_directional_axisymmetric_piecewise):
+    """Angle-dependent absorptance as above; each ray is mirrored with probability `specularity`, else scattered
+    (optics_callables.py:427-455)."""
+    def _native(self):
+        kind, params, extra = Lambertian_directional_axisymmetric_piecewise._native(self)
+        return kind, [1., float(self.specularity)], extra
+
+
+class Lambertian_piecewise_Specular_directional_axisymmetric_piecewise(NativeOptics):
+    """Angle-dependent absorptance and angle-dependent probability of a specular reflection, both piecewise linear on the
+    incidence angle (optics_callables.py:457-487)."""
+    def __init__(self, thetas, absorptance_th, specularity_th):
+        self.thetas = thetas
+        self.abs_th = absorptance_th
+        self.spec_th = specularity_th
+
+    def _native(self):
+        cols = [N.ravel(N.asarray(c, dtype=float)) for c in (self.thetas, self.abs_th, self.spec_th)]
+        if not (len(cols[0]) == len(cols[1]) == len(cols[2])):
+            raise ValueError('thetas, absorptance_th and specularity_th must have the same length')
+        return _cabi.OPT_LAMBERTIAN_DIRECTIONAL, [2.], N.concatenate(cols).tolist()
+
+
 class Lambertian_directional_axisymmetric_piecewise_spectral(NativeOptics):
     """Same with absorptance tabulated on (incidence angle, wavelength), bilinear (optics_callables.py:363-391).
     Arguments outside the table are clamped to its edge (the reference's RegularGridInterpolator raises)."""
