@@ -555,3 +555,39 @@ def test_attenuating_media_in_the_engines():
     ref1 = oeng.trace_bundle(compile_scene(asm1), pos, dirs, en, 1000, 1e-9 / n, 4, ref_index=N.ones(n))
     assert N.array_equal(h1, ref1['hits']) and N.allclose(a1, ref1['absorbed'], rtol=1e-9, atol=1e-15)
     assert abs(a1[2] - series) < 5. * N.sqrt(series * (1. - series) / n)
+
+
+def test_bifacial_and_periodic_boundary_plugins():
+    """
+    BiFacial (optics_callables.py:1877-1926) and PeriodicBoundary (:690-723), host compositions that run under the protocol
+    engine: a plate that mirrors from above and absorbs 40 % from below, between two mirrors; and a periodic face that moves
+    the rays one period along its normal with their direction and energy.
+    """
+    plate = Surface(RectPlateGM(4., 4.), opt.BiFacial(opt.Reflective(0.), opt.Reflective(0.4)))
+    above = Surface(RectPlateGM(4., 4.), opt.ReflectiveReceiver(1.), location=N.r_[0., 0., 1.], rotation=rotx(N.pi)[:3, :3])
+    below = Surface(RectPlateGM(4., 4.), opt.ReflectiveReceiver(1.), location=N.r_[0., 0., -1.])
+    asm = Assembly(objects=[AssembledObject(surfs=[plate]), AssembledObject(surfs=[above]), AssembledObject(surfs=[below])])
+    pos = N.c_[[0.1, 0., 0.5], [-0.2, 0.3, 0.5], [0.3, 0.1, -0.5], [0., -0.4, -0.5]]
+    dirs = N.c_[[0., 0., -1.], [0., 0., -1.], [0., 0., 1.], [0., 0., 1.]]
+    eng = TracerEngine(asm)
+    eng.ray_tracer(RayBundle(pos, dirs, energy=N.ones(4)), reps=3, min_energy=1e-9, tree=True)
+    e_up, h_up = above.get_optics_manager().get_all_hits()
+    e_dn, h_dn = below.get_optics_manager().get_all_hits()
+    assert N.allclose(N.sort(e_up), [1., 1.]) and N.allclose(N.sort(e_dn), [0.6, 0.6])
+    assert N.allclose(N.sort(h_up[0]), [-0.2, 0.1]) and N.allclose(N.sort(h_dn[1]), [-0.4, 0.1])
+
+    face = Surface(RectPlateGM(4., 4.), opt.PeriodicBoundary(2.5))
+    target = Surface(RectPlateGM(6., 6.), opt.ReflectiveReceiver(1.), location=N.r_[0., 0., -1.5])
+    asm = Assembly(objects=[AssembledObject(surfs=[face]), AssembledObject(surfs=[target])])
+    d = N.c_[[0.3, 0., 1.], [0., -0.2, 1.]]
+    d /= N.sqrt(N.sum(d ** 2, axis=0))
+    start = N.c_[[0., 0., -1.], [0.5, 0.5, -1.]]
+    eng = TracerEngine(asm)
+    eng.ray_tracer(RayBundle(start, d, energy=N.r_[2., 3.]), reps=3, min_energy=1e-9, tree=True)
+    e, h = target.get_optics_manager().get_all_hits()
+    # flight: 1 in z up to the face, a jump of one period along the normal that faces the ray (back to z = -2.5, as into the
+    # opposite face of a periodic cell), then 1 more in z up to the target at z = -1.5, which the rays started above
+    expect = start + d / d[2] * 1. + N.c_[[0., 0., -2.5]] + d / d[2] * 1.
+    order = N.argsort(e)
+    assert N.allclose(e[order], [2., 3.]) and N.allclose(h[:, order], expect, atol=1e-9)
+    assert eng.tree._bunds[1].get_num_rays() == 4 and N.allclose(N.sort(eng.tree._bunds[1].get_energy()), [0., 0., 2., 3.])

@@ -364,6 +364,62 @@ class RefractiveAbsorbantHomogenous(RefractiveTransmissiveHomogenous):
 
 
 # --------------------------------------------------------------------------------------------------
+# optics composed on the host.  They are ordinary optics callables of the four-step protocol (their scenes are traced by
+# TracerEngine with engine='protocol', the native surfaces and the optics they wrap still running on the device per call).
+# --------------------------------------------------------------------------------------------------
+class BiFacial(object):
+    """
+    Different optics for rays arriving on the front (+z of the surface) and on the back (optics_callables.py:1877-1926):
+    both callables are run on the selected hits and the outgoing rays of the side each ray arrived on are kept, back side
+    first.
+    """
+    def __init__(self, OpticsCallable_front, OpticsCallable_back):
+        self.OpticsCallable_front = OpticsCallable_front
+        self.OpticsCallable_back = OpticsCallable_back
+
+    def __call__(self, geometry, rays, selector):
+        from .ray_bundle import concatenate_rays
+        proj = N.around(N.sum(rays.get_directions(selector) * geometry.up()[:, None], axis=0), decimals=6)
+        back = proj > 0.
+        parts = []
+        if back.any():
+            parts.append(self.OpticsCallable_back(geometry, rays, selector).inherit(N.nonzero(back)[0]))
+        if not back.all():
+            parts.append(self.OpticsCallable_front(geometry, rays, selector).inherit(N.nonzero(~back)[0]))
+        return concatenate_rays(parts) if len(parts) > 1 else parts[0]
+
+    def get_all_hits(self):
+        def hits_of(side):
+            try:
+                return side.get_all_hits()
+            except Exception:
+                return []
+        return hits_of(self.OpticsCallable_front), hits_of(self.OpticsCallable_back)
+
+    def reset(self):
+        for side in (self.OpticsCallable_front, self.OpticsCallable_back):
+            if hasattr(side, 'reset'):
+                side.reset()
+
+
+class PeriodicBoundary(object):
+    """
+    Periodic boundary condition (optics_callables.py:690-723): a ray that lands on the surface stops there (a zero-energy
+    stub keeps the tree connected) and continues, unchanged, from the hit point translated by `period` along the surface
+    normal.
+    """
+    def __init__(self, period):
+        self.period = period
+
+    def __call__(self, geometry, rays, selector):
+        vertices = geometry.get_intersection_points_global()
+        stopped = rays.inherit(selector, vertices=vertices, energy=N.zeros(len(selector)),
+                               direction=rays.get_directions(selector), parents=selector)
+        moved = rays.inherit(selector, vertices=vertices + self.period * geometry.get_normals(), parents=selector)
+        return stopped + moved
+
+
+# --------------------------------------------------------------------------------------------------
 # accountants (optics_callables.py:1577-1848)
 # --------------------------------------------------------------------------------------------------
 class Accountant(object):
