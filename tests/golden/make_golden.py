@@ -304,6 +304,7 @@ def make_optics(ref, amd, out):
         k = int(N.sum(~(u < 0.4)))
         return dict(u=u, xi1=N.random.uniform(low=0., high=2. * N.pi, size=k), xi2=N.random.uniform(size=k))
     run('lambertian_specular', oc.LambertianSpecular(0.1, 0.4), A.LambertianSpecular(0.1, 0.4), draws=ls_draws)
+    run('lambertian_specular_iam', oc.LambertianSpecular_IAM(0.3, 0.4, 0.16), A.LambertianSpecular_IAM(0.3, 0.4, 0.16), draws=ls_draws)
     n_in = N.where(N.arange(H) % 2 == 0, 1.0, 1.5)
     run('refractive_split', oc.RefractiveHomogenous(1.0, 1.5, single_ray=False), A.RefractiveHomogenous(1.0, 1.5, single_ray=False),
         ref_index=n_in)

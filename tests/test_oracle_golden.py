@@ -126,12 +126,13 @@ def test_optics_variate_replay():
         # and shade() itself draws the same decision from its own uniforms: energies are deterministic
         blocks = optics.shade(int(o[pre + 'kind']), opt_p, ex, up, d, e, o[pre + 'ref_in'], wl, nrm, 1, rid, 1)
         assert N.allclose(blocks[0]['energy'], o[pre + 'out_energy'], **TOL)
-    pre = _optics_case(o, 'lambertian_specular')
-    spec = o[pre + 'draw_u'] < o[pre + 'opt'][1]
-    dirs = N.zeros((3, H))
-    dirs[:, spec] = optics.reflections(d[:, spec], nrm[:, spec])
-    dirs[:, ~spec] = optics.lambertian_directions(nrm[:, ~spec], o[pre + 'draw_xi1'], o[pre + 'draw_xi2'], N.pi / 2.)
-    check(pre, dirs, e * (1. - o[pre + 'opt'][0]), N.arange(H))
+    for name in ('lambertian_specular', 'lambertian_specular_iam'):      # (the _IAM class of the reference absorbs nothing, :607-609)
+        pre = _optics_case(o, name)
+        spec = o[pre + 'draw_u'] < o[pre + 'opt'][1]
+        dirs = N.zeros((3, H))
+        dirs[:, spec] = optics.reflections(d[:, spec], nrm[:, spec])
+        dirs[:, ~spec] = optics.lambertian_directions(nrm[:, ~spec], o[pre + 'draw_xi1'], o[pre + 'draw_xi2'], N.pi / 2.)
+        check(pre, dirs, e * (1. - o[pre + 'opt'][0]), N.arange(H))
     # single-ray refraction: replay the reflect-or-refract draw
     pre = _optics_case(o, 'refractive_single')
     n1 = o[pre + 'ref_in']

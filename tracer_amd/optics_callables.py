@@ -213,6 +213,18 @@ class SemiLambertian(NativeOptics):
         return _cabi.OPT_SEMI_LAMBERTIAN, [self._abs, self._ang_range], []
 
 
+class LambertianSpecular_IAM(LambertianSpecular):
+    """
+    optics_callables.py:588-627.  The reference evaluates its incidence-angle factor on a direction array it has just filled
+    with zeros (:607-609), so cos(theta) = 0 and the outgoing energy is the incident energy whatever the absorptivity: that
+    is what its users get, and what this class gives (a LambertianSpecular that absorbs nothing).
+    """
+    def __init__(self, absorptivity=0., specularity=0.5, a_r=0.16):
+        LambertianSpecular.__init__(self, 0., specularity)
+        self._abs_declared = absorptivity
+        self.a_r = a_r
+
+
 class Reflective_spectral(NativeOptics):
     """Mirror whose absorptance is interpolated on the ray wavelength (optics_callables.py:178-193)."""
     def __init__(self, absorptances, wavelengths):
