@@ -591,3 +591,52 @@ def test_bifacial_and_periodic_boundary_plugins():
     order = N.argsort(e)
     assert N.allclose(e[order], [2., 3.]) and N.allclose(h[:, order], expect, atol=1e-9)
     assert eng.tree._bunds[1].get_num_rays() == 4 and N.allclose(N.sort(eng.tree._bunds[1].get_energy()), [0., 0., 2., 3.])
+
+
+def test_tracer_engine_mp_merges_trees_and_hits():
+    """
+    TracerEngineMP.multi_ray_sim (tracer_engine_mp.py:19-130): three bundles traced "by three processes" = the three bundles
+    traced one after another; the merged tree is their level-by-level concatenation with consistent parents, the receiver's
+    accountant holds the hits of all three.
+    """
+    from tracer_amd.tracer_engine_mp import TracerEngineMP
+    def build():
+        mirror = Surface(RectPlateGM(4., 4.), opt.Reflective(0.1))
+        rec = Surface(RoundPlateGM(3.), opt.ReflectiveReceiver(1.), location=N.r_[0., 0., 2.], rotation=rotx(N.pi)[:3, :3])
+        return Assembly(objects=[AssembledObject(surfs=[mirror]), AssembledObject(surfs=[rec])]), rec
+    rng = N.random.RandomState(5)
+    bundles = []
+    for k in range(3):
+        m = 40 + 10 * k
+        p = N.vstack((rng.uniform(-2.5, 2.5, (2, m)), N.ones(m)))          # some rays miss the mirror
+        d = N.vstack((rng.normal(scale=0.2, size=(2, m)), -N.ones(m)))
+        d /= N.sqrt(N.sum(d ** 2, axis=0))
+        bundles.append((p, d, rng.uniform(0.5, 1.5, m)))
+    asm, rec = build()
+    eng = TracerEngineMP(asm)
+    eng.multi_ray_sim([RayBundle(p.copy(), d.copy(), energy=e.copy()) for p, d, e in bundles], procs=3, minener=1e-9, reps=5, tree=True)
+    with pytest.raises(Exception):
+        eng.multi_ray_sim([RayBundle(*bundles[0][:2], energy=bundles[0][2])], procs=2)
+    singles = []
+    for p, d, e in bundles:
+        a1, r1 = build()
+        e1 = TracerEngine(a1)
+        e1.ray_tracer(RayBundle(p.copy(), d.copy(), energy=e.copy()), reps=5, min_energy=1e-9, tree=True)
+        singles.append((e1.tree, r1.get_optics_manager().get_all_hits()))
+    tree = eng.tree
+    assert tree.num_bunds() == max(t.num_bunds() for t, _ in singles)
+    for level in range(tree.num_bunds()):
+        parts = [t._bunds[level] for t, _ in singles if level < t.num_bunds()]
+        assert tree._bunds[level].get_num_rays() == sum(b.get_num_rays() for b in parts)
+        assert N.allclose(tree._bunds[level].get_vertices(), N.hstack([b.get_vertices() for b in parts]))
+        assert N.allclose(tree._bunds[level].get_energy(), N.hstack([b.get_energy() for b in parts]))
+        if level > 0:       # a ray starts where its parent ended up one level further -- with the shifted indices
+            par = N.asarray(tree._bunds[level].get_parents())
+            prev = tree._bunds[level - 1]
+            assert par.max() < prev.get_num_rays()
+            hit = tree._bunds[level].get_vertices() - prev.get_vertices()[:, par]
+            along = prev.get_directions()[:, par]
+            assert N.allclose(N.cross(hit.T, along.T), 0., atol=1e-9)
+    e_all, h_all = rec.get_optics_manager().get_all_hits()
+    assert N.allclose(N.sort(e_all), N.sort(N.hstack([h[0] for _, h in singles])))
+    assert len(e_all) > 60
