@@ -10,8 +10,9 @@ import types
 _MODULES = ['assembly', 'object', 'surface', 'has_frame', 'geometry_manager', 'flat_surface', 'triangular_face',
             'quadric', 'paraboloid', 'sphere_surface', 'cylinder', 'cone', 'quadratic_surface', 'ellipsoid',
             'optics', 'optics_callables', 'ray_bundle', 'trace_tree', 'tracer_engine', 'sources',
-            'spatial_geometry', 'boundary_shape', 'accel_tree', 'models', 'models.one_sided_mirror',
-            'models.heliostat_field']
+            'spatial_geometry', 'boundary_shape', 'accel_tree', 'polygon', 'tracer_engine_mp', 'models',
+            'models.one_sided_mirror', 'models.heliostat_field', 'models.homogenizer', 'models.spherical_lens',
+            'models.triangulated_surface']
 
 
 def install(force=False):
@@ -27,6 +28,9 @@ def install(force=False):
         sys.modules['tracer.' + name] = mod
         parent = alias if '.' not in name else sys.modules['tracer.' + name.rsplit('.', 1)[0]]
         setattr(parent, name.rsplit('.', 1)[-1], mod)
+    # the top-level `emissive_losses` package of the reference (view factors, radiosity)
+    for name in ('emissive_losses', 'emissive_losses.emissive_losses', 'emissive_losses.view_factors_3D'):
+        sys.modules.setdefault(name, importlib.import_module('tracer_amd.' + name))
     rtu = types.ModuleType('ray_trace_utils')
     rtu.__path__ = []
     rtu.vector_manipulations = importlib.import_module('tracer_amd.vector_manipulations')
