@@ -31,6 +31,20 @@ def install(force=False):
     # the top-level `emissive_losses` package of the reference (view factors, radiosity)
     for name in ('emissive_losses', 'emissive_losses.emissive_losses', 'emissive_losses.view_factors_3D'):
         sys.modules.setdefault(name, importlib.import_module('tracer_amd.' + name))
+    # scene scripts import the Coin3D viewer with a star import; rendering is outside this package: a Renderer that says so
+    coin = types.ModuleType('tracer.CoIn_rendering')
+    coin.__path__ = []
+    rendering = types.ModuleType('tracer.CoIn_rendering.rendering')
+
+    class Renderer(object):
+        def __init__(self, *args, **kwargs):
+            raise NotImplementedError('tracer_amd has no Coin3D viewer: trace with it, render with the reference')
+    rendering.Renderer = Renderer
+    rendering.__all__ = ['Renderer']
+    coin.rendering = rendering
+    alias.CoIn_rendering = coin
+    sys.modules['tracer.CoIn_rendering'] = coin
+    sys.modules['tracer.CoIn_rendering.rendering'] = rendering
     rtu = types.ModuleType('ray_trace_utils')
     rtu.__path__ = []
     rtu.vector_manipulations = importlib.import_module('tracer_amd.vector_manipulations')
