@@ -806,3 +806,59 @@ def test_transfer_matrix_equals_the_tree_of_the_oracle():
     eng.enable_transfer_matrix(False)
     with pytest.raises(ValueError):
         eng.get_transfer_matrix()
+
+
+_EXCHANGE_SCRIPT = r"""
+import sys
+import numpy as N
+import torch
+torch.cuda.init()                 # torch's HIP runtime first, as in bench.py: initialised second it finds no GPU
+sys.path.insert(0, sys.argv[1])
+from tracer_amd import _cabi, scenes
+from tracer_amd.scene import compile_scene, DeviceScene
+ctx = _cabi.get_context(0)
+plant, field, rec, src = scenes.nsttf_field(n_heliostats=30)
+cs = compile_scene(plant)
+dev = DeviceScene(cs, ctx)
+ue, ve = scenes.nsttf_fluxmap_edges()
+rec_index = plant.get_surfaces().index(rec.get_surfaces()[0])
+dev.set_fluxmap(rec_index, ue, ve)
+dev.enable_transfer(True)
+dev.trace_fast(scenes.nsttf_source(300000, src, seed=3), 100, 1e-10, 3, accel=True)
+a0, r0, h0 = dev.get_tallies()
+fm0, T0 = dev.get_fluxmap(rec_index), dev.get_transfer()
+n = dev.tally_size()
+S = cs.n_surf
+assert n == 3 * S + 2 + (len(ue) - 1) * (len(ve) - 1) + (S + 1) * S
+assert a0.sum() > 0 and fm0.sum() > 0 and T0.sum() > 0
+t = torch.empty(n, dtype=torch.float64, device='cuda')
+dev.export_tallies(out=t.data_ptr())
+torch.cuda.synchronize()
+host = dev.export_tallies()
+assert N.array_equal(t.cpu().numpy(), host)
+t += t                                   # the "all-reduce" with a second rank that traced the same
+torch.cuda.synchronize()
+dev.import_tallies(t.data_ptr())
+a1, r1, h1 = dev.get_tallies()
+assert N.array_equal(a1, 2 * a0) and N.array_equal(r1, 2 * r0) and N.array_equal(h1, 2 * h0)
+assert N.array_equal(dev.get_fluxmap(rec_index), 2 * fm0) and N.array_equal(dev.get_transfer(), 2 * T0)
+dev.import_tallies(host)
+assert N.array_equal(dev.get_tallies()[0], a0)
+dev.close()
+print('EXCHANGE OK')
+"""
+
+
+@pytest.mark.gpu
+def test_packed_tallies_round_trip_through_device_memory():
+    """
+    The exchange step of the multi-GPU path without the other GPUs: the packed tally buffer (per-surface energies and counts,
+    segment / hit totals, flux-map bins, transfer matrix) exported into a torch tensor on the device -- what
+    distributed.reduce_scene_tallies hands to the RCCL all-reduce -- summed with itself there and imported again doubles every
+    tally; through a host array the same.  In a process of its own, torch first (the order bench.py uses).
+    """
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, '-c', _EXCHANGE_SCRIPT, root], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and 'EXCHANGE OK' in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]

@@ -43,6 +43,7 @@ def reduce_scene_tallies(dev):
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return
     if dist.get_backend() == 'nccl':
+        # (torch's HIP runtime must have been initialised before the library's context was created: INTEGRATION.md)
         t = torch.empty(dev.tally_size(), dtype=torch.float64, device='cuda')
         dev.export_tallies(out=t.data_ptr())
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
