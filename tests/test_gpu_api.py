@@ -669,3 +669,38 @@ def test_homogenized_local_receiver_model():
     assert N.isclose(H.sum(), a[rec_index], rtol=1e-9) and a[rec_index] > 0.5 * 1000. * N.pi * 0.95 ** 2 * 0.3
     assert N.allclose(eng.get_fluxmap(rec_surface), H, rtol=1e-9, atol=1e-9)
     assert (h[2:] > 0).all()            # every wall of the duct takes part
+
+
+def test_stl_mesh_object(tmp_path):
+    """ray_trace_utils/stl_utils.py:156-235 through tracer_amd.stl_utils: a closed box written to STL, loaded as polygons and as
+    triangles; rays from inside all land on it, both forms and six RectPlateGM faces absorb the same per wall"""
+    from tracer_amd import stl_utils as su
+    verts = N.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], dtype=float) * N.r_[2., 1.5, 1.]
+    faces = N.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [2, 3, 7], [2, 7, 6], [1, 2, 6], [1, 6, 5], [0, 4, 7], [0, 7, 3]])
+    path = str(tmp_path / 'box.stl')
+    su.make_stl(verts, faces, path)
+    n = 100000
+    rng = N.random.RandomState(8)
+    pos = N.tile(N.c_[[0.7, 0.6, 0.4]], (1, n))
+    dirs = rng.normal(size=(3, n))
+    dirs /= N.sqrt(N.sum(dirs ** 2, axis=0))
+    per_wall = []
+    for option in ('polygon', 'triangle'):
+        obj = su.load_stl_into_tracer(path, opt.Lambertian, dict(absorptivity=1.), option=option)
+        assert len(obj.get_surfaces()) == 12
+        eng = TracerEngine(Assembly(objects=[obj]))
+        eng.ray_tracer(RayBundle(pos.copy(), dirs.copy(), energy=N.ones(n) / n), reps=1, min_energy=1e-12, tree=False, accel=True)
+        a, r, h = eng.get_tallies()
+        assert n - 5 <= h.sum() <= n                      # (a ray through an edge can slip between two triangles)
+        per_wall.append(a.reshape(6, 2).sum(axis=1))
+    assert N.allclose(per_wall[0], per_wall[1], atol=3e-5)
+    # the same box from six plates: bottom, top, y = 0, y = 1.5, x = 2, x = 0 (the order of the faces above)
+    plates = [(RectPlateGM(2., 1.5), translate(1., 0.75, 0.)), (RectPlateGM(2., 1.5), translate(1., 0.75, 1.)),
+              (RectPlateGM(2., 1.), N.dot(translate(1., 0., 0.5), rotx(N.pi / 2.))), (RectPlateGM(2., 1.), N.dot(translate(1., 1.5, 0.5), rotx(N.pi / 2.))),
+              (RectPlateGM(1., 1.5), N.dot(translate(2., 0.75, 0.5), generate_transform(N.r_[0., 1., 0.], N.pi / 2., N.c_[[0., 0., 0.]]))),
+              (RectPlateGM(1., 1.5), N.dot(translate(0., 0.75, 0.5), generate_transform(N.r_[0., 1., 0.], N.pi / 2., N.c_[[0., 0., 0.]])))]
+    box = Assembly(objects=[AssembledObject(surfs=[Surface(g, opt.Lambertian(1.))], transform=t) for g, t in plates])
+    eng = TracerEngine(box)
+    eng.ray_tracer(RayBundle(pos.copy(), dirs.copy(), energy=N.ones(n) / n), reps=1, min_energy=1e-12, tree=False)
+    a, r, h = eng.get_tallies()
+    assert N.allclose(a, per_wall[0], atol=3e-5)

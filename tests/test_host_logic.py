@@ -182,3 +182,35 @@ def test_homogenizer_layout():
     assert N.allclose(normals, [[-1, 0, 0], [1, 0, 0], [0, -1, 0], [0, 1, 0]], atol=1e-15)   # mirrors face the duct axis
     centres = N.array([s._temp_frame[:3, 3] for s in frames])
     assert N.allclose(centres, [[2.5, 0, 5], [-2.5, 0, 5], [0, 1.5, 5], [0, -1.5, 5]])
+
+
+def test_stl_reader_writer_and_triangle_frames(tmp_path):
+    """tracer_amd.stl_utils: binary and ASCII STL parsed with numpy alone; the frame of every triangle has z along its normal and
+    maps the planar profile back onto the vertices (ray_trace_utils/stl_utils.py:178-210)"""
+    from tracer_amd import stl_utils as su
+    verts = N.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], dtype=float)
+    faces = N.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [2, 3, 7], [2, 7, 6], [1, 2, 6], [1, 6, 5], [0, 4, 7], [0, 7, 3]])
+    path = str(tmp_path / 'box.stl')
+    su.make_stl(verts, faces, path)
+    tri = su.load_stl(path)
+    assert tri.shape == (12, 3, 3) and N.allclose(tri, verts[faces])
+    ascii_path = str(tmp_path / 'two.stl')
+    with open(ascii_path, 'w') as f:
+        f.write('solid two\n')
+        for t in tri[:2]:
+            f.write('facet normal 0 0 0\n outer loop\n' + ''.join('  vertex %r %r %r\n' % tuple(float(x) for x in v) for v in t) + ' endloop\nendfacet\n')
+        f.write('endsolid two\n')
+    assert N.array_equal(su.load_stl(ascii_path), tri[:2])
+    with open(str(tmp_path / 'bad.stl'), 'w') as f:
+        f.write('not a mesh')
+    with pytest.raises(ValueError):
+        su.load_stl(str(tmp_path / 'bad.stl'))
+    geoms, locs, rots = su.stl_to_tracer_geom(tri, 'polygon')
+    for k in range(12):
+        A, B, C = tri[k]
+        normal = N.cross(B - A, C - B)
+        assert N.allclose(rots[k][:, 2], normal / N.linalg.norm(normal)) and N.allclose(N.dot(rots[k], rots[k].T), N.eye(3))
+        back = locs[k][:, None] + N.dot(rots[k], N.vstack((geoms[k].profile, N.zeros(3))))
+        assert N.allclose(back.T, tri[k], atol=1e-12)
+    with pytest.raises(ValueError):
+        su.stl_to_tracer_geom(tri, 'quad')
