@@ -863,6 +863,24 @@ def make_emissive(out):
 
 
 
+def make_host_samplers(ref, amd, out):
+    """S1 direction samplers and the host-generated bundles: outputs of the reference under a fixed seed of numpy's global
+    generator (the host functions of tracer_amd draw the same variates in the same order)"""
+    nrm = N.random.RandomState(1).normal(size=(3, 50))
+    nrm /= N.sqrt(N.sum(nrm ** 2, axis=0))
+    nrm[:, 0], nrm[:, 1] = [0, 0, 1], [0, 0, -1]
+    out['normals'] = nrm
+    with N.errstate(all='ignore'):
+        for key, fn, args in (('lambertian', 'Lambertian_directions', (1000, 0.7)), ('lambertian_zero', 'Lambertian_directions', (200, 0.)),
+                              ('pillbox', 'pillbox_sunshape_directions', (500, 4.65e-3)), ('edge', 'edge_rays_directions', (500, 0.3)),
+                              ('lambertian_normals', 'Lambertian_directions', (50, 0.5, nrm))):
+            N.random.seed(11)
+            out[key] = getattr(ref.sources, fn)(*args)
+        N.random.seed(13)
+        b = ref.sources.edge_rays_bundle(300, N.c_[[1., 2., 3.]], N.r_[0., 0.6, 0.8], 2., 0.2, flux=10., radius_in=0.5)
+    out['edge_bundle_vertices'], out['edge_bundle_directions'], out['edge_bundle_energy'] = b.get_vertices(), b.get_directions(), b.get_energy()
+
+
 def main():
     import_reference()
     if '--mc' in sys.argv:
@@ -872,7 +890,8 @@ def main():
     amd = NS('tracer_amd')
     only = [a[len('--only='):] for a in sys.argv if a.startswith('--only=')]
     for fname, maker in (('geometry.npz', make_geometry), ('optics.npz', make_optics), ('sources.npz', make_sources),
-                         ('engine.npz', make_engine), ('emissive.npz', lambda ref, amd, out: make_emissive(out))):
+                         ('engine.npz', make_engine), ('emissive.npz', lambda ref, amd, out: make_emissive(out)),
+                         ('host_samplers.npz', make_host_samplers)):
         if only and fname not in only:
             continue
         out = {}

@@ -704,3 +704,20 @@ def test_stl_mesh_object(tmp_path):
     eng.ray_tracer(RayBundle(pos.copy(), dirs.copy(), energy=N.ones(n) / n), reps=1, min_energy=1e-12, tree=False)
     a, r, h = eng.get_tallies()
     assert N.allclose(a, per_wall[0], atol=3e-5)
+
+
+def test_trapezoid_bundle():
+    """sources.trapezoid_bundle (sources.py:599-642): two triangular bundles sharing the rays by area; every ray starts inside the
+    isosceles trapezoid ABCD, energies 1/n"""
+    A, B, C = N.r_[0., 0., 0.], N.r_[4., 0., 0.], N.r_[3., 2., 0.]
+    n = 20000
+    b = sources.trapezoid_bundle(n, A, B, C, ang_range=0.3, seed=4)
+    v, d, e = b.get_vertices(), b.get_directions(), b.get_energy()
+    assert v.shape == (3, n) and N.allclose(e, 1. / n) and N.allclose(v[2], 0.)
+    # D = (1, 2, 0) by symmetry: inside means 0 <= y <= 2 and y / 2 <= x <= 4 - y / 2
+    assert (v[1] >= -1e-12).all() and (v[1] <= 2. + 1e-12).all()
+    assert (v[0] >= v[1] / 2. - 1e-12).all() and (v[0] <= 4. - v[1] / 2. + 1e-12).all()
+    # ABC holds 4 of the 6 area units, ACD the other 2
+    upper = N.sum(v[1] > 1.)
+    assert abs(upper / float(n) - 2.5 / 6.) < 0.015        # the strip 1 < y < 2 holds 2.5 of the 6 area units
+    assert (N.arccos(N.clip(d[2], -1., 1.)) <= 0.3 + 1e-9).all()

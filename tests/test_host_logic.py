@@ -214,3 +214,23 @@ def test_stl_reader_writer_and_triangle_frames(tmp_path):
         assert N.allclose(back.T, tri[k], atol=1e-12)
     with pytest.raises(ValueError):
         su.stl_to_tracer_geom(tri, 'quad')
+
+
+def test_host_direction_samplers_equal_reference():
+    """S1: Lambertian_directions / pillbox_sunshape_directions / edge_rays_directions / edge_rays_bundle draw from numpy's global
+    generator what the reference draws, in its order: equal to the reference's outputs under the same seed"""
+    from tracer_amd import sources
+    from helpers import load
+    g = load("host_samplers.npz")
+    nrm = g['normals']
+    for key, fn, args in (('lambertian', sources.Lambertian_directions, (1000, 0.7)), ('lambertian_zero', sources.Lambertian_directions, (200, 0.)),
+                          ('pillbox', sources.pillbox_sunshape_directions, (500, 4.65e-3)), ('edge', sources.edge_rays_directions, (500, 0.3)),
+                          ('lambertian_normals', sources.Lambertian_directions, (50, 0.5, nrm))):
+        N.random.seed(11)
+        got = fn(*args)
+        assert N.allclose(got, g[key], rtol=0., atol=1e-13), key
+        assert N.allclose(N.sum(got ** 2, axis=0), 1.)
+    N.random.seed(13)
+    b = sources.edge_rays_bundle(300, N.c_[[1., 2., 3.]], N.r_[0., 0.6, 0.8], 2., 0.2, flux=10., radius_in=0.5)
+    assert N.allclose(b.get_vertices(), g['edge_bundle_vertices'], atol=1e-13) and N.allclose(b.get_directions(), g['edge_bundle_directions'], atol=1e-13)
+    assert N.allclose(b.get_energy(), g['edge_bundle_energy'])

@@ -142,6 +142,9 @@ def concatenate_rays(bundles):
     """Merge bundles in order; properties are those set in the first one (ray_bundle.py:197-223)."""
     if len(bundles) == 0:
         return RayBundle.empty_bund()
+    for b in bundles:              # source bundles still described by their generator are generated now
+        if hasattr(b, '_materialize'):
+            b._materialize()
     out = RayBundle()
     first = bundles[0]
     for attr in first._check_attr:

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as N
 
 from . import _cabi, rng
-from .ray_bundle import RayBundle
+from .ray_bundle import RayBundle, concatenate_rays
 from .spatial_geometry import rotation_to_z
 
 
@@ -215,6 +215,79 @@ def vf_frustum_bundle(num_rays, r0, r1, depth, center, direction, flux=None, ray
     desc = _fill_source(_cabi.SRC_VF_FRUSTUM, center, rot, rot,
                         [r0, r1, depth, angular_span[0], angular_span[1], angular_range, 1. if rays_in else -1.], energy)
     return _new_bundle(desc, num_rays, seed, ray_offset)
+
+
+def Lambertian_directions(num_rays, ang_range, normals=None):
+    """
+    (3, num_rays) unit directions about +z (or about `normals`), cosine-weighted within ang_range of it
+    (sources.py:88-101).  A host sampler on numpy's global generator, drawing what the reference draws in its order -- the
+    bundles above sample on the device from Philox streams instead.
+    """
+    xi1 = N.random.uniform(low=0., high=2. * N.pi, size=num_rays)
+    if ang_range == 0.:
+        dirs = N.zeros((3, num_rays))
+        dirs[2] = 1.
+    else:
+        xi2 = N.random.uniform(size=num_rays)
+        sinsqrt = N.sin(ang_range) * N.sqrt(xi2)
+        dirs = N.vstack((N.cos(xi1) * sinsqrt, N.sin(xi1) * sinsqrt, N.sqrt(1. - sinsqrt ** 2.)))
+    if normals is not None:
+        from .vector_manipulations import rotate_z_to_normal
+        dirs = rotate_z_to_normal(dirs, normals)
+    return dirs
+
+
+def pillbox_sunshape_directions(num_rays, ang_range):
+    """pillbox sunshape about +z: the cone-limited Lambertian distribution (sources.py:103-117)"""
+    return Lambertian_directions(num_rays, ang_range)
+
+
+def edge_rays_directions(num_rays, ang_range):
+    """directions on the rim of the cone of half-angle ang_range about +z (sources.py:152-173)"""
+    xi1 = N.random.uniform(high=2. * N.pi, size=num_rays)
+    sin_th = N.ones(num_rays) * N.sin(ang_range)
+    return N.vstack((N.cos(xi1) * sin_th, N.sin(xi1) * sin_th, N.cos(N.ones(num_rays) * ang_range)))
+
+
+def edge_rays_bundle(num_rays, center, direction, radius, ang_range, flux=None, radius_in=0.):
+    """annular disc source whose rays all leave at exactly ang_range from `direction` (sources.py:304-328); host-generated"""
+    radius, radius_in = float(radius), float(radius_in)
+    a = edge_rays_directions(num_rays, ang_range)
+    perp_rot = rotation_to_z(direction)
+    directions = N.sum(perp_rot[..., None] * a[None, ...], axis=1)
+    xi1 = N.random.uniform(size=num_rays)
+    thetas = N.random.uniform(high=2. * N.pi, size=num_rays)
+    rs = N.sqrt(radius_in ** 2. + xi1 * (radius ** 2. - radius_in ** 2.))
+    vertices_local = N.vstack((rs * N.cos(thetas), rs * N.sin(thetas), N.zeros(num_rays)))
+    rayb = RayBundle(vertices=N.dot(perp_rot, vertices_local) + center, directions=directions)
+    if flux is not None:
+        rayb.set_energy(N.pi * (radius ** 2. - radius_in ** 2.) / num_rays * flux * N.ones(num_rays))
+    return rayb
+
+
+def trapezoid_bundle(num_rays, A, B, C, direction=None, ang_range=N.pi / 2., flux=None, procs=1, seed=None, ray_offset=0):
+    """
+    Isosceles trapezoid ABCD (AB the first base, C the third vertex, D by symmetry) as two triangular bundles sharing the
+    rays in proportion to their areas (sources.py:599-642).
+    """
+    A, B, C = [N.asarray(v, dtype=float) for v in (A, B, C)]
+    AB, AC = B - A, C - A
+    l1, l2 = N.sqrt(N.sum(AB ** 2)), N.sqrt(N.sum(AC ** 2))
+    cos_theta = N.dot(AC, AB) / (l1 * l2)
+    cB = AB * (1. - 1. / l1 * l2 * cos_theta)
+    AD = AC - (AB - 2. * cB)
+    D = A + AD
+    l3, l4, l5 = N.sqrt(N.sum(AD ** 2)), N.sqrt(N.sum((AC - AB) ** 2)), N.sqrt(N.sum((AD - AC) ** 2))
+    s1, s2 = (l1 + l2 + l4) / 2., (l2 + l3 + l5) / 2.
+    area_ABC = N.sqrt(s1 * (s1 - l1) * (s1 - l2) * (s1 - l4))      # Heron
+    area_ACD = N.sqrt(s2 * (s2 - l2) * (s2 - l3) * (s2 - l5))
+    n_ABC = int(area_ABC / (area_ABC + area_ACD) * num_rays)
+    first = triangular_bundle(n_ABC, A, B, C, direction, ang_range, flux, seed=seed, ray_offset=ray_offset)
+    second = triangular_bundle(num_rays - n_ABC, A, C, D, direction, ang_range, flux, seed=seed, ray_offset=ray_offset + n_ABC)
+    rayb = concatenate_rays([first, second])
+    if flux is None:
+        rayb.set_energy(N.ones(num_rays) / float(num_rays) / procs)
+    return rayb
 
 
 def regular_square_bundle(num_rays, center, direction, width):
