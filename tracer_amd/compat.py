@@ -50,6 +50,8 @@ def install(force=False):
     rtu.vector_manipulations = importlib.import_module('tracer_amd.vector_manipulations')
     sys.modules.setdefault('ray_trace_utils', rtu)
     sys.modules.setdefault('ray_trace_utils.vector_manipulations', rtu.vector_manipulations)
+    rtu.estimator = importlib.import_module('tracer_amd.estimator')
+    sys.modules.setdefault('ray_trace_utils.estimator', rtu.estimator)
     rtu.stl_utils = importlib.import_module('tracer_amd.stl_utils')
     sys.modules.setdefault('ray_trace_utils.stl_utils', rtu.stl_utils)
     return root
