@@ -879,22 +879,6 @@ def make_host_samplers(ref, amd, out):
         N.random.seed(13)
         b = ref.sources.edge_rays_bundle(300, N.c_[[1., 2., 3.]], N.r_[0., 0.6, 0.8], 2., 0.2, flux=10., radius_in=0.5)
     out['edge_bundle_vertices'], out['edge_bundle_directions'], out['edge_bundle_energy'] = b.get_vertices(), b.get_directions(), b.get_energy()
-    # ray_trace_utils/estimator.py: batches of different sizes, scalar and vector estimates, both interval conventions
-    import importlib.util
-    spec = importlib.util.spec_from_file_location('ref_estimator', os.path.join(REFERENCE, 'ray_trace_utils', 'estimator.py'))
-    est = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(est)
-    rng = N.random.RandomState(3)
-    batches = [(rng.normal(loc=[5., 0.2, 40.], scale=[0.5, 0.05, 8.]), float(k)) for k in (1000, 1000, 2500, 400, 1000, 8000, 1000)]
-    out['est_values'], out['est_sizes'] = N.array([b[0] for b in batches]), N.array([b[1] for b in batches])
-    for rel in (True, False):
-        E = est.Estimator(n_sigmas=3., relative_CI=rel)
-        means, cis = [], []
-        for vals, m in batches:
-            E.update(vals.copy(), m)
-            with N.errstate(all='ignore'):
-                means.append(N.array(E.mean, dtype=float).copy()); cis.append(N.array(E.get_CI(), dtype=float).copy())
-        out['est_mean_rel%d' % rel], out['est_ci_rel%d' % rel] = N.array(means), N.array(cis)
 
 
 def main():

@@ -642,35 +642,6 @@ def test_tracer_engine_mp_merges_trees_and_hits():
     assert len(e_all) > 60
 
 
-def test_homogenized_local_receiver_model():
-    """
-    models/homogenized_local_receiver.py: a dish, a mirror duct and a receiver; histogram_hits() (the caller-side histogram2d of
-    :59-83) holds what the receiver absorbed, and equals the flux map accumulated on the device for the same trace.
-    """
-    from tracer_amd.models.homogenized_local_receiver import HomogenizedLocalReceiver
-    from tracer_amd.paraboloid import ParabolicDishGM
-    def build():
-        dish = Surface(ParabolicDishGM(2., 1.5), opt.perfect_mirror)
-        return HomogenizedLocalReceiver(dish, receiver_pos=1.6, receiver_dims=0.3, homogenizer_depth=0.25, homog_opt_eff=0.9)
-    plant = build()
-    assert len(plant.get_surfaces()) == 6 and plant.get_homogenizer() is plant.get_assemblies()[0]
-    assert plant.get_main_reflector() in plant.get_surfaces()
-    n = 200000
-    eng = TracerEngine(plant)
-    rec_surface = plant.get_receiver_surf().get_surfaces()[0]
-    edges = N.linspace(-0.15, 0.15, 21)
-    eng.set_fluxmap(rec_surface, edges, edges)
-    src = sources.disk_bundle(n, N.c_[[0., 0., 3.]], N.r_[0., 0., -1.], 0.95, 5e-3, flux=1000., seed=12)
-    eng.ray_tracer(src, reps=20, min_energy=1e-9, tree=False, seed=12)
-    H, xb, yb = plant.histogram_hits(bins=20)
-    a, r, h = eng.get_tallies()
-    rec_index = plant.get_surfaces().index(rec_surface)
-    assert H.shape == (20, 20) and N.allclose(xb, edges) and N.allclose(yb, edges)
-    assert N.isclose(H.sum(), a[rec_index], rtol=1e-9) and a[rec_index] > 0.5 * 1000. * N.pi * 0.95 ** 2 * 0.3
-    assert N.allclose(eng.get_fluxmap(rec_surface), H, rtol=1e-9, atol=1e-9)
-    assert (h[2:] > 0).all()            # every wall of the duct takes part
-
-
 def test_stl_mesh_object(tmp_path):
     """ray_trace_utils/stl_utils.py:156-235 through tracer_amd.stl_utils: a closed box written to STL, loaded as polygons and as
     triangles; rays from inside all land on it, both forms and six RectPlateGM faces absorb the same per wall"""

@@ -234,26 +234,3 @@ def test_host_direction_samplers_equal_reference():
     b = sources.edge_rays_bundle(300, N.c_[[1., 2., 3.]], N.r_[0., 0.6, 0.8], 2., 0.2, flux=10., radius_in=0.5)
     assert N.allclose(b.get_vertices(), g['edge_bundle_vertices'], atol=1e-13) and N.allclose(b.get_directions(), g['edge_bundle_directions'], atol=1e-13)
     assert N.allclose(b.get_energy(), g['edge_bundle_energy'])
-
-
-def test_estimator_equals_reference():
-    """ray_trace_utils/estimator.py: weighted Welford mean and confidence interval, batch by batch, against the reference's class"""
-    from helpers import load
-    from tracer_amd.estimator import Estimator, MCRT_to_CI
-    g = load('host_samplers.npz')
-    for rel in (1, 0):
-        E = Estimator(n_sigmas=3., relative_CI=bool(rel))
-        assert N.isinf(E.get_CI()).all()
-        for k in range(len(g['est_sizes'])):
-            E.update(g['est_values'][k].copy(), float(g['est_sizes'][k]))
-            with N.errstate(all='ignore'):
-                assert N.array_equal(E.mean, g['est_mean_rel%d' % rel][k]), (rel, k)
-                assert N.array_equal(E.get_CI(), g['est_ci_rel%d' % rel][k]), (rel, k)
-    # the convergence loop: a noisy estimator of 2.0 stops once 3 sigma of the mean is below 1 %
-    rng = N.random.RandomState(0)
-    calls = []
-    def batch(num_rays):
-        calls.append(num_rays)
-        return N.array([2. + rng.normal(scale=0.2)])
-    est = MCRT_to_CI(batch, 0.01, 1000)
-    assert est.get_CI()[0] <= 0.01 and abs(est.mean[0] - 2.) < 0.02 and len(calls) >= 3 and est.n == 1000. * len(calls)

@@ -12,7 +12,7 @@ _MODULES = ['assembly', 'object', 'surface', 'has_frame', 'geometry_manager', 'f
             'optics', 'optics_callables', 'ray_bundle', 'trace_tree', 'tracer_engine', 'sources',
             'spatial_geometry', 'boundary_shape', 'accel_tree', 'polygon', 'tracer_engine_mp', 'models',
             'models.one_sided_mirror', 'models.heliostat_field', 'models.homogenizer', 'models.spherical_lens',
-            'models.triangulated_surface', 'models.homogenized_local_receiver']
+            'models.triangulated_surface']
 
 
 def install(force=False):
@@ -50,8 +50,6 @@ def install(force=False):
     rtu.vector_manipulations = importlib.import_module('tracer_amd.vector_manipulations')
     sys.modules.setdefault('ray_trace_utils', rtu)
     sys.modules.setdefault('ray_trace_utils.vector_manipulations', rtu.vector_manipulations)
-    rtu.estimator = importlib.import_module('tracer_amd.estimator')
-    sys.modules.setdefault('ray_trace_utils.estimator', rtu.estimator)
     rtu.stl_utils = importlib.import_module('tracer_amd.stl_utils')
     sys.modules.setdefault('ray_trace_utils.stl_utils', rtu.stl_utils)
     return root
