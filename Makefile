@@ -7,7 +7,7 @@ ARCH ?= gfx950
 
 LIB := $(ROOT)tracer_amd/lib/libtracer_amd.so
 SRC := $(ROOT)tracer_amd/csrc/trc_kernels.hip
-HDR := $(ROOT)tracer_amd/csrc/trc_core.h $(ROOT)tracer_amd/csrc/trc_bounds.h $(ROOT)tracer_amd/csrc/trc_stream.inc $(ROOT)include/tracer_amd.h
+HDR := $(ROOT)tracer_amd/csrc/trc_core.h $(ROOT)tracer_amd/csrc/trc_bounds.h $(ROOT)tracer_amd/csrc/trc_footprint.h $(ROOT)tracer_amd/csrc/trc_stream.inc $(ROOT)include/tracer_amd.h
 
 HOSTCHECK := $(ROOT)tests/hostcheck/libtrc_hostcheck.so
 HOSTCHECK_SRC := $(ROOT)tests/hostcheck/hostcheck.cpp

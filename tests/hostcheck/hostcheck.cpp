@@ -9,6 +9,7 @@
 #include <cstring>
 #include "../../tracer_amd/csrc/trc_core.h"
 #include "../../tracer_amd/csrc/trc_bounds.h"
+#include "../../tracer_amd/csrc/trc_footprint.h"
 
 static void pack_record(const trc_surface_desc &s, double *rec, int stride) {
     for (int i = 0; i < stride; ++i) rec[i] = 0.0;
@@ -224,6 +225,89 @@ int hc_nearest_grid(int n_surf, const trc_surface_desc *surfs, const double *ext
         s_out[i] = sb;
     }
     return 0;
+}
+
+// The footprint map of a source (trc_footprint.h) against brute force: rays of the source, generated in float64 like the
+// kernels generate them; every ray that hits a surface and does not take the general path must have its mask bit set, the
+// surface in the list of its cell, and pass the oriented-box test from its advanced origin.
+// out[0] rays, [1] generic, [2] mask bit set, [3] hits, [4] VIOLATIONS, [5] listed candidates (sum over rays with the bit set),
+// [6] candidates passing the oriented box, [7] coverage, [8] largest |float32 - float64| start point, [9] eps.
+// Returns 0, or -3 when the map does not apply (reason in `why`).
+int hc_footprint(int n_surf, const trc_surface_desc *surfs, const double *extra, const trc_source_desc *src, long n, uint64_t seed,
+                 uint64_t offset, int M, double *out, char *why, int why_len) {
+    int max_np = 0;
+    for (int i = 0; i < n_surf; ++i) { int np = trc_gm_nparams(surfs[i].gm_kind); if (np > max_np) max_np = np; }
+    int stride = TRC_REC_HDR + max_np;
+    if ((stride & 1) == 0) stride += 1;
+    std::vector<double> recs((size_t)n_surf * stride);
+    for (int i = 0; i < n_surf; ++i) pack_record(surfs[i], recs.data() + (size_t)i * stride, stride);
+    trc_accel_host H;
+    trc_accel_build_surfaces(surfs, n_surf, H);
+    trc_fp_host F;
+    trc_fp_build(surfs, n_surf, H, *src, F, M);
+    for (int k = 0; k < 10; ++k) out[k] = 0.0;
+    if (!F.ok) { if (why && why_len > 0) { strncpy(why, F.why, (size_t)why_len - 1); why[why_len - 1] = 0; } return -3; }
+    const trc_fp_params &P = F.P;
+    out[7] = F.coverage;
+    out[9] = TRC_FP_EPS_REL * (double)P.half;
+    const double *rp = src->rot_pos;
+    for (long i = 0; i < n; ++i) {
+        const uint64_t rid = offset + (uint64_t)i;
+        double px, py, pz, dx, dy, dz;
+        trc_source_ray(src, src->buie, nullptr, seed, rid, &px, &py, &pz, &dx, &dy, &dz);
+        double tb; int sb;
+        trc_nearest_brute(recs.data(), stride, n_surf, extra, px, py, pz, dx, dy, dz, &tb, &sb);
+        uint32_t o[4];
+        trc_philox4x32_10((uint32_t)rid, (uint32_t)(rid >> 32), 0, 0, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        float lx, ly;
+        trc_fp_position32(P, o, &lx, &ly);
+        // the float64 start point in the source's local coordinates
+        const double vx = px - src->center[0], vy = py - src->center[1], vz = pz - src->center[2];
+        const double ex = rp[0] * vx + rp[3] * vy + rp[6] * vz, ey = rp[1] * vx + rp[4] * vy + rp[7] * vz;
+        out[8] = std::fmax(out[8], std::fmax(std::fabs(ex - (double)lx), std::fabs(ey - (double)ly)));
+        int32_t ix, iy;
+        trc_fp_cell(P, lx, ly, &ix, &iy);
+        const bool bit = (F.mask[((size_t)iy * P.M + ix) >> 5] >> (ix & 31)) & 1u;
+        const bool generic = trc_fp_generic(P, o);
+        out[0] += 1.0;
+        if (generic) out[1] += 1.0;
+        if (bit) out[2] += 1.0;
+        if (sb >= 0) out[3] += 1.0;
+        const size_t c = (size_t)(iy >> TRC_FP_SHIFT) * P.Mc + (ix >> TRC_FP_SHIFT);
+        const float ox = (float)(px + P.t_adv * dx - H.cen[0]), oy = (float)(py + P.t_adv * dy - H.cen[1]), oz = (float)(pz + P.t_adv * dz - H.cen[2]);
+        bool listed = false, boxed = false;
+        for (uint32_t k = F.coff[c]; k < F.coff[c + 1]; ++k) {
+            const int s = F.clist[k];
+            const bool hit = trc_obb_hit32(H.obb.data() + (size_t)TRC_OBB_STRIDE * s, ox, oy, oz, (float)dx, (float)dy, (float)dz);
+            if (bit && !generic) { out[5] += 1.0; if (hit) out[6] += 1.0; }
+            if (s == sb) { listed = true; boxed = hit; }
+        }
+        if (sb >= 0 && !generic && !(bit && listed && boxed)) out[4] += 1.0;
+    }
+    return 0;
+}
+
+// the oriented-box test against the exact test on arbitrary rays (the walk kernel's use): a ray that hits surface s exactly must
+// pass the box of s from an origin advanced to the scene box.  Returns the number of violations; *passed = rays passing the box.
+long hc_obb(const trc_surface_desc *s, const double *extra, long n, const double *x, const double *y, const double *z, const double *dx,
+            const double *dy, const double *dz, long *passed) {
+    double rec[TRC_REC_HDR + 16];
+    pack_record(*s, rec, TRC_REC_HDR + 16);
+    trc_accel_host H;
+    trc_accel_build_surfaces(s, 1, H);
+    long bad = 0;
+    *passed = 0;
+    if (!H.unbounded.empty()) { *passed = -1; return 0; }      // no box: such surfaces are tested exactly for every ray
+    for (long i = 0; i < n; ++i) {
+        const double t = trc_intersect(rec, extra, x[i], y[i], z[i], dx[i], dy[i], dz[i]);
+        trc_ray32 r;
+        double t0;
+        const bool in = trc_ray32_prepare(H.slo, H.shi, H.cen, x[i], y[i], z[i], dx[i], dy[i], dz[i], &r, &t0);
+        const bool box = in && trc_obb_hit32(H.obb.data(), r.ox, r.oy, r.oz, r.dx, r.dy, r.dz);
+        if (box) *passed += 1;
+        if (t > 0.0 && t < TRC_INF && !box) ++bad;
+    }
+    return bad;
 }
 
 }  // extern "C"

@@ -236,3 +236,98 @@ def test_core_kd_traversal_equals_brute_force(hc):
     with N.errstate(all='ignore'):
         front, tmin = engine.intersect_ray(scene, v[:, :20000], dr[:, :20000])
     assert N.array_equal(front, sb[:20000])
+
+
+def _fp(hc, cs, desc, n, M=512, seed=77, offset=0):
+    out = N.zeros(10)
+    why = C.create_string_buffer(128)
+    extra = N.ascontiguousarray(cs.extra if len(cs.extra) else N.zeros(1))
+    rc = hc.hc_footprint(cs.n_surf, cs.descs, _p(extra), C.byref(desc), C.c_long(n), C.c_uint64(seed), C.c_uint64(offset), M, _p(out),
+                         why, 128)
+    return rc, out, why.value.decode()
+
+
+def test_footprint_map_is_conservative(hc):
+    """
+    trc_footprint.h (the streaming engine's fresh-ray kernel): rays of the scene's source generated in float64; every ray whose
+    brute-force nearest hit exists (and that does not belong to the Buie aureole, which takes the general path) starts in a
+    set cell of the mask, finds the surface in the cell's list and passes its oriented-box test; the float32 start point of
+    stage A stays inside the margin the map was built with.
+    """
+    from tracer_amd import scenes, sources
+    from tracer_amd.scene import compile_scene
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM, RoundPlateGM
+    from tracer_amd.paraboloid import ParabolicDishGM
+    from tracer_amd.sphere_surface import HemisphereGM
+    from tracer_amd.cylinder import FiniteCylinder
+    from tracer_amd import optics_callables as opt
+    from tracer_amd.spatial_geometry import translate, rotx, roty, rotz
+    hc.hc_footprint.restype = C.c_int
+    # NSTTF, Buie disc: the bench workload
+    plant, field, rec, src = scenes.nsttf_field()
+    cs = compile_scene(plant)
+    for M in (512, 256):
+        rc, o, why = _fp(hc, cs, scenes.nsttf_source(10, src, seed=1).source_args()[0], 150000, M=M)
+        assert rc == 0, why
+        print('NSTTF M=%d: coverage %.3f, rays with the bit set %.3f, hits %.4f, generic %.4f, candidates per listed ray %.2f, box-passing %.2f, |f32-f64| %.2e (eps %.2e)'
+              % (M, o[7], o[2] / o[0], o[3] / o[0], o[1] / o[0], o[5] / max(o[2], 1), o[6] / max(o[2], 1), o[8], o[9]))
+        assert o[4] == 0 and o[3] > 5000 and o[8] < 0.1 * o[9]
+        assert o[2] / o[0] < 0.35          # the map culls most of the disc
+    # the dish under a Buie disc (everything is footprint), pillbox disc and rectangle sources over a small mixed scene, turned
+    # and shifted, and a source that is oblique to its own plane
+    asm, dish_surf, rec_surf, dsrc = scenes.dish()
+    rc, o, why = _fp(hc, compile_scene(asm), scenes.dish_source(10, dsrc, seed=1).source_args()[0], 60000)
+    assert rc == 0 and o[4] == 0 and o[3] > 50000, (why, o)
+    rng = N.random.RandomState(5)
+    objs = []
+    for k in range(14):
+        gm = [RectPlateGM(1.2, 0.7), RoundPlateGM(0.6), ParabolicDishGM(1.4, 1.1), HemisphereGM(0.5), FiniteCylinder(0.8, 1.1)][k % 5]
+        tr = N.dot(translate(*rng.uniform(-4, 4, 3)), N.dot(rotx(rng.uniform(0, 6.3)), N.dot(roty(rng.uniform(0, 6.3)), rotz(rng.uniform(0, 6.3)))))
+        objs.append(AssembledObject(surfs=[Surface(gm, opt.Reflective(0.1))], transform=tr))
+    mixed = compile_scene(Assembly(objects=objs))
+    direction = N.r_[0.3, -0.2, -1.] / N.linalg.norm([0.3, -0.2, -1.])
+    center = N.c_[-25. * direction]
+    cases = [sources.disk_bundle(10, center, direction, 9., 0.02, flux=1., seed=1),
+             sources.disk_bundle(10, center, direction, 9., 0.004, flux=1., radius_in=2., angular_span=[0.3, 5.1], seed=1),
+             sources.rect_bundle(10, center, direction, 16., 13., 0.01, flux=1., seed=1),
+             sources.rect_bundle(10, N.c_[[0., 0., 30.]], N.r_[0., 0., -1.], 16., 13., 0.01, flux=1., seed=1),
+             sources.buie_sunshape(10, center, direction, 9., 0.05, flux=1., seed=1),
+             sources.rect_buie_sunshape(10, center, direction, 17., 15., 0.1, flux=1., seed=1),
+             sources.oblique_solar_rect_bundle(10, N.c_[[-9., 6., 30.]], N.r_[0., 0., -1.], direction, 22., 20., 0.008, flux=1., seed=1)]
+    for k, b in enumerate(cases):
+        rc, o, why = _fp(hc, mixed, b.source_args()[0], 80000, seed=100 + k)
+        assert rc == 0, (k, why)
+        assert o[4] == 0 and o[3] > 1000 and o[8] < 0.1 * o[9], (k, list(o))
+    # not applicable: a wide cone, a disc with x_cut, a scene with an unbounded plane
+    rc, o, why = _fp(hc, mixed, sources.disk_bundle(10, center, direction, 9., 1.2, flux=1., seed=1).source_args()[0], 10)
+    assert rc == -3 and 'cone' in why
+    rc, o, why = _fp(hc, mixed, sources.disk_bundle(10, center, direction, 9., 0.01, flux=1., x_cut=1., seed=1).source_args()[0], 10)
+    assert rc == -3 and 'x_cut' in why
+    from tracer_amd.flat_surface import FlatGeometryManager
+    unb = compile_scene(Assembly(objects=objs + [AssembledObject(surfs=[Surface(FlatGeometryManager(), opt.Reflective(0.))], transform=translate(0, 0, -9))]))
+    rc, o, why = _fp(hc, unb, cases[0].source_args()[0], 10)
+    assert rc == -3 and 'unbounded' in why
+
+
+def test_oriented_box_never_rejects_a_hit(hc):
+    """trc_obb_hit32 (float32, the candidate test in front of every exact test) on the geometry fixtures: a ray that the
+    exact float64 test of the kind accepts passes the kind's oriented box -- all bounded kinds, three frames, 240 rays each"""
+    hc.hc_obb.restype = C.c_long
+    g = load('geometry.npz')
+    names = case_names(g)
+    tested = 0
+    for ci in range(int(g['n_cases'])):
+        pre = 'g%d_' % ci
+        kind = int(g[pre + 'kind'])
+        desc = _desc(kind, g[pre + 'frame'], g[pre + 'gm'], g[pre + 'extra'])
+        v = N.ascontiguousarray(g[pre + 'v']); d = N.ascontiguousarray(g[pre + 'd']); extra = N.ascontiguousarray(g[pre + 'extra'])
+        if not len(extra):
+            extra = N.zeros(1)
+        passed = C.c_long(0)
+        bad = hc.hc_obb(C.byref(desc), _p(extra), C.c_long(v.shape[1]), _p(v[0]), _p(v[1]), _p(v[2]), _p(d[0]), _p(d[1]), _p(d[2]), C.byref(passed))
+        assert bad == 0, (names[ci], bad)
+        tested += int(N.isfinite(g[pre + 't']).sum())
+    assert tested > 2000

@@ -11,11 +11,12 @@
 #include <vector>
 #include "trc_core.h"
 
-// Box of a surface in global coordinates.  Returns false for unbounded kinds.
+// Box of a surface in its own frame (l, h).  Returns false for unbounded kinds.  The sphere kinds work in the global
+// frame (sphere_surface.py:58-66): their box is centred on the frame's origin with the GLOBAL axes (*global_axes = true).
 // Every point the exact test of the kind can return lies inside the box (aperture rules of trc_core.h).
-static inline bool trc_surface_bounds(const trc_surface_desc &s, double lo[3], double hi[3]) {
+static inline bool trc_surface_local_box(const trc_surface_desc &s, double l[3], double h[3], bool *global_axes) {
     const double *g = s.gm;
-    double l[3], h[3];   // local box
+    *global_axes = false;
     switch (s.gm_kind) {
     case TRC_GM_RECT: case TRC_GM_RECT_EXTRUDED: case TRC_GM_RECT_PERFORATED:
         l[0] = -g[0]; h[0] = g[0]; l[1] = -g[1]; h[1] = g[1]; l[2] = h[2] = 0.0; break;
@@ -39,8 +40,9 @@ static inline bool trc_surface_bounds(const trc_surface_desc &s, double lo[3], d
         l[0] = -rx; h[0] = rx; l[1] = -g[1]; h[1] = g[1]; l[2] = 0.0; h[2] = g[2]; break;
     }
     case TRC_GM_SPHERE: case TRC_GM_HEMISPHERE: case TRC_GM_SPHERE_RECT: case TRC_GM_SPHERE_CUT:
-        for (int i = 0; i < 3; ++i) { lo[i] = s.frame[4 * i + 3] - g[0]; hi[i] = s.frame[4 * i + 3] + g[0]; }
-        return true;
+        for (int i = 0; i < 3; ++i) { l[i] = -g[0]; h[i] = g[0]; }
+        *global_axes = true;
+        break;
     case TRC_GM_CYL_FINITE: case TRC_GM_CYL_RECTCUT:
         l[0] = l[1] = -g[0]; h[0] = h[1] = g[0]; l[2] = -g[1]; h[2] = g[1]; break;
     case TRC_GM_CONE_FINITE: {
@@ -68,13 +70,28 @@ static inline bool trc_surface_bounds(const trc_surface_desc &s, double lo[3], d
         return false;   // FLAT_INF, PARABOLOID, PARAB_RECT_OFFAXIS, PARAB_CYL, CYL_INF, CONE_INF, QUADRATIC
     }
     for (int i = 0; i < 3; ++i) if (!(l[i] <= h[i]) || !std::isfinite(l[i]) || !std::isfinite(h[i])) return false;
+    return true;
+}
+
+// corner c (0..7) of a surface's local box in global coordinates
+static inline void trc_surface_box_corner(const trc_surface_desc &s, const double l[3], const double h[3], bool global_axes, int c,
+                                          double q[3]) {
+    const double p[3] = {(c & 1) ? h[0] : l[0], (c & 2) ? h[1] : l[1], (c & 4) ? h[2] : l[2]};
+    for (int i = 0; i < 3; ++i)
+        q[i] = global_axes ? p[i] + s.frame[4 * i + 3]
+                           : s.frame[4 * i] * p[0] + s.frame[4 * i + 1] * p[1] + s.frame[4 * i + 2] * p[2] + s.frame[4 * i + 3];
+}
+
+// Box of a surface in global coordinates.  Returns false for unbounded kinds.
+static inline bool trc_surface_bounds(const trc_surface_desc &s, double lo[3], double hi[3]) {
+    double l[3], h[3];
+    bool global_axes;
+    if (!trc_surface_local_box(s, l, h, &global_axes)) return false;
     for (int i = 0; i < 3; ++i) { lo[i] = std::numeric_limits<double>::infinity(); hi[i] = -lo[i]; }
     for (int c = 0; c < 8; ++c) {
-        double p[3] = {(c & 1) ? h[0] : l[0], (c & 2) ? h[1] : l[1], (c & 4) ? h[2] : l[2]};
-        for (int i = 0; i < 3; ++i) {
-            double q = s.frame[4 * i] * p[0] + s.frame[4 * i + 1] * p[1] + s.frame[4 * i + 2] * p[2] + s.frame[4 * i + 3];
-            lo[i] = std::fmin(lo[i], q); hi[i] = std::fmax(hi[i], q);
-        }
+        double q[3];
+        trc_surface_box_corner(s, l, h, global_axes, c, q);
+        for (int i = 0; i < 3; ++i) { lo[i] = std::fmin(lo[i], q[i]); hi[i] = std::fmax(hi[i], q[i]); }
     }
     return true;
 }
@@ -82,8 +99,14 @@ static inline bool trc_surface_bounds(const trc_surface_desc &s, double lo[3], d
 static inline float trc_f32_down(double x) { float f = (float)x; return ((double)f > x) ? std::nextafterf(f, -INFINITY) : f; }
 static inline float trc_f32_up(double x) { float f = (float)x; return ((double)f < x) ? std::nextafterf(f, INFINITY) : f; }
 
+// Oriented box of a surface for the single-precision candidate test (trc_obb_hit32, trc_core.h): the surface's own box in
+// its own frame, inflated by delta, with the rotation global -> local and the frame origin relative to the scene centre.
+// For a flat surface the box is the plate itself +- delta: a ray that passes this test nearly always passes the exact one.
+#define TRC_OBB_STRIDE 20   /* [A0 A1 A2 c0 | A3 A4 A5 c1 | A6 A7 A8 c2 | lo0 lo1 lo2 hi0 | hi1 hi2 - -]; A = R^T */
+
 struct trc_accel_host {
     std::vector<float> sbox;          // 6 per surface
+    std::vector<float> obb;           // TRC_OBB_STRIDE per surface (unbounded: a box nothing misses)
     std::vector<int32_t> unbounded;
     std::vector<uint32_t> nodes;      // 2 per Kd node
     std::vector<uint16_t> leaf_surfs;
@@ -147,6 +170,25 @@ static inline void trc_accel_build_surfaces(const trc_surface_desc *surfs, int n
                 A.sbox[6 * (size_t)i + 3 + k] = INFINITY;
             }
         }
+    A.obb.assign((size_t)TRC_OBB_STRIDE * (size_t)n, 0.0f);
+    for (int i = 0; i < n; ++i) {
+        float *B = &A.obb[(size_t)TRC_OBB_STRIDE * (size_t)i];
+        double l[3], h[3];
+        bool global_axes = false;
+        const bool ok = bounded[i] && trc_surface_local_box(surfs[i], l, h, &global_axes);
+        for (int r = 0; r < 3; ++r) {
+            for (int k = 0; k < 3; ++k)         // row r of A = column r of the frame's rotation (local axis r in global coordinates)
+                B[4 * r + k] = (ok && !global_axes) ? (float)surfs[i].frame[4 * k + r] : (r == k ? 1.0f : 0.0f);
+            B[4 * r + 3] = ok ? (float)(surfs[i].frame[4 * r + 3] - A.cen[r]) : 0.0f;
+        }
+        for (int k = 0; k < 3; ++k) {
+            // the rotation is rounded to float32 (6e-8 relative): over a box of half-size |l|, |h| that moves a point by at most
+            // ~2e-7 * size, far inside delta
+            const float blo = ok ? trc_f32_down(l[k] - delta) : -INFINITY, bhi = ok ? trc_f32_up(h[k] + delta) : INFINITY;
+            B[12 + k] = blo;
+            B[15 + k] = bhi;
+        }
+    }
 }
 
 // Uniform grid over the scene box for the DDA of trc_core.h (call after trc_accel_build_surfaces).  About two cells per

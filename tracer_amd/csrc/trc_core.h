@@ -688,6 +688,29 @@ TRC_HD bool trc_box_hit32(const float *b, const trc_ray32 &r) {
     return hi * 1.0001f + 1e-6f >= lo;
 }
 
+// The same question for the surface's own (oriented) box, a record of TRC_OBB_STRIDE floats made by trc_bounds.h:
+// [A0 A1 A2 c0 | A3 A4 A5 c1 | A6 A7 A8 c2 | lo0 lo1 lo2 hi0 | hi1 hi2 - -], A = R^T, c = frame origin relative to the
+// scene centre, lo / hi = the surface's box in its own frame inflated by delta.  (ox, oy, oz) is relative to the scene
+// centre like trc_ray32's origin.  The ray is taken into the frame in float32: a point of the ray at distance t moves by
+// ~1e-7 (|o - c| + t), which delta (>= 2.5e-5 of the scene extent) covers with two orders of magnitude to spare as long as
+// the origin is no farther from the scene than a few times its size -- the callers advance it to the scene first.
+TRC_HD bool trc_obb_hit32(const float *B, float ox, float oy, float oz, float dx, float dy, float dz) {
+    const float rx = ox - B[3], ry = oy - B[7], rz = oz - B[11];
+    const float lx = B[0] * rx + B[1] * ry + B[2] * rz, ly = B[4] * rx + B[5] * ry + B[6] * rz, lz = B[8] * rx + B[9] * ry + B[10] * rz;
+    const float ex = B[0] * dx + B[1] * dy + B[2] * dz, ey = B[4] * dx + B[5] * dy + B[6] * dz, ez = B[8] * dx + B[9] * dy + B[10] * dz;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float ix = __builtin_amdgcn_rcpf(ex), iy = __builtin_amdgcn_rcpf(ey), iz = __builtin_amdgcn_rcpf(ez);
+#else
+    const float ix = 1.0f / ex, iy = 1.0f / ey, iz = 1.0f / ez;
+#endif
+    const float ax = (B[12] - lx) * ix, bx = (B[15] - lx) * ix;
+    const float ay = (B[13] - ly) * iy, by = (B[16] - ly) * iy;
+    const float az = (B[14] - lz) * iz, bz = (B[17] - lz) * iz;
+    const float lo = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float hi = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return hi * 1.0001f + 1e-6f >= lo;       // NaNs (0 * inf) are ignored by fminf/fmaxf: conservative, as in trc_box_hit32
+}
+
 // One interior-node step of the conservative single-precision walk (used by trc_nearest_accel32 below and by the
 // wave-cooperative kernel).  w0/w1: the packed node.  Returns the node to continue with; when *push is set the
 // caller must push (*push_na = other child << 2 | axis code, *push_t = interval end of that child) and the

@@ -27,6 +27,7 @@
 
 #include "trc_core.h"
 #include "trc_bounds.h"
+#include "trc_footprint.h"
 
 // ================================================================================================
 // error handling
@@ -91,6 +92,7 @@ struct DScene {
     double kd_bmin[3], kd_bmax[3];
     // single-precision acceleration data (trc_bounds.h)
     const float *a_sbox;
+    const float *a_obb;        // TRC_OBB_STRIDE floats per surface: oriented boxes (trc_obb_hit32)
     const uint32_t *a_nodes;
     const uint16_t *a_leaf;
     const int32_t *a_unbounded;
@@ -140,6 +142,8 @@ struct trc_scene {
     trc_accel_host accel;
     bool accel_ok, accel_kd_ok;
     float *d_a_sbox;
+    float *d_a_obb;
+    uint64_t geom_version;     // bumped whenever the surfaces are (re)uploaded: tables derived from their poses are stale
     uint32_t *d_a_nodes;
     uint16_t *d_a_leaf;
     int32_t *d_a_unbounded;
@@ -1376,7 +1380,10 @@ static int scene_upload_surfaces(trc_scene *sc) {
     HIP_TRY(hipMemcpy(sc->d_sflags, flags.data(), flags.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     // conservative single-precision boxes of the bounded surfaces (fast engine)
     trc_accel_build_surfaces(sc->surfs.data(), sc->n_surf, sc->accel);
-    dev_free(sc->d_a_sbox); dev_free(sc->d_a_unbounded); dev_free(sc->d_a_bleaf);
+    sc->geom_version += 1;
+    dev_free(sc->d_a_sbox); dev_free(sc->d_a_obb); dev_free(sc->d_a_unbounded); dev_free(sc->d_a_bleaf);
+    TRC_TRY(dev_alloc(&sc->d_a_obb, sc->accel.obb.size()));
+    HIP_TRY(hipMemcpy(sc->d_a_obb, sc->accel.obb.data(), sc->accel.obb.size() * sizeof(float), hipMemcpyHostToDevice));
     TRC_TRY(dev_alloc(&sc->d_a_bleaf, sc->accel.brute_leaf.size()));
     if (!sc->accel.brute_leaf.empty())
         HIP_TRY(hipMemcpy(sc->d_a_bleaf, sc->accel.brute_leaf.data(), sc->accel.brute_leaf.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -1470,7 +1477,7 @@ extern "C" int trc_scene_destroy(trc_scene *sc) {
     scene_free_stream_ws(sc);
     dev_free(sc->d_recs); dev_free(sc->d_opt); dev_free(sc->d_extra); dev_free(sc->d_sflags);
     dev_free(sc->d_kd_a); dev_free(sc->d_kd_b); dev_free(sc->d_kd_leaf); dev_free(sc->d_kd_always);
-    dev_free(sc->d_a_sbox); dev_free(sc->d_a_nodes); dev_free(sc->d_a_leaf); dev_free(sc->d_a_unbounded); dev_free(sc->d_a_bleaf);
+    dev_free(sc->d_a_sbox); dev_free(sc->d_a_obb); dev_free(sc->d_a_nodes); dev_free(sc->d_a_leaf); dev_free(sc->d_a_unbounded); dev_free(sc->d_a_bleaf);
     dev_free(sc->d_a_goff); dev_free(sc->d_a_glist); dev_free(sc->d_a_gapart);
     dev_free(sc->d_kd_split); dev_free(sc->d_tally); dev_free(sc->d_fm_of_surf); dev_free(sc->d_fms);
     dev_free(sc->d_fm_edges); dev_free(sc->d_counters); dev_free(sc->d_src_buf); dev_free(sc->d_h_surf);
@@ -1820,7 +1827,7 @@ static DScene make_dscene(trc_scene *sc) {
     d.kd_split = sc->d_kd_split;
     d.kd_nodes = sc->kd_nodes; d.kd_nleaf = sc->kd_nleaf; d.kd_nalways = sc->kd_nalways;
     for (int i = 0; i < 3; ++i) { d.kd_bmin[i] = sc->kd_bounds[i]; d.kd_bmax[i] = sc->kd_bounds[3 + i]; }
-    d.a_sbox = sc->d_a_sbox; d.a_nodes = sc->d_a_nodes; d.a_leaf = sc->d_a_leaf; d.a_unbounded = sc->d_a_unbounded;
+    d.a_sbox = sc->d_a_sbox; d.a_obb = sc->d_a_obb; d.a_nodes = sc->d_a_nodes; d.a_leaf = sc->d_a_leaf; d.a_unbounded = sc->d_a_unbounded;
     d.a_n_unbounded = (int32_t)sc->accel.unbounded.size(); d.a_kd_depth = sc->accel.kd_depth;
     d.a_bleaf = sc->d_a_bleaf; d.a_n_bleaf = (int32_t)sc->accel.brute_leaf.size();
     d.a_bnodes[0] = sc->accel.brute_nodes[0]; d.a_bnodes[1] = sc->accel.brute_nodes[1];
@@ -2027,7 +2034,20 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
                 if (!sc->stream_eng) { st = trc_fail(TRC_ERR_NOMEM, "out of host memory"); break; }
                 memset(sc->stream_eng, 0, sizeof(StreamEngine));
             }
-            if ((st = stream_trace(sc, P, want_accel, src ? src->kind : -1, *sc->stream_eng, &s, &stream_seg, &stream_hits))) break;
+            if ((st = stream_trace(sc, P, want_accel, src, *sc->stream_eng, &s, &stream_seg, &stream_hits))) {
+                // the hits captured by the bounces that completed: wind the buffer back to where the call found it
+                const std::string why = g_last_error;
+                unsigned long long now = 0;
+                (void)hipDeviceSynchronize();
+                if (sc->hit_cap > 0 && hipMemcpy(&now, sc->d_counters, sizeof(now), hipMemcpyDeviceToHost) == hipSuccess && now > cnt_before[0]) {
+                    const unsigned long long end = now < (unsigned long long)sc->hit_cap ? now : (unsigned long long)sc->hit_cap;
+                    if (end > cnt_before[0]) (void)hipMemset(sc->d_h_surf + cnt_before[0], 0xFF, (size_t)(end - cnt_before[0]) * sizeof(int32_t));
+                    (void)hipMemcpy(sc->d_counters, &cnt_before[0], sizeof(unsigned long long), hipMemcpyHostToDevice);
+                }
+                sc->hit_epoch += 1;
+                g_last_error = why;
+                break;
+            }
             stream_counts_known = true;
         } else {
         if (hipMemcpy(tally_before, sc->d_tally + 3 * S, sizeof(tally_before), hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "counter readback failed"); break; }
