@@ -39,48 +39,48 @@ struct trc_fp_params {
 };
 
 // float32 start point of a source ray in the source's local coordinates from its Philox block (the float64 one is
-// trc_source_ray_t's).  Device: v_sqrt_f32 / v_sin_f32 / v_cos_f32.
-TRC_HD void trc_fp_position32(const trc_fp_params &F, const uint32_t o[4], float *lx, float *ly) {
-    const float s = 1.0f / 4294967296.0f;
-    float sn, cs;
-    switch (F.kind) {
-    case TRC_SRC_BUIE_DISK: {            // r = R sqrt(u0), phi = 2 pi u1
-        const float u0 = ((float)o[0] + 0.5f) * s, u1 = ((float)o[1] + 0.5f) * s;
-        const float r = F.p[0] * sqrtf(u0);
+// trc_source_ray_t's).  Device: v_sqrt_f32 / v_sin_f32 / v_cos_f32 (1 ulp / ~1e-6 absolute: see TRC_FP_EPS_REL).
+// KIND >= 0 promises F.kind == KIND (the kernels compile one instance per source kind).
+TRC_HD float trc_fp_sqrt32(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        sn = __builtin_amdgcn_sinf(u1); cs = __builtin_amdgcn_cosf(u1);       // argument in revolutions
+    return __builtin_amdgcn_sqrtf(x);
 #else
-        sn = sinf(6.2831853071795865f * u1); cs = cosf(6.2831853071795865f * u1);
+    return sqrtf(x);
 #endif
+}
+TRC_HD void trc_fp_sincos_rev32(float rev, float *sn, float *cs) {        // sine and cosine of 2 pi rev
+#if defined(__HIP_DEVICE_COMPILE__)
+    *sn = __builtin_amdgcn_sinf(rev); *cs = __builtin_amdgcn_cosf(rev);
+#else
+    *sn = sinf(6.2831853071795865f * rev); *cs = cosf(6.2831853071795865f * rev);
+#endif
+}
+template <int KIND>
+TRC_HD void trc_fp_position32_t(const trc_fp_params &F, const uint32_t o[4], float *lx, float *ly) {
+    const float s = 1.0f / 4294967296.0f;
+    const int kind = KIND >= 0 ? KIND : F.kind;
+    float sn, cs;
+    if (kind == TRC_SRC_BUIE_DISK) {            // r = R sqrt(u0), phi = 2 pi u1
+        const float u0 = ((float)o[0] + 0.5f) * s, u1 = ((float)o[1] + 0.5f) * s;
+        const float r = F.p[0] * trc_fp_sqrt32(u0);
+        trc_fp_sincos_rev32(u1, &sn, &cs);
         *lx = r * cs; *ly = r * sn;
-        break;
-    }
-    case TRC_SRC_BUIE_RECT: {
+    } else if (kind == TRC_SRC_BUIE_RECT) {
         const float u0 = ((float)o[0] + 0.5f) * s, u1 = ((float)o[1] + 0.5f) * s;
         *lx = F.p[0] * (u0 - 0.5f); *ly = F.p[1] * (u1 - 0.5f);
-        break;
-    }
-    case TRC_SRC_PILLBOX_DISK: {         // r = sqrt(Ri^2 + u2 (Re^2 - Ri^2)), th = span0 + (span1 - span0) u3
+    } else if (kind == TRC_SRC_PILLBOX_DISK) {  // r = sqrt(Ri^2 + u2 (Re^2 - Ri^2)), th = span0 + (span1 - span0) u3
         const float u2 = ((float)o[2] + 0.5f) * s, u3 = ((float)o[3] + 0.5f) * s;
-        const float r = sqrtf(F.p[0] + u2 * F.p[1]);
-        const float rev = F.p[2] + F.p[3] * u3;
-#if defined(__HIP_DEVICE_COMPILE__)
-        sn = __builtin_amdgcn_sinf(rev); cs = __builtin_amdgcn_cosf(rev);
-#else
-        sn = sinf(6.2831853071795865f * rev); cs = cosf(6.2831853071795865f * rev);
-#endif
+        const float r = trc_fp_sqrt32(F.p[0] + u2 * F.p[1]);
+        trc_fp_sincos_rev32(F.p[2] + F.p[3] * u3, &sn, &cs);
         *lx = r * cs; *ly = r * sn;
-        break;
-    }
-    default: {                           // TRC_SRC_PILLBOX_RECT: (lx, ly) = (ys, xs), swapped when the source says so
+    } else {                                    // TRC_SRC_PILLBOX_RECT: (lx, ly) = (ys, xs), swapped when the source says so
         const float u2 = ((float)o[2] + 0.5f) * s, u3 = ((float)o[3] + 0.5f) * s;
         const float a = F.p[0] * (u2 - 0.5f), b = F.p[1] * (u3 - 0.5f);    // xs, ys
         const bool swap = F.p[2] != 0.0f;
         *lx = swap ? a : b; *ly = swap ? b : a;
-        break;
-    }
     }
 }
+TRC_HD void trc_fp_position32(const trc_fp_params &F, const uint32_t o[4], float *lx, float *ly) { trc_fp_position32_t<-1>(F, o, lx, ly); }
 
 // mask cell of a start point (clamped: a point that float32 puts just outside the map belongs to its border cell)
 TRC_HD void trc_fp_cell(const trc_fp_params &F, float lx, float ly, int32_t *ix, int32_t *iy) {

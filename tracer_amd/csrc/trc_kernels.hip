@@ -268,6 +268,13 @@ __device__ __forceinline__ WaveChunk chunk_init_static(unsigned size, unsigned l
     return c;
 }
 
+// the same with the chunk's first entry given (chunks of different sizes pre-assigned in one list)
+__device__ __forceinline__ WaveChunk chunk_init_static_at(unsigned size, unsigned long long base) {
+    WaveChunk c;
+    c.base = base; c.used = 0; c.open = 1; c.size = size;
+    return c;
+}
+
 // after a chunk_append made by a subset of the lanes: every lane takes the state of `lane` (one that took part)
 __device__ __forceinline__ void chunk_rebroadcast(WaveChunk &c, int lane) {
     c.base = __shfl(c.base, lane, 64);
@@ -315,13 +322,16 @@ __device__ __forceinline__ unsigned long long chunk_append(unsigned long long *c
 }
 
 #define SHADE_MAX_WAVES 4096     /* waves of one k_s_shade launch (at most n_cu * 4 workgroups of 4 waves, n_cu <= 256) */
-#define TRC_HIT_SLACK (4ll * SHADE_MAX_WAVES * SQ_CHUNK + 64)   /* unused entries the open chunks of two slots can hold */
+#define SQ_HIT_CHUNK 1024        /* entries of the hit buffer a wave of k_s_shade reserves per atomic: the cursor is one word (~88 returning
+                                    atomics per microsecond), and at 256 the 12 000 reservations of an NSTTF batch were half of the kernel */
+#define TRC_HIT_SLACK (4ll * SHADE_MAX_WAVES * SQ_HIT_CHUNK + 64)   /* unused entries the open chunks of two slots can hold */
 
 // per-hit bookkeeping shared by both engines: tallies, flux map, hit capture
 template <bool LDS_TALLY>
 __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, int s, double e_in,
                                            double e_abs, double hx, double hy, double hz, double dx,
-                                           double dy, double dz, bool capture_enabled, int prev, WaveChunk *hc = nullptr) {
+                                           double dy, double dz, bool capture_enabled, int prev, WaveChunk *hc = nullptr,
+                                           double *lds_fm = nullptr) {
     const int S = sc.n_surf;
     // energy carried from the surface the ray left (S = the source) to the one it lands on
     if (sc.tr_off >= 0) atomicAdd(&sc.tally[sc.tr_off + (long long)prev * S + s], e_in);
@@ -341,7 +351,12 @@ __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, 
         double v = m.proj[4] * hx + m.proj[5] * hy + m.proj[6] * hz + m.proj[7];
         int iu = trc_bin_index(sc.fm_edges + m.edges_u, m.nu, u);
         int iv = trc_bin_index(sc.fm_edges + m.edges_v, m.nv, v);
-        if (iu >= 0 && iv >= 0) atomicAdd(&sc.tally[m.bins + (int64_t)iu * m.nv + iv], e_abs);
+        if (iu >= 0 && iv >= 0) {
+            // lds_fm: the workgroup's private copy of all flux-map bins (they follow the 3S+2 per-surface sums in the tally buffer);
+            // scattered global float64 atomics run at ~1/17 of the rate of the contiguous ones the copy is flushed with
+            if (lds_fm) atomicAdd(&lds_fm[m.bins - (3 * (int64_t)S + 2) + (int64_t)iu * m.nv + iv], e_abs);
+            else atomicAdd(&sc.tally[m.bins + (int64_t)iu * m.nv + iv], e_abs);
+        }
     }
     if (capture_enabled && hc) {
         // chunked append (streaming engine): one atomic per 256 captured hits instead of one per wave and iteration --
@@ -580,7 +595,8 @@ __device__ __forceinline__ void coop_drain_leaves(const trc_accel_view &A, const
 template <bool LDS_TALLY>
 __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *recs, double *l_tally, double t, int s, double &px,
                                            double &py, double &pz, double &dx, double &dy, double &dz, double &e, double &ref,
-                                           double wl, unsigned long long rid, int &bounce, int &prev, WaveChunk *hc = nullptr) {
+                                           double wl, unsigned long long rid, int &bounce, int &prev, WaveChunk *hc = nullptr,
+                                           double *lds_fm = nullptr) {
     const DScene &sc = P.sc;
     bounce += 1;
     const double *rec = recs + (size_t)s * sc.stride;
@@ -593,7 +609,7 @@ __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *re
                           rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, path, nx, ny, nz, P.seed, rid, (uint32_t)bounce, out);
     (void)n_out;  // scenes whose optics split rays are routed to the ordered engine by the host
     double e_abs = e - out[0].e;
-    record_hit<LDS_TALLY>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0, prev, hc);
+    record_hit<LDS_TALLY>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0, prev, hc, lds_fm);
     prev = s;
     px = hx; py = hy; pz = hz;
     dx = out[0].dx; dy = out[0].dy; dz = out[0].dz;
