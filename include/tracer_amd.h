@@ -331,6 +331,16 @@ int trc_source_generate(trc_ctx *ctx, const trc_source_desc *src, int64_t n, uin
                         uint64_t ray_offset, trc_rays *out);
 
 /*
+ * Start points of the first n rays of a disc / rectangle source (sources.py:175-515) in the source's own plane coordinates
+ * (the two columns of rot_pos), evaluated in float32 exactly as the fast engine's culling kernel evaluates them before it
+ * decides from the footprint map (csrc/trc_footprint.h) whether a ray can reach any surface.  *eps receives the distance the
+ * map allows between this and the float64 start point of trc_source_generate.  A self-check of the engine: tests compare
+ * the two on the device.  TRC_ERR_UNSUPPORTED for sources the map does not apply to.
+ */
+int trc_source_start32(trc_ctx *ctx, const trc_source_desc *src, int64_t n, uint64_t seed,
+                       uint64_t ray_offset, float *lx, float *ly, double *eps);
+
+/*
  * Per-surface trace protocol (user-doc/trace_protocol.rst:1-24), for callers that drive
  * surfaces one at a time like the reference engine does:
  *   GeometryManager.find_intersections(frame, bundle) -> t (+inf = miss)   geometry_manager.py:8-26

@@ -1,0 +1,263 @@
+"""
+GPU tests of the streaming fast engine's own paths (run with -m gpu on the MI355X box), through the C-ABI.
+
+The engine answers one question -- nearest hit of every ray, the reference's tie rule (tracer_engine.py:27-64) -- along several
+routes: fresh rays of a plane source through the footprint map (k_s_cull + k_s_fresh, csrc/trc_footprint.h) or through the
+general path (k_s_gen + k_s_walk + k_s_exact), continued rays through k_s_bounce or the general path, the megakernel as a third
+form.  Every draw is a pure function of (seed, ray, event), so all routes must agree ray for ray: hit counts per surface are
+compared exactly, energies to the order-of-summation noise of float64 atomics (1e-9).
+"""
+import ctypes as C
+import os
+
+import numpy as N
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from tracer_amd import _cabi
+    return _cabi.get_context(0)
+
+
+class env(object):
+    """environment knobs of the library for the duration of a block (read at every call)"""
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = dict((k, os.environ.get(k)) for k in self.kw)
+        for k, v in self.kw.items():
+            os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _trace(ctx, cs, bundle, reps=20, accel=True, stream=True, kd=None, fluxmap=None, hit_capacity=0, **knobs):
+    from tracer_amd.scene import DeviceScene
+    with env(**knobs):
+        dev = DeviceScene(cs, ctx)
+        if kd is not None:
+            dev.set_kdtree(kd)
+        if fluxmap is not None:
+            dev.set_fluxmap(*fluxmap)
+        if hit_capacity:
+            dev.set_hit_capacity(hit_capacity)
+        st, _ = dev.trace_fast(bundle(), reps, 1e-10, 1, accel=accel, stream=stream)
+        a, r, h = dev.get_tallies()
+        out = dict(a=a.copy(), r=r.copy(), h=h.copy(), segments=st.segments, hits=st.hits, launches=st.launches)
+        if fluxmap is not None:
+            out['fm'] = dev.get_fluxmap(fluxmap[0]).copy()
+        if hit_capacity:
+            out['captured'] = dev.get_hits()
+        dev.close()
+    return out
+
+
+def _same(x, y, what=''):
+    assert N.array_equal(x['h'], y['h']), what
+    assert x['segments'] == y['segments'] and x['hits'] == y['hits'], what
+    assert N.allclose(x['a'], y['a'], rtol=1e-9, atol=1e-12) and N.allclose(x['r'], y['r'], rtol=1e-9, atol=1e-12), what
+    if 'fm' in x:
+        assert N.allclose(x['fm'], y['fm'], rtol=1e-9, atol=1e-12), what
+
+
+def test_source_start_points_float32_vs_float64(ctx):
+    """
+    The culling kernel decides from a float32 start point; the footprint map allows it eps = 1e-4 of the source's half extent
+    from the float64 one (trc_footprint.h).  On the device (v_sqrt_f32 / v_sin_f32 / v_cos_f32): every source kind the map
+    applies to, 2e6 rays each, the largest difference must stay below a tenth of eps.
+    """
+    from tracer_amd import _cabi, sources
+    direction = N.r_[0.3, -0.2, -1.] / N.linalg.norm([0.3, -0.2, -1.])
+    center = N.c_[[3., -2., 40.]]
+    cases = [sources.buie_sunshape(10, center, direction, 163., 0.01, flux=1., seed=1),
+             sources.rect_buie_sunshape(10, center, direction, 17., 15., 0.1, flux=1., seed=1),
+             sources.disk_bundle(10, center, direction, 9., 0.004, flux=1., radius_in=2., angular_span=[0.3, 5.1], seed=1),
+             sources.rect_bundle(10, center, direction, 16., 13., 0.01, flux=1., seed=1),
+             sources.rect_bundle(10, center, N.r_[0., 0., -1.], 16., 13., 0.01, flux=1., seed=1)]
+    n = 2000000
+    for k, b in enumerate(cases):
+        desc = b.source_args()[0]
+        lx, ly = N.empty(n, dtype=N.float32), N.empty(n, dtype=N.float32)
+        eps = C.c_double(0.)
+        f32 = C.POINTER(C.c_float)
+        _cabi.check(ctx.lib.trc_source_start32(ctx.handle, C.byref(desc), n, 77, 10 ** 9, lx.ctypes.data_as(f32), ly.ctypes.data_as(f32), C.byref(eps)))
+        v = N.empty((3, n)); d = N.empty((3, n)); e = N.empty(n)
+        rays = _cabi.make_rays(n, v[0], v[1], v[2], d[0], d[1], d[2], e)
+        _cabi.check(ctx.lib.trc_source_generate(ctx.handle, C.byref(desc), n, 77, 10 ** 9, C.byref(rays)))
+        rot = N.array(list(desc.rot_pos)).reshape(3, 3)
+        loc = N.dot(rot.T, v - N.array(list(desc.center))[:, None])
+        err = max(N.abs(loc[0] - lx).max(), N.abs(loc[1] - ly).max())
+        assert eps.value > 0 and err < 0.1 * eps.value, (k, err, eps.value)
+    # a source the map does not apply to says so
+    wide = sources.disk_bundle(10, center, direction, 9., 1.2, flux=1., seed=1).source_args()[0]
+    lx = N.empty(4, dtype=N.float32)
+    rc = ctx.lib.trc_source_start32(ctx.handle, C.byref(wide), 4, 1, 0, lx.ctypes.data_as(C.POINTER(C.c_float)), lx.ctypes.data_as(C.POINTER(C.c_float)), None)
+    assert rc == _cabi.ERR_UNSUPPORTED
+
+
+def test_fresh_and_bounce_kernels_equal_the_general_path_nsttf(ctx):
+    """
+    NSTTF, 4e6 rays (two batches would need 2^23; one batch here): the default route (footprint map + k_s_bounce), the general
+    path for the fresh rays (TRC_STREAM_FRESH=0), for the continued rays (TRC_STREAM_BOUNCE=0), for both, the Kd walk of the
+    queues (TRC_STREAM_SEARCH=1), brute force, and the megakernel: identical hit counts per surface, tallies and flux map.
+    """
+    from tracer_amd import scenes
+    from tracer_amd.accel_tree import KdTree
+    from tracer_amd.scene import compile_scene
+    plant, field, rec, src = scenes.nsttf_field()
+    cs = compile_scene(plant)
+    kd = KdTree(plant, 8 + 1.3 * N.log(cs.n_surf), min_leaf=1)
+    ue, ve = scenes.nsttf_fluxmap_edges()
+    n = 4000000
+    bundle = lambda: scenes.nsttf_source(n, src, seed=5, ray_offset=123456789)
+    kw = dict(kd=kd, fluxmap=(218, ue, ve), reps=100)
+    ref = _trace(ctx, cs, bundle, **kw)
+    assert ref['h'][218] > 0.06 * n and ref['h'][:218].sum() > 0.06 * n and ref['segments'] > 1.06 * n
+    assert N.isclose(ref['fm'].sum(), ref['a'][218], rtol=1e-9)
+    _same(ref, _trace(ctx, cs, bundle, TRC_STREAM_FRESH=0, **kw), 'fresh rays on the general path')
+    _same(ref, _trace(ctx, cs, bundle, TRC_STREAM_BOUNCE=0, **kw), 'continued rays on the general path')
+    _same(ref, _trace(ctx, cs, bundle, TRC_STREAM_FRESH=0, TRC_STREAM_BOUNCE=0, **kw), 'general path only')
+    _same(ref, _trace(ctx, cs, bundle, TRC_STREAM_SEARCH=1, **kw), 'Kd walk')
+    _same(ref, _trace(ctx, cs, bundle, TRC_STREAM_SEARCH=1, TRC_STREAM_FRESH=0, **kw), 'Kd walk, general path')
+    _same(ref, _trace(ctx, cs, bundle, accel=False, **kw), 'all boxes (accel=False)')
+    _same(ref, _trace(ctx, cs, bundle, accel=False, TRC_STREAM_FRESH=0, TRC_STREAM_BOUNCE=0, **kw), 'all boxes, general path')
+    _same(ref, _trace(ctx, cs, bundle, stream=False, **kw), 'megakernel')
+    _same(ref, _trace(ctx, cs, bundle, TRC_STREAM_FP_CELLS=128, **kw), 'coarser footprint map')
+    _same(ref, _trace(ctx, cs, bundle, TRC_STREAM_STATIC=0, **kw), 'no pre-assigned chunks')
+
+
+def _mixed_scene(seed, n_obj=24, flat_only=False):
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM, RoundPlateGM
+    from tracer_amd.paraboloid import ParabolicDishGM
+    from tracer_amd.sphere_surface import HemisphereGM
+    from tracer_amd.cylinder import FiniteCylinder
+    from tracer_amd.triangular_face import TriangularFace
+    from tracer_amd import optics_callables as opt
+    from tracer_amd.spatial_geometry import translate, rotx, roty, rotz
+    rng = N.random.RandomState(seed)
+    objs = []
+    for k in range(n_obj):
+        if flat_only:
+            gm = [RectPlateGM(1.6, 0.9), RoundPlateGM(0.8), TriangularFace(N.c_[[1.2, 0., 0.], [0.2, 1.1, 0.]])][k % 3]
+        else:
+            gm = [RectPlateGM(1.6, 0.9), RoundPlateGM(0.8), ParabolicDishGM(1.6, 1.1), HemisphereGM(0.6), FiniteCylinder(0.8, 1.2)][k % 5]
+        o = [opt.Reflective(0.1), opt.RealReflective(0.2, 3e-3), opt.LambertianReceiver(0.6), opt.Reflective(0.05)][k % 4]
+        tr = N.dot(translate(*rng.uniform(-5, 5, 3)), N.dot(rotx(rng.uniform(0, 6.3)), N.dot(roty(rng.uniform(0, 6.3)), rotz(rng.uniform(0, 6.3)))))
+        objs.append(AssembledObject(surfs=[Surface(gm, o)], transform=tr))
+    return Assembly(objects=objs)
+
+
+def test_fresh_and_bounce_kernels_on_mixed_scenes_and_sources(ctx):
+    """
+    Scenes of mixed kinds (the general instance of k_s_fresh: quadrics, spheres, cylinders) and of flat kinds only (its flat
+    instance: plates, discs, triangles), under every source kind the footprint map applies to, a Buie source with a strong
+    aureole (CSR 0.3: a third of the rays take the general path, listed per wave) and an oblique source: default route against
+    the general path and the megakernel over 12 bounces.
+    """
+    from tracer_amd import sources
+    from tracer_amd.scene import compile_scene
+    direction = N.r_[0.25, -0.15, -1.] / N.linalg.norm([0.25, -0.15, -1.])
+    center = N.c_[-30. * direction]
+    n = 1500000
+    srcs = [lambda s: sources.buie_sunshape(n, center, direction, 9., 0.05, flux=1., seed=s),
+            lambda s: sources.buie_sunshape(n, center, direction, 9., 0.3, flux=1., seed=s),
+            lambda s: sources.rect_buie_sunshape(n, center, direction, 17., 15., 0.02, flux=1., seed=s),
+            lambda s: sources.disk_bundle(n, center, direction, 9., 0.006, flux=1., radius_in=1., angular_span=[0.2, 6.0], seed=s),
+            lambda s: sources.rect_bundle(n, center, direction, 16., 14., 0.01, flux=1., seed=s),
+            lambda s: sources.oblique_solar_rect_bundle(n, N.c_[[-7.5, 4.5, 30.]], N.r_[0., 0., -1.], direction, 22., 20., 0.008, flux=1., seed=s)]
+    for flat_only in (False, True):
+        cs = compile_scene(_mixed_scene(3 + flat_only, flat_only=flat_only))
+        for k, make in enumerate(srcs):
+            bundle = lambda: make(40 + k)
+            ref = _trace(ctx, cs, bundle, reps=12)
+            assert ref['hits'] > 0.02 * n and ref['segments'] > n, (flat_only, k)
+            _same(ref, _trace(ctx, cs, bundle, reps=12, TRC_STREAM_FRESH=0, TRC_STREAM_BOUNCE=0), ('general', flat_only, k))
+            _same(ref, _trace(ctx, cs, bundle, reps=12, stream=False), ('megakernel', flat_only, k))
+            if k in (0, 4):
+                _same(ref, _trace(ctx, cs, bundle, reps=12, accel=False), ('all boxes', flat_only, k))
+
+
+def test_list_overflows_are_reported_and_leave_no_trace(ctx):
+    """
+    The lists of the engine (ray table, footprint list, general-path list, walker queue, hit list, active list) are sized for
+    the batch plus room for the chunks' unused tails; whatever overflows one sets flag 2 and the call ends with
+    TRC_ERR_CAPACITY before anything reads beyond an allocation.  TRC_STREAM_ROOM (entries per list) provokes it on each
+    route.  A failed call leaves nothing behind: the next call on the same scene gives what a fresh scene gives, tallies, flux
+    map and captured hits alike (the private tally copies and the open chunks of the hit buffer are wound back).
+    """
+    from tracer_amd import _cabi, scenes
+    from tracer_amd.accel_tree import KdTree
+    from tracer_amd.scene import compile_scene, DeviceScene
+    plant, field, rec, src = scenes.nsttf_field(n_heliostats=30)
+    cs = compile_scene(plant)
+    kd = KdTree(plant, 8 + 1.3 * N.log(cs.n_surf), min_leaf=1)
+    ue, ve = scenes.nsttf_fluxmap_edges()
+    n = 600000
+    bundle = lambda: scenes.nsttf_source(n, src, seed=9)
+    good = _trace(ctx, cs, bundle, kd=kd, fluxmap=(30, ue, ve), reps=100, hit_capacity=n)
+    assert good['h'][30] > 1000 and len(good['captured']['surf']) == good['h'][30]
+    # too little room on every route (TRC_STREAM_ROOM: entries of the ray table and of each list, instead of cap + slack)
+    for knobs in (dict(), dict(TRC_STREAM_FRESH=0), dict(TRC_STREAM_BOUNCE=0), dict(TRC_STREAM_STATIC=0)):
+        with env(TRC_STREAM_ROOM=2048, **knobs):
+            dev = DeviceScene(cs, ctx)
+            dev.set_kdtree(kd)
+            dev.set_fluxmap(30, ue, ve)
+            dev.set_hit_capacity(n)
+            with pytest.raises(_cabi.TracerAmdError) as ei:
+                dev.trace_fast(bundle(), 100, 1e-10, 1, accel=True, stream=True)
+            assert ei.value.status == _cabi.ERR_CAPACITY, knobs
+        # the same scene, room as usual: nothing of the failed call is left
+        st, _ = dev.trace_fast(bundle(), 100, 1e-10, 1, accel=True, stream=True)
+        a, r, h = dev.get_tallies()
+        assert N.array_equal(h, good['h']) and N.allclose(a, good['a'], rtol=1e-9, atol=1e-12), knobs
+        assert N.allclose(dev.get_fluxmap(30), good['fm'], rtol=1e-9, atol=1e-12), knobs
+        cap = dev.get_hits()
+        assert len(cap['surf']) == good['h'][30] and N.isclose(cap['e_abs'].sum(), good['a'][30], rtol=1e-9), knobs
+        dev.close()
+
+
+def test_full_size_routes_agree(ctx):
+    """
+    configs[2] / configs[3] at their real size: 1e8 NSTTF source rays (two batches of 5e7 in flight) and the per-GPU share of
+    the 8-GPU job, 1.25e8 (two batches of 6.25e7 < 2^26), through the default route; the same 1e8 on the Kd walk of the queues
+    (configs[3] names accel_tree's traversal) and by brute force must give identical hit counts; flux map == receiver tally;
+    the receiver's power within 3 sigma of the reference's own Monte-Carlo runs (tests/golden/mc_reference.npz).
+    """
+    from helpers import load
+    from tracer_amd import scenes
+    from tracer_amd.accel_tree import KdTree
+    from tracer_amd.scene import compile_scene
+    plant, field, rec, src = scenes.nsttf_field()
+    cs = compile_scene(plant)
+    kd = KdTree(plant, 8 + 1.3 * N.log(cs.n_surf), min_leaf=1)
+    ue, ve = scenes.nsttf_fluxmap_edges()
+    mc = load('mc_reference.npz')
+    p_ref, se_ref = float(mc['nsttf_receiver_mean']), float(mc['nsttf_receiver_se'])
+    out = {}
+    for n in (100000000, 125000000):
+        bundle = lambda: scenes.nsttf_source(n, src, seed=2024, ray_offset=7 * n)
+        res = _trace(ctx, cs, bundle, kd=kd, fluxmap=(218, ue, ve), reps=100, stream=None)
+        out[n] = res
+        e_ray = 1000. * N.pi * src['radius'] ** 2 / n
+        assert res['launches'] > 1                                                  # the streaming form, by default at this size
+        assert n <= res['segments'] <= n + res['h'][:218].sum()
+        assert N.isclose(res['fm'].sum(), res['a'][218], rtol=1e-9)
+        # receiver hits carry 0.96 e_ray (one mirror) -- at most e_ray: the standard error of the sum from its own count
+        se_gpu = e_ray * N.sqrt(res['h'][218])
+        assert abs(res['a'][218] - p_ref) <= 3. * N.sqrt(se_gpu ** 2 + se_ref ** 2), (n, res['a'][218], p_ref)
+    n = 100000000
+    bundle = lambda: scenes.nsttf_source(n, src, seed=2024, ray_offset=7 * n)
+    _same(out[n], _trace(ctx, cs, bundle, kd=kd, fluxmap=(218, ue, ve), reps=100, stream=None, TRC_STREAM_SEARCH=1, TRC_STREAM_FRESH=0), 'Kd walk, 1e8')
+    _same(out[n], _trace(ctx, cs, bundle, kd=kd, fluxmap=(218, ue, ve), reps=100, stream=None, accel=False), 'brute force, 1e8')

@@ -18,6 +18,8 @@ TRC_BUIE_NELEM = 210
 BUIE_LEN = 3 * (TRC_BUIE_NELEM + 1) + 6
 
 # trace flags
+# trc_status
+OK, ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_NOMEM = 0, -1, -2, -3, -4, -5
 TRACE_ACCEL = 0x1
 TRACE_KEEP_LAST = 0x2
 BIN_ANGLE, BIN_HEIGHT, BIN_RADIUS, BIN_ROUND9, BIN_RADIUS_HALF_OPEN = 0x1, 0x2, 0x4, 0x8, 0x10      # trc_scene_bin_hits modes
@@ -116,6 +118,8 @@ SIGNATURES = {
     'trc_result_level_get': (C.c_int, [_vp, C.c_int32, C.POINTER(Rays), _p_i32]),
     'trc_result_destroy': (C.c_int, [_vp]),
     'trc_source_generate': (C.c_int, [_vp, C.POINTER(SourceDesc), C.c_int64, C.c_uint64, C.c_uint64, C.POINTER(Rays)]),
+    'trc_source_start32': (C.c_int, [_vp, C.POINTER(SourceDesc), C.c_int64, C.c_uint64, C.c_uint64, C.POINTER(C.c_float),
+                                     C.POINTER(C.c_float), _p_f64]),
     'trc_gm_find_intersections': (C.c_int, [_vp, C.POINTER(SurfaceDesc), C.c_int32, _p_f64, C.POINTER(Rays), _p_f64,
                                             _p_f64, _p_f64, _p_f64]),
     'trc_gm_get_normals': (C.c_int, [_vp, C.POINTER(SurfaceDesc), C.c_int64] + [_p_f64] * 9),

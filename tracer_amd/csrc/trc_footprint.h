@@ -148,21 +148,12 @@ static inline void trc_fp_hull(std::vector<std::pair<double, double>> pts, std::
     for (auto &p : h) { hx.push_back(p.first); hy.push_back(p.second); }
 }
 
-// A: trc_accel_build_surfaces of the same surfaces.  M: mask cells per side (a multiple of 32 << TRC_FP_SHIFT is not needed,
-// a multiple of 32 is).
-static inline void trc_fp_build(const trc_surface_desc *surfs, int n_surf, const trc_accel_host &A, const trc_source_desc &src,
-                                trc_fp_host &F, int M = 512) {
-    F.ok = false;
-    F.why = "";
-    F.mask.clear(); F.coff.clear(); F.clist.clear();
-    F.coverage = 1.0;
-    memset(&F.P, 0, sizeof(F.P));
-    if (n_surf > 65535) { F.why = "more than 65535 surfaces"; return; }
-    if (!A.unbounded.empty()) { F.why = "the scene has unbounded surfaces"; return; }
-    if (!A.any_bounded) { F.why = "no bounded surface"; return; }
+// The source's part of the map: kind, extent of the start shape (half), float32 mapping parameters, the cone's half angle.
+// Returns false (reason in *why) for a source the map does not apply to.
+static inline bool trc_fp_source(const trc_source_desc &src, trc_fp_params &P, double *half_out, double *theta_c_out, const char **why) {
+    memset(&P, 0, sizeof(P));
     const double *p = src.p;
     double half = 0.0, theta_c = 0.0;
-    trc_fp_params &P = F.P;
     P.kind = src.kind;
     switch (src.kind) {
     case TRC_SRC_BUIE_DISK: {
@@ -180,7 +171,7 @@ static inline void trc_fp_build(const trc_surface_desc *surfs, int n_surf, const
         break;
     }
     case TRC_SRC_PILLBOX_DISK:
-        if (p[5] != 0.0) { F.why = "disc source with x_cut (positions are redrawn)"; return; }
+        if (p[5] != 0.0) { *why = "disc source with x_cut (positions are redrawn)"; return false; }
         half = std::fmax(std::fabs(p[0]), std::fabs(p[1])); theta_c = p[4];
         P.p[0] = (float)(p[1] * p[1]); P.p[1] = (float)(p[0] * p[0] - p[1] * p[1]);
         P.p[2] = (float)(p[2] / TRC_TWO_PI); P.p[3] = (float)((p[3] - p[2]) / TRC_TWO_PI);
@@ -190,9 +181,29 @@ static inline void trc_fp_build(const trc_surface_desc *surfs, int n_surf, const
         P.p[0] = (float)p[0]; P.p[1] = (float)p[1]; P.p[2] = p[3] != 0.0 ? 1.0f : 0.0f;
         break;
     default:
-        F.why = "source kind without a plane start shape"; return;
+        *why = "source kind without a plane start shape"; return false;
     }
-    if (!(half > 0.0) || !std::isfinite(half) || !(theta_c >= 0.0) || !(theta_c < 0.5)) { F.why = "cone too wide (or degenerate source)"; return; }
+    if (!(half > 0.0) || !std::isfinite(half) || !(theta_c >= 0.0) || !(theta_c < 0.5)) { *why = "cone too wide (or degenerate source)"; return false; }
+    P.half = (float)half;
+    *half_out = half; *theta_c_out = theta_c;
+    return true;
+}
+
+// A: trc_accel_build_surfaces of the same surfaces.  M: mask cells per side (a multiple of 32 << TRC_FP_SHIFT is not needed,
+// a multiple of 32 is).
+static inline void trc_fp_build(const trc_surface_desc *surfs, int n_surf, const trc_accel_host &A, const trc_source_desc &src,
+                                trc_fp_host &F, int M = 512) {
+    F.ok = false;
+    F.why = "";
+    F.mask.clear(); F.coff.clear(); F.clist.clear();
+    F.coverage = 1.0;
+    memset(&F.P, 0, sizeof(F.P));
+    if (n_surf > 65535) { F.why = "more than 65535 surfaces"; return; }
+    if (!A.unbounded.empty()) { F.why = "the scene has unbounded surfaces"; return; }
+    if (!A.any_bounded) { F.why = "no bounded surface"; return; }
+    double half = 0.0, theta_c = 0.0;
+    trc_fp_params &P = F.P;
+    if (!trc_fp_source(src, P, &half, &theta_c, &F.why)) return;
     const double *rp = src.rot_pos, *rd = src.rot_dir;
     const double e1[3] = {rp[0], rp[3], rp[6]}, e2[3] = {rp[1], rp[4], rp[7]}, w[3] = {rd[2], rd[5], rd[8]};
     auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };

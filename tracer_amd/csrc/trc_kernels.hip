@@ -1025,6 +1025,19 @@ __global__ __launch_bounds__(256) void k_source_generate(const trc_source_desc *
     }
 }
 
+// float32 start points as k_s_cull evaluates them (trc_source_start32)
+__global__ __launch_bounds__(256) void k_source_start32(trc_fp_params F, long long n, unsigned long long seed, unsigned long long offset,
+                                                        float *lx, float *ly) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long rid = offset + (unsigned long long)i;
+        uint32_t o[4];
+        trc_philox4x32_10((uint32_t)rid, (uint32_t)(rid >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        float x, y;
+        trc_fp_position32(F, o, &x, &y);
+        lx[i] = x; ly[i] = y;
+    }
+}
+
 // ================================================================================================
 // ordered engine
 // ================================================================================================
@@ -2138,6 +2151,33 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
 // ================================================================================================
 // C-ABI: source generation
 // ================================================================================================
+extern "C" int trc_source_start32(trc_ctx *ctx, const trc_source_desc *src, int64_t n, uint64_t seed, uint64_t ray_offset,
+                                  float *lx, float *ly, double *eps) {
+    if (!ctx || !src || n < 0 || !lx || !ly) return trc_fail(TRC_ERR_INVALID, "trc_source_start32: bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    trc_fp_params F;
+    double half = 0.0, theta_c = 0.0;
+    const char *why = "";
+    if (!trc_fp_source(*src, F, &half, &theta_c, &why)) return trc_fail(TRC_ERR_UNSUPPORTED, "no footprint map for this source: %s", why);
+    if (eps) *eps = TRC_FP_EPS_REL * half;
+    if (n == 0) return TRC_OK;
+    float *d[2] = {nullptr, nullptr};
+    int st = TRC_OK;
+    do {
+        if ((st = dev_alloc(&d[0], (size_t)n)) || (st = dev_alloc(&d[1], (size_t)n))) break;
+        long long grid = (n + 255) / 256;
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(k_source_start32, dim3((unsigned)grid), dim3(256), 0, ctx->stream, F, (long long)n, (unsigned long long)seed,
+                           (unsigned long long)ray_offset, d[0], d[1]);
+        hipError_t se = hipStreamSynchronize(ctx->stream);
+        if (se != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "k_source_start32 failed: %s", hipGetErrorString(se)); break; }
+        if (hipMemcpy(lx, d[0], (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(ly, d[1], (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            st = trc_fail(TRC_ERR_DEVICE, "memcpy failed");
+    } while (0);
+    dev_free(d[0]); dev_free(d[1]);
+    return st;
+}
+
 extern "C" int trc_source_generate(trc_ctx *ctx, const trc_source_desc *src, int64_t n, uint64_t seed,
                                    uint64_t ray_offset, trc_rays *out) {
     if (!ctx || !src || n < 0) return trc_fail(TRC_ERR_INVALID, "trc_source_generate: bad arguments");
