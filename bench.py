@@ -14,7 +14,13 @@ exchange is ONE all-reduce (RCCL) of the packed tally buffer at the end of the j
 
 Prints ONE JSON line on rank 0: metric/value/unit per BASELINE.json, plus
   roofline      algorithmic HBM bytes of the fast engine (112 B per ray segment) over the time of its
-                kernels for one step, measured with HIP events on the launch stream, against the 8 TB/s HBM peak
+                kernels for one step, measured with HIP events on the launch stream, against the 8 TB/s HBM peak;
+                `traffic` = HBM bytes per step from the rocprofv3 PMC passes kept in profiles/traffic.json
+  api_level     the same step through the public entry point, TracerEngine.ray_tracer(tree=False, accel=True): scene
+                signature check, hit buffer sized by the engine, receiver hits fetched and fed to the accountants
+                (N=1 only, after the timed region; `value` above is the C-ABI call trc_trace_fast)
+  check         receiver power, hit fractions; the process exits with status 3 when the receiver power is more than
+                5 sigma from the reference's own Monte-Carlo mean (tests/golden/mc_reference.npz)
   cpu_baseline  the oracle (NumPy restatement of the reference's algorithm = the reference's own CPU path, which
                 is NumPy too) timed on this host's cores (one process per core, independent batches) on a bounded
                 sample of the same workload, rank 0 at N=1 only, before the GPU part starts.
@@ -86,6 +92,20 @@ def cpu_baseline(n_rays, workers, batches):
                 receiver_kW=sum(r['receiver_kW'] for r in res) / len(res))
 
 
+def traffic_for(n, accel):
+    """HBM bytes per step from the committed PMC passes (profiles/traffic.json, made by tools/pmc_traffic.py on this workload):
+    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, the same with FETCH_SIZE as counted), or (None, None) when the
+    passes were taken on another workload"""
+    tf = os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        tj = json.load(open(tf))
+        if int(tj.get('rays_per_launch', 0)) == int(n) and bool(tj.get('accel', True)) == bool(accel):
+            return tj.get('hbm_bytes_per_launch'), tj.get('hbm_bytes_per_launch_fetch_as_counted')
+    except Exception:
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -96,6 +116,7 @@ def main():
     ap.add_argument('--cpu-batches', type=int, default=6, help='bundles traced by every CPU baseline worker')
     ap.add_argument('--cpu-workers', type=int, default=0, help='CPU baseline processes (0 = one per core, at most 16)')
     ap.add_argument('--cpu-worker', nargs=3, metavar=('RAYS', 'SEED', 'BATCHES'), help=argparse.SUPPRESS)
+    ap.add_argument('--api-steps', type=int, default=2, help='steps timed through TracerEngine.ray_tracer (N=1 only; 0 = skip)')
     ap.add_argument('--no-accel', action='store_true', help='brute force instead of the accelerated candidate search')
     ap.add_argument('--kernel', choices=['auto', 'stream', 'megakernel'], default='auto',
                     help='fast-engine form: streaming kernels (default at this size) or the single persistent kernel')
@@ -105,6 +126,7 @@ def main():
         print(json.dumps(cpu_worker(int(args.cpu_worker[0]), int(args.cpu_worker[1]), int(args.cpu_worker[2]))), flush=True)
         return
 
+    exit_code = 0
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -189,23 +211,38 @@ def main():
     else:
         total_segments, dt_max = float(seg), dt
 
+    api = None
     if rank == 0:
         a, r, h = dev.get_tallies()
         fm = dev.get_fluxmap(218)
+        if world == 1 and args.api_steps > 0 and args.kernel == 'auto':
+            # the public entry point on the same workload (a scene of its own: the engine compiles the assembly itself)
+            dev.close()
+            dev = None
+            from tracer_amd.tracer_engine import TracerEngine
+            eng = TracerEngine(plant)
+            eng.set_fluxmap(218, ue, ve)
+            mk = lambda k: scenes.nsttf_source(n, src, seed=2024, ray_offset=(args.steps + args.warmup + 1 + k) * n)
+            eng.ray_tracer(mk(0), reps=100, min_energy=1e-10, tree=False, accel=accel, seed=2024)       # warm-up: allocations, Kd-tree
+            plant.reset_all_optics()
+            torch.cuda.synchronize()
+            t1 = time.time()
+            aseg = 0
+            for k in range(args.api_steps):
+                eng.ray_tracer(mk(1 + k), reps=100, min_energy=1e-10, tree=False, accel=accel, seed=2024)
+                aseg += eng.stats['segments']
+                plant.reset_all_optics()           # the accountants' lists of the step (filled from the device hit buffer)
+            torch.cuda.synchronize()
+            adt = time.time() - t1
+            api = {'entry': 'TracerEngine.ray_tracer(bundle, reps=100, min_energy=1e-10, tree=False, accel=%r)' % accel,
+                   'steps': args.api_steps, 'ms_per_step': adt / args.api_steps * 1e3, 'value': aseg / adt / 1e6, 'unit': 'Mray-bounces/s',
+                   'includes': 'scene signature check, hit buffer of 2n+1024 entries cleared, trc_trace_fast, %d receiver hits per step '
+                               'copied to the host and fed to the receiver\'s accountants' % int(h[218] / max(args.steps, 1))}
         total_rays = float(n) * args.steps * world
         e_ray = 1000. * N.pi * src['radius'] ** 2 / n        # energy per ray of ONE step's bundle
         receiver_kw = a[218] / args.steps / world / 1e3       # mean over the independent batches
         ach = (seg * B_SEG / 1e9) / (kms / 1e3) if kms > 0 else 0.0     # GB/s, this rank's launches
-        traffic = None
-        tf = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tf):
-            try:
-                tj = json.load(open(tf))
-                # the PMC passes were taken on the default workload (1e8 rays per launch, Kd-tree)
-                if int(tj.get('rays_per_launch', 0)) == n and accel:
-                    traffic = tj.get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
+        traffic, traffic_raw = traffic_for(n, accel)
         out = {
             'metric': 'Mray-bounces/s on Sandia NSTTF field',
             'value': total_segments / dt_max / 1e6,
@@ -222,22 +259,44 @@ def main():
                        'rays_per_step_per_gpu': n, 'segments_per_step_per_gpu': seg / args.steps, 'accel': accel,
                        'parallelism': 'rays sharded by stream id over %d GPU(s), one all-reduce of tallies at the end' % world},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                         'traffic': traffic,
+                         'traffic': traffic, 'traffic_fetch_as_counted': traffic_raw,
                          'kernel': 'k_trace_coop<512>' if launches == 1 else
-                                   'fast engine, streaming form: k_s_gen + k_s_walk<256,grid> + k_s_exact + k_s_shade per '
-                                   'bounce (%d launches per step)' % launches,
+                                   'fast engine, streaming form: k_s_cull + k_s_fresh (+ the general path for the aureole) + k_s_shade, '
+                                   'then k_s_bounce + k_s_shade per bounce (%d launches per step)' % launches,
                          'kernel_ms_per_launch': kms / args.steps,
                          'algorithmic_bytes_per_launch': seg / args.steps * B_SEG},
             'check': {'receiver_kW': receiver_kw, 'receiver_hits_per_ray': h[218] / total_rays,
                       'heliostat_hits_per_ray': float(h[:218].sum()) / total_rays,
                       'fluxmap_sum_kW': float(fm.sum()) / args.steps / world / 1e3, 'energy_per_ray_W': e_ray},
         }
+        out['api_level'] = api
         out['cpu_baseline'] = cpu
+        # the reference's own Monte-Carlo mean of the receiver power (10 runs of 1e5 rays): 5 sigma of both estimates
+        ok = True
+        try:
+            mc = N.load(os.path.join(ROOT, 'tests', 'golden', 'mc_reference.npz'))
+            p_ref, se_ref = float(mc['nsttf_receiver_mean']) / 1e3, float(mc['nsttf_receiver_se']) / 1e3
+            se_gpu = e_ray * N.sqrt(max(h[218], 1.)) / (args.steps * world) / 1e3
+            sig = float(N.sqrt(se_ref ** 2 + se_gpu ** 2))
+            out['check']['reference_receiver_kW'] = p_ref
+            out['check']['sigma_kW'] = sig
+            out['check']['deviation_sigma'] = abs(receiver_kw - p_ref) / sig
+            ok = abs(receiver_kw - p_ref) <= 5. * sig and abs(float(fm.sum()) / args.steps / world / 1e3 - receiver_kw) <= 1e-6 * receiver_kw
+            out['check']['ok'] = bool(ok)
+        except Exception as err:        # no fixture: nothing to compare with
+            out['check']['ok'] = None
+            log('check skipped: %s' % err)
         print(json.dumps(out), flush=True)
-    dev.close()
+        if not ok:
+            log('CHECK FAILED: receiver power %.1f kW vs reference %.1f kW' % (receiver_kw, out['check'].get('reference_receiver_kW', float('nan'))))
+            exit_code = 3
+    if dev is not None:
+        dev.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == '__main__':

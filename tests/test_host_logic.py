@@ -234,3 +234,15 @@ def test_host_direction_samplers_equal_reference():
     b = sources.edge_rays_bundle(300, N.c_[[1., 2., 3.]], N.r_[0., 0.6, 0.8], 2., 0.2, flux=10., radius_in=0.5)
     assert N.allclose(b.get_vertices(), g['edge_bundle_vertices'], atol=1e-13) and N.allclose(b.get_directions(), g['edge_bundle_directions'], atol=1e-13)
     assert N.allclose(b.get_energy(), g['edge_bundle_energy'])
+
+
+def test_bench_reports_the_committed_traffic():
+    """bench.py's roofline.traffic comes from profiles/traffic.json: the committed passes must be those of the default workload"""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    hi, lo = bench.traffic_for(1e8, True)
+    assert hi is not None and lo is not None and 1e9 < lo <= hi < 2 * lo
+    assert bench.traffic_for(1e7, True) == (None, None) and bench.traffic_for(1e8, False) == (None, None)

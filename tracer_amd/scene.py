@@ -296,7 +296,9 @@ class DeviceScene(object):
                                ref_index=cols.get('ref_index'), wavelength=cols.get('wavelength'))
         return rays, None, n, None, 0, cols
 
-    def trace_fast(self, bundle, reps, min_energy, seed, accel=False, keep_last=False, stream=None):
+    def trace_fast(self, bundle, reps, min_energy, seed, accel=False, keep_last=False, stream=None, last_capacity=None):
+        """last_capacity: room for the rays still alive after `reps` interactions (keep_last); None = one per ray.  More rays
+        left than that is a TracerAmdError with status ERR_CAPACITY."""
         rays, src, n, src_seed, off, keep = self._bundle_args(bundle)
         if src_seed is not None:
             seed = src_seed
@@ -306,8 +308,9 @@ class DeviceScene(object):
         last = None
         last_cols = None
         if keep_last:
-            last_cols = [N.empty(n) for _ in range(7)]
-            last = _cabi.make_rays(n, *last_cols)
+            m = n if last_capacity is None else max(1, min(int(last_capacity), n))
+            last_cols = [N.empty(m) for _ in range(7)]
+            last = _cabi.make_rays(m, *last_cols)
         _cabi.check(self.lib.trc_trace_fast(self.handle, C.byref(rays) if rays is not None else None,
                                             C.byref(src) if src is not None else None, n, int(reps), float(min_energy),
                                             int(seed), int(off), flags, C.byref(last) if last is not None else None,

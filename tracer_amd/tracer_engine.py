@@ -132,14 +132,17 @@ class TracerEngine(object):
         Trace `bundle` through the assembly for at most `reps` interactions per ray, dropping rays
         whose energy falls to `min_energy` or below.  accel: False, True, 'fast' or 'lightweight'
         (Kd-tree over the objects' BoundaryBoxes; 'lightweight' is accepted and gives the same results).
-        Extra keywords: engine ('auto'|'ordered'|'fast'|'protocol'), seed, hit_capacity, and the
+        Extra keywords: engine ('auto'|'ordered'|'fast'|'protocol'), seed, hit_capacity, last_capacity, and the
         KdTree keywords of the reference (min_leaf, t_trav, t_isec, empty_bonus).
+        tree=False records the last bundle only, like the reference (tracer_engine.py:288-291): its rays are those the call
+        returns, with their energies; the fast engine does not keep the bundle before it, so this record has no parents.
         """
         engine = kwargs.pop('engine', 'auto')
         seed = kwargs.pop('seed', None)
         hit_capacity = kwargs.pop('hit_capacity', None)
         fast_kernel = kwargs.pop('fast_kernel', 'auto')     # 'auto' | 'stream' | 'megakernel' (fast engine only)
         feed = kwargs.pop('feed', True)     # False: captured hits stay on the device (bin_hits), accountants are not fed
+        last_capacity = kwargs.pop('last_capacity', None)   # fast engine: room for the rays still alive after `reps` (see _trace_fast)
         if seed is None:
             seed = rng.next_seed()
         self.reps = reps
@@ -177,13 +180,13 @@ class TracerEngine(object):
         if engine == 'auto':
             engine = 'ordered' if (tree or dev.compiled.splits) else 'fast'
         if engine == 'fast':
-            return self._trace_fast(dev, bundle, reps, min_energy, seed, bool(accel), hit_capacity, fast_kernel, feed)
+            return self._trace_fast(dev, bundle, reps, min_energy, seed, bool(accel), hit_capacity, fast_kernel, feed, last_capacity)
         if engine == 'ordered':
             return self._trace_ordered(dev, bundle, reps, min_energy, seed, bool(accel), tree)
         raise ValueError("unknown engine %r" % (engine,))
 
     # -- fast engine --------------------------------------------------------------------------------
-    def _trace_fast(self, dev, bundle, reps, min_energy, seed, accel, hit_capacity, fast_kernel='auto', feed=True):
+    def _trace_fast(self, dev, bundle, reps, min_energy, seed, accel, hit_capacity, fast_kernel='auto', feed=True, last_capacity=None):
         n = bundle.get_num_rays()
         capture = any(dev.compiled.capture)
         if capture:
@@ -191,7 +194,12 @@ class TracerEngine(object):
             dev.lib.trc_scene_clear_hits(dev.handle)
         t0 = time.time()
         stream = {'auto': None, 'stream': True, 'megakernel': False}[fast_kernel]
-        stats, last = dev.trace_fast(bundle, reps, min_energy, seed, accel=accel, keep_last=True, stream=stream)
+        # Rays still alive after `reps` interactions come back as the call's result (tracer_engine.py:293-295).  Bundles beyond
+        # 2^24 rays get room for 2^22 of them unless the caller says otherwise (last_capacity=...): 1e8 rays would cost 5.6 GB
+        # of host arrays per call for a result that is empty in most scenes.  More rays left than room is an error of the
+        # call (status ERR_CAPACITY), raised after the trace: tallies and flux maps of the scene then hold it, the accountants do not.
+        cap = last_capacity if last_capacity is not None else (n if n <= (1 << 24) else (1 << 22))
+        stats, last = dev.trace_fast(bundle, reps, min_energy, seed, accel=accel, keep_last=True, stream=stream, last_capacity=cap)
         wall = time.time() - t0
         self._set_stats(stats, wall, 'fast')
         if stats.hits_dropped:
@@ -202,7 +210,10 @@ class TracerEngine(object):
             feed_accountants(dev.compiled.surfaces, h['surf'], h['e_in'], h['e_in'] - h['e_abs'], h['points'],
                              h['directions'])
         self._warn_left(stats.rays_left, stats.energy_left, bundle)
-        return N.vstack(last[0:3]), N.vstack(last[3:6])
+        vertices, directions = N.vstack(last[0:3]), N.vstack(last[3:6])
+        # "otherwise only register the last bundle" (tracer_engine.py:288-291): scripts read engine.tree[-1] after tree=False
+        self.tree.append(RayBundle(vertices=vertices, directions=directions, energy=N.asarray(last[6])))
+        return vertices, directions
 
     # -- ordered engine -----------------------------------------------------------------------------
     def _trace_ordered(self, dev, bundle, reps, min_energy, seed, accel, tree):
