@@ -265,7 +265,8 @@ def main():
                                    'then k_s_bounce + k_s_shade per bounce (%d launches per step)' % launches,
                          'kernel_ms_per_launch': kms / args.steps,
                          'algorithmic_bytes_per_launch': seg / args.steps * B_SEG},
-            'check': {'receiver_kW': receiver_kw, 'receiver_hits_per_ray': h[218] / total_rays,
+            'check': {'receiver_kW': receiver_kw, 'receiver_hits': int(h[218]), 'heliostat_hits': int(h[:218].sum()),
+                      'segments_total': int(round(total_segments)), 'receiver_hits_per_ray': h[218] / total_rays,
                       'heliostat_hits_per_ray': float(h[:218].sum()) / total_rays,
                       'fluxmap_sum_kW': float(fm.sum()) / args.steps / world / 1e3, 'energy_per_ray_W': e_ray},
         }

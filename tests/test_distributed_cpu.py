@@ -1,7 +1,9 @@
 """
 The N>1 path on CPU: two processes (gloo), rays sharded by stream id, one all-reduce of the tallies.
 The oracle stands in for the device engine (no GPU here); what is under test is the product's sharding and
-reduction logic and the stream-id design: the summed tallies of 2 ranks equal the single-process result.
+reduction logic (distributed.shard, reduce_scene_tallies' host branch on the packed tally buffer) and the stream-id design:
+the summed tallies of 2 ranks equal the single-process result.  tests/test_gpu_stream.py runs bench.py itself as two ranks
+on one GPU.
 """
 import os
 import sys
@@ -28,8 +30,28 @@ def _worker(rank, world, port, n_total, q):
     with N.errstate(all='ignore'):
         res = engine.trace_from_compiled(cs, b.source_args(), reps=20, min_energy=1e-10)
     scale = float(hi - lo) / n_total
-    packed = N.concatenate((res['absorbed'] * scale, res['received'] * scale, res['hits'].astype(float), [res['segments']]))
-    total = distributed.all_reduce_sum(packed)
+
+    class Tallies(object):
+        """what reduce_scene_tallies needs of a DeviceScene: the packed tally buffer [absorbed S | received S | count S | segments,
+        hits | ...] exported to and imported from the host (the gloo branch; the nccl branch hands device pointers over)"""
+        def __init__(self):
+            self.buf = N.concatenate((res['absorbed'] * scale, res['received'] * scale, res['hits'].astype(float),
+                                      [res['segments'], res['hits'].sum()]))
+
+        def tally_size(self):
+            return len(self.buf)
+
+        def export_tallies(self, out=None):
+            assert out is None          # host branch
+            return self.buf.copy()
+
+        def import_tallies(self, src):
+            assert isinstance(src, N.ndarray) and src.shape == self.buf.shape
+            self.buf = src.copy()
+
+    dev = Tallies()
+    distributed.reduce_scene_tallies(dev)
+    total = dev.buf
     if rank == 0:
         q.put(total)
     dist.barrier()
@@ -59,6 +81,6 @@ def test_two_rank_shards_sum_to_single_process():
         res = engine.trace_from_compiled(cs, b.source_args(), reps=20, min_energy=1e-10)
     S = cs.n_surf
     assert N.array_equal(total[2 * S:3 * S], res['hits'])
-    assert total[3 * S] == res['segments']
+    assert total[3 * S] == res['segments'] and total[3 * S + 1] == res['hits'].sum()
     assert N.allclose(total[:S], res['absorbed'], rtol=1e-12, atol=1e-9)
     assert N.allclose(total[S:2 * S], res['received'], rtol=1e-12, atol=1e-9)

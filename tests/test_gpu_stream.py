@@ -261,3 +261,82 @@ def test_full_size_routes_agree(ctx):
     bundle = lambda: scenes.nsttf_source(n, src, seed=2024, ray_offset=7 * n)
     _same(out[n], _trace(ctx, cs, bundle, kd=kd, fluxmap=(218, ue, ve), reps=100, stream=None, TRC_STREAM_SEARCH=1, TRC_STREAM_FRESH=0), 'Kd walk, 1e8')
     _same(out[n], _trace(ctx, cs, bundle, kd=kd, fluxmap=(218, ue, ve), reps=100, stream=None, accel=False), 'brute force, 1e8')
+
+
+def test_bench_as_two_ranks_on_one_gpu(ctx):
+    """
+    bench.py under torch.distributed.run with two ranks sharing this GPU (TRC_BENCH_BACKEND=gloo: the tallies cross ranks through
+    the host; on an 8-GPU node the same code path uses RCCL): rays sharded by stream id, one reduction of the packed tally buffer.
+    The line it prints must hold the sum of both ranks -- hits and segments equal to the same four batches traced in this
+    process, `value` counting both ranks' segments over the slowest rank's time.
+    """
+    import json, subprocess, sys
+    from tracer_amd import scenes
+    from tracer_amd.accel_tree import KdTree
+    from tracer_amd.scene import compile_scene, DeviceScene
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, steps, warmup, world = 3000000, 2, 1, 2
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', str(steps), '--warmup', str(warmup),
+           '--rays', str(n), '--cpu-rays', '0', '--api-steps', '0']
+    envv = dict(os.environ, TRC_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run(cmd, cwd=root, env=envv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == world and out['steps'] == steps and out['scaling'] == 'weak' and out['check']['ok'] is True
+    # the same batches here: stream ids (step * world + rank) * n, seed 2024 (bench.py's)
+    plant, field, rec, src = scenes.nsttf_field()
+    cs = compile_scene(plant)
+    dev = DeviceScene(cs, ctx)
+    dev.set_kdtree(KdTree(plant, 8 + 1.3 * N.log(cs.n_surf), min_leaf=1))
+    seg = 0
+    for k in range(warmup, warmup + steps):
+        for rank in range(world):
+            st, _ = dev.trace_fast(scenes.nsttf_source(n, src, seed=2024, ray_offset=(k * world + rank) * n), 100, 1e-10, 2024, accel=True)
+            seg += st.segments
+    a, r, h = dev.get_tallies()
+    dev.close()
+    c = out['check']
+    assert c['receiver_hits'] == h[218] and c['heliostat_hits'] == h[:218].sum() and c['segments_total'] == seg
+    assert N.isclose(c['receiver_kW'], a[218] / (steps * world) / 1e3, rtol=1e-9)
+    assert N.isclose(out['value'], seg / (out['ms_per_step'] * 1e-3 * steps) / 1e6, rtol=1e-6)
+
+
+def test_accel_keyword_forms_through_ray_tracer(ctx):
+    """
+    ray_tracer(accel=...) as the reference spells it (tracer_engine.py:171-185): False, True, 'fast' (KdTree with at most 12
+    candidate planes per axis, accel_tree.py:118) and 'lightweight' (the reference's per-leaf sequencing, :66-122 -- a
+    scheduling artefact the device traversal subsumes).  All four give the same tallies and the same recorded tree through
+    both engines; the engine keeps the Kd-tree it built (engine.Kd_Tree) with the reference's node count for the form asked.
+    """
+    from tracer_amd import scenes
+    from tracer_amd.tracer_engine import TracerEngine
+    from tracer_amd.ray_bundle import RayBundle
+    n = 300000
+    res = {}
+    for accel in (False, True, 'fast', 'lightweight'):
+        plant, field, rec, src = scenes.nsttf_field(n_heliostats=40)
+        eng = TracerEngine(plant)
+        eng.ray_tracer(scenes.nsttf_source(n, src, seed=3), reps=100, min_energy=1e-10, tree=False, accel=accel, seed=3)
+        a, r, h = eng.get_tallies()
+        assert eng.stats['engine'] == 'fast' and len(eng.tree._bunds) == 1 and eng.tree._bunds[-1].get_num_rays() == eng.stats['rays_left']
+        kd_nodes = None if not accel else len(eng.Kd_Tree.flat()['flag'])
+        # the ordered engine (tree=True) on a materialised bundle of the same rays: the recorded levels
+        lazy = scenes.nsttf_source(20000, src, seed=3)
+        b = RayBundle(vertices=lazy.get_vertices(), directions=lazy.get_directions(), energy=lazy.get_energy())
+        plant.reset_all_optics(); eng.reset_tallies()
+        eng.ray_tracer(b, reps=100, min_energy=1e-10, tree=True, accel=accel, seed=3)
+        levels = [(bd.get_vertices().copy(), bd.get_energy().copy(), N.asarray(bd.get_parents()).copy()) for bd in eng.tree._bunds[1:]]
+        res[accel] = (a.copy(), h.copy(), eng.stats['segments'], levels, kd_nodes)
+    a0, h0, s0, lv0, _ = res[False]
+    assert h0[40] > 0.05 * n * 40 / 218. and len(lv0) >= 2
+    for accel in (True, 'fast', 'lightweight'):
+        a1, h1, s1, lv1, nodes = res[accel]
+        assert N.array_equal(h1, h0) and s1 == s0 and N.allclose(a1, a0, rtol=1e-10), accel
+        assert len(lv1) == len(lv0), accel
+        for (v1, e1, p1), (v0, e0, p0) in zip(lv1, lv0):
+            assert N.array_equal(p1, p0) and N.array_equal(v1, v0) and N.array_equal(e1, e0), accel
+        assert nodes is not None and nodes > 40
+    assert res['lightweight'][4] == res[True][4]           # the same tree as accel=True; 'fast' may split elsewhere
