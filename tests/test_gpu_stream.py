@@ -340,3 +340,108 @@ def test_accel_keyword_forms_through_ray_tracer(ctx):
             assert N.array_equal(p1, p0) and N.array_equal(v1, v0) and N.array_equal(e1, e0), accel
         assert nodes is not None and nodes > 40
     assert res['lightweight'][4] == res[True][4]           # the same tree as accel=True; 'fast' may split elsewhere
+
+
+def _height_field(m, extent=10., amp=0.8):
+    """m x m quads over [-extent, extent]^2 on a relief steep enough for second and third bounces, two triangles each:
+    vertices (n, 3), faces (2 m^2, 3)"""
+    x, y = N.meshgrid(N.linspace(-extent, extent, m + 1), N.linspace(-extent, extent, m + 1), indexing='ij')
+    z = amp * N.sin(1.3 * x) * N.cos(1.1 * y)
+    V = N.c_[x.ravel(), y.ravel(), z.ravel()]
+    i, j = N.meshgrid(N.arange(m), N.arange(m), indexing='ij')
+    a, b, c, d = (i * (m + 1) + j).ravel(), ((i + 1) * (m + 1) + j).ravel(), ((i + 1) * (m + 1) + j + 1).ravel(), (i * (m + 1) + j + 1).ravel()
+    return V, N.vstack((N.c_[a, b, c], N.c_[a, c, d]))
+
+
+def test_mesh_of_1e5_triangles(ctx, tmp_path):
+    """
+    SURVEY 8(f)4: meshes as the reference builds them -- one Surface per face (models/triangulated_surface.py:12-52,
+    ray_trace_utils/stl_utils.py:178-235) -- at a size where nothing fits LDS: 105 800 triangles + a receiver.  The device keeps
+    records, boxes, the 32-bit uniform grid and the footprint lists in global memory (L2-resident) and searches with k_s_bounce
+    for every ray.  Checked: (1) a 10 082-triangle mesh against brute force over all boxes (streaming form and megakernel) and
+    against the oracle ray by ray on the same Philox streams; (2) the 105 800-triangle mesh: footprint route == the per-ray route
+    for all fresh rays == given bundle; energy conservation; (3) the same mesh written to STL and loaded with
+    load_stl_into_tracer gives the same totals (float32 vertices in the file: 1e-3).
+    """
+    from tracer_amd import sources, stl_utils
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM
+    from tracer_amd.models.triangulated_surface import TriangulatedSurface
+    from tracer_amd import optics_callables as opt
+    from tracer_amd.spatial_geometry import translate, rotx
+    from tracer_amd.scene import compile_scene
+    from tracer_amd.ray_bundle import RayBundle
+    from tracer_amd.tracer_engine import TracerEngine
+    direction = N.r_[0.1, -0.05, -1.] / N.linalg.norm([0.1, -0.05, -1.])
+    center = N.c_[-40. * direction]
+
+    def scene(m):
+        V, F = _height_field(m)
+        mesh = TriangulatedSurface(V, F, opt.Reflective(0.2))
+        lid = AssembledObject(surfs=[Surface(RectPlateGM(90., 90.), opt.LambertianReceiver(1.))], transform=N.dot(translate(0., 0., 50.), rotx(N.pi)))
+        return Assembly(objects=[mesh, lid]), len(F)
+
+    # (1) 1e4 triangles: every route, brute force, the oracle
+    asm, nf = scene(71)
+    assert nf == 10082
+    cs = compile_scene(asm)
+    n = 400000
+    bundle = lambda: sources.buie_sunshape(n, center, direction, 12., 0.05, flux=1., seed=21)
+    ref = _trace(ctx, cs, bundle, reps=6)
+    assert ref['hits'] > 0.5 * n and ref['h'][nf] > 0.15 * n and ref['segments'] > 1.8 * n
+    _same(ref, _trace(ctx, cs, bundle, reps=6, TRC_STREAM_FRESH=0), 'fresh rays through k_s_bounce<FRESH> / the general path')
+    _same(ref, _trace(ctx, cs, bundle, reps=6, TRC_STREAM_FIRST=1), 'aureole through k_s_bounce<FRESH>')
+    _same(ref, _trace(ctx, cs, bundle, reps=6, TRC_STREAM_FRESH=0, TRC_STREAM_FIRST=1), 'all fresh rays through k_s_bounce<FRESH>')
+    small = lambda: sources.buie_sunshape(20000, center, direction, 12., 0.05, flux=1., seed=22)
+    brute = _trace(ctx, cs, small, reps=6, accel=False, TRC_STREAM_FRESH=0, TRC_STREAM_BOUNCE=0)
+    _same(brute, _trace(ctx, cs, small, reps=6), 'default route vs all boxes')
+    _same(brute, _trace(ctx, cs, small, reps=6, stream=False, accel=False), 'megakernel, brute force')
+    from oracle import engine as oracle_engine
+    with N.errstate(all='ignore'):
+        o = oracle_engine.trace_from_compiled(cs, small().source_args(), reps=6, min_energy=1e-10)
+    assert N.array_equal(o['hits'], brute['h']) and o['segments'] == brute['segments']
+    assert N.allclose(o['absorbed'], brute['a'], rtol=1e-9, atol=1e-12)
+
+    # (2) 1e5 triangles through the public entry point
+    asm, nf = scene(230)
+    assert nf == 105800
+    eng = TracerEngine(asm)
+    n = 2000000
+    out = {}
+    for key, knobs in (('map', {}), ('per ray', dict(TRC_STREAM_FRESH=0))):
+        with env(**knobs):
+            eng.reset_tallies(); asm.reset_all_optics()
+            eng.ray_tracer(sources.buie_sunshape(n, center, direction, 12., 0.05, flux=1., seed=23), reps=6, min_energy=1e-10, tree=False, accel=True, seed=23)
+            a, r, h = eng.get_tallies()
+            out[key] = (a.copy(), r.copy(), h.copy(), eng.stats['segments'])
+    assert eng.Kd_Tree is None and eng.stats['launches'] > 1
+    a0, r0, h0, s0 = out['map']
+    a1, r1, h1, s1 = out['per ray']
+    assert N.array_equal(h0, h1) and s0 == s1 and N.allclose(a0, a1, rtol=1e-9, atol=1e-15)
+    assert h0[:nf].sum() > 0.5 * n and h0[nf] > 0.15 * n and (h0[:nf] > 0).sum() > 0.4 * nf
+    lazy = sources.buie_sunshape(300000, center, direction, 12., 0.05, flux=1., seed=24)
+    eng.reset_tallies(); asm.reset_all_optics()
+    eng.ray_tracer(sources.buie_sunshape(300000, center, direction, 12., 0.05, flux=1., seed=24), reps=6, min_energy=1e-10, tree=False, accel=True, seed=24)
+    a2, r2, h2 = [x.copy() for x in eng.get_tallies()]
+    given = RayBundle(vertices=lazy.get_vertices(), directions=lazy.get_directions(), energy=lazy.get_energy())
+    eng.reset_tallies(); asm.reset_all_optics()
+    eng.ray_tracer(given, reps=6, min_energy=1e-10, tree=False, accel=True, seed=24)
+    a3, r3, h3 = eng.get_tallies()
+    assert N.array_equal(h3, h2) and N.allclose(a3, a2, rtol=1e-9, atol=1e-15)
+    # energy: what the source sent lands on the mesh (20 % absorbed per touch) or on the lid, or leaves sideways
+    e_src = N.pi * 12. ** 2
+    assert a0.sum() <= e_src * (1 + 1e-9) and a0.sum() > 0.3 * e_src
+
+    # (3) through an STL file
+    V, F = _height_field(230)
+    path = str(tmp_path / 'relief.stl')
+    stl_utils.make_stl(V, F, path)
+    obj = stl_utils.load_stl_into_tracer(path, opt.Reflective, dict(absorptivity=0.2), option='triangle')
+    assert len(obj.get_surfaces()) == nf
+    lid = AssembledObject(surfs=[Surface(RectPlateGM(90., 90.), opt.LambertianReceiver(1.))], transform=N.dot(translate(0., 0., 50.), rotx(N.pi)))
+    eng2 = TracerEngine(Assembly(objects=[obj, lid]))
+    eng2.ray_tracer(sources.buie_sunshape(n, center, direction, 12., 0.05, flux=1., seed=23), reps=6, min_energy=1e-10, tree=False, accel=True, seed=23)
+    a4, r4, h4 = eng2.get_tallies()
+    assert abs(a4[:nf].sum() / a0[:nf].sum() - 1.) < 1e-3 and abs(a4[nf] / a0[nf] - 1.) < 1e-3

@@ -126,6 +126,12 @@ struct trc_accel_host {
     std::vector<uint16_t> grid_list;
     std::vector<int32_t> grid_apart;   // bounded surfaces kept out of the grid: their boxes are tested for every ray
     float grid_root[6];                // box of the surfaces in the grid, relative, rounded outwards
+    // the same kind of grid without the limits of LDS, for scenes the one above cannot hold (trc_accel_build_grid32):
+    // 32-bit offsets and lists in global memory, every bounded surface in it (none set apart)
+    bool big_ok;
+    int32_t big_dim[3];
+    float big_lo[3], big_cs[3], big_inv[3], big_root[6];
+    std::vector<uint32_t> big_off, big_list;
 };
 
 // surfaces -> boxes, scene box, centre, delta
@@ -159,6 +165,8 @@ static inline void trc_accel_build_surfaces(const trc_surface_desc *surfs, int n
         A.brute_root[3 + k] = trc_f32_up(A.shi[k] - A.cen[k]);
     }
     A.grid_ok = false;
+    A.big_ok = false;
+    A.big_off.clear(); A.big_list.clear();
     A.sbox.assign(6 * (size_t)n, 0.0f);
     for (int i = 0; i < n; ++i)
         for (int k = 0; k < 3; ++k) {
@@ -220,7 +228,8 @@ static inline void trc_accel_build_grid(trc_accel_host &A, int n_surf) {
         for (int k = 0; k < 3; ++k) v *= std::fmax(e[k], 1e-3 * emax);     // flat axes do not make the volume vanish
         return v;
     };
-    while (A.grid_apart.size() < 8 && members.size() > 4 && A.grid_apart.size() * 4 < A.brute_leaf.size()) {
+    // (the search is quadratic in the number of surfaces: scenes beyond a few thousand keep everything in the grid)
+    while (A.grid_apart.size() < 8 && members.size() > 4 && members.size() <= 4096 && A.grid_apart.size() * 4 < A.brute_leaf.size()) {
         double blo[3], bhi[3];
         box_of(members, -1, blo, bhi);
         const double v_all = volume(blo, bhi);
@@ -310,6 +319,90 @@ static inline void trc_accel_build_grid(trc_accel_host &A, int n_surf) {
                         A.grid_list[cur[((size_t)z * dim[1] + y) * dim[0] + x]++] = members[j];
         for (int k = 0; k < 3; ++k) { A.grid_dim[k] = dim[k]; A.grid_lo[k] = (float)lo[k]; A.grid_cs[k] = cs[k]; A.grid_inv[k] = inv[k]; }
         A.grid_ok = true;
+        return;
+    }
+}
+
+// The grid for scenes that do not fit the one above: same construction (cells of about equal sides, TRC_GRID_DENSITY cells per
+// surface, a surface listed in every cell its box inflated by 2*delta overlaps), at most 2^24 cells and 2^28 list entries, all
+// bounded surfaces (none set apart), 32-bit offsets and lists.  Call after trc_accel_build_surfaces.
+static inline void trc_accel_build_grid32(const trc_surface_desc *, int n_surf, trc_accel_host &A) {
+    A.big_ok = false;
+    A.big_off.clear(); A.big_list.clear();
+    std::vector<uint32_t> members;
+    for (int i = 0; i < n_surf; ++i) {
+        const float *b = &A.sbox[6 * (size_t)i];
+        if (!(b[3] == INFINITY && b[0] == -INFINITY)) members.push_back((uint32_t)i);
+    }
+    const size_t nb = members.size();
+    if (nb == 0) return;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, ext[3];
+    for (size_t j = 0; j < nb; ++j) {
+        const float *b = &A.sbox[6 * (size_t)members[j]];
+        for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], (double)b[k]); hi[k] = std::fmax(hi[k], (double)b[3 + k]); }
+    }
+    for (int k = 0; k < 3; ++k) {
+        A.big_root[k] = trc_f32_down(lo[k] - 2.0 * (double)A.delta);
+        A.big_root[3 + k] = trc_f32_up(hi[k] + 2.0 * (double)A.delta);
+        lo[k] = (double)A.big_root[k];
+        ext[k] = (double)A.big_root[3 + k] - lo[k];
+    }
+    double target = std::fmin(16777216.0, std::fmax(8.0, TRC_GRID_DENSITY * (double)nb));
+    for (int attempt = 0; attempt < 16; ++attempt, target *= 0.5) {
+        double emax = std::fmax(ext[0], std::fmax(ext[1], ext[2]));
+        if (!(emax > 0.0)) return;
+        double vol = 1.0;
+        int nax = 0;
+        for (int k = 0; k < 3; ++k) if (ext[k] > 1e-3 * emax) { vol *= ext[k]; ++nax; }
+        double cell = std::pow(vol / target, 1.0 / (double)(nax > 0 ? nax : 1));
+        int dim[3];
+        size_t cells = 1;
+        for (int k = 0; k < 3; ++k) {
+            int n = (ext[k] > 1e-3 * emax) ? (int)std::ceil(ext[k] / cell) : 1;
+            dim[k] = n < 1 ? 1 : (n > 1024 ? 1024 : n);
+            cells *= (size_t)dim[k];
+        }
+        if (cells > 16777216) continue;
+        float cs[3], inv[3];
+        for (int k = 0; k < 3; ++k) {
+            double c = ext[k] / dim[k];
+            if (!(c > 0.0)) c = 1.0;
+            cs[k] = (float)c;
+            inv[k] = (float)(1.0 / c);
+        }
+        const double pad = 2.0 * (double)A.delta;
+        std::vector<uint32_t> count(cells + 1, 0u);
+        std::vector<int> range(6 * nb);
+        size_t total = 0;
+        for (size_t j = 0; j < nb; ++j) {
+            const float *b = &A.sbox[6 * (size_t)members[j]];
+            size_t c = 1;
+            for (int k = 0; k < 3; ++k) {
+                int a = (int)std::floor(((double)b[k] - pad - lo[k]) / (double)cs[k]);
+                int z = (int)std::floor(((double)b[3 + k] + pad - lo[k]) / (double)cs[k]);
+                a = a < 0 ? 0 : (a >= dim[k] ? dim[k] - 1 : a);
+                z = z < 0 ? 0 : (z >= dim[k] ? dim[k] - 1 : z);
+                range[6 * j + k] = a; range[6 * j + 3 + k] = z;
+                c *= (size_t)(z - a + 1);
+            }
+            total += c;
+        }
+        if (total > 268435456) continue;
+        for (size_t j = 0; j < nb; ++j)
+            for (int z = range[6 * j + 2]; z <= range[6 * j + 5]; ++z)
+                for (int y = range[6 * j + 1]; y <= range[6 * j + 4]; ++y)
+                    for (int x = range[6 * j]; x <= range[6 * j + 3]; ++x) count[((size_t)z * dim[1] + y) * dim[0] + x + 1]++;
+        for (size_t c = 0; c < cells; ++c) count[c + 1] += count[c];
+        A.big_off.assign(count.begin(), count.end());
+        A.big_list.assign(total > 0 ? total : 1, 0u);
+        std::vector<uint32_t> cur(count.begin(), count.end() - 1);
+        for (size_t j = 0; j < nb; ++j)      // ascending surface index inside every cell
+            for (int z = range[6 * j + 2]; z <= range[6 * j + 5]; ++z)
+                for (int y = range[6 * j + 1]; y <= range[6 * j + 4]; ++y)
+                    for (int x = range[6 * j]; x <= range[6 * j + 3]; ++x)
+                        A.big_list[cur[((size_t)z * dim[1] + y) * dim[0] + x]++] = members[j];
+        for (int k = 0; k < 3; ++k) { A.big_dim[k] = dim[k]; A.big_lo[k] = (float)lo[k]; A.big_cs[k] = cs[k]; A.big_inv[k] = inv[k]; }
+        A.big_ok = true;
         return;
     }
 }

@@ -763,14 +763,19 @@ TRC_HD bool trc_kd32_root(const float *root, const trc_ray32 &r, float *tmin, fl
 // extent, 400 times below delta) cannot lose a surface the exact ray touches.  Cell planes are recomputed from the
 // integer cell index at every step (no accumulated error).
 // ---------------------------------------------------------------------------------------------
-struct trc_grid_view {
-    const uint16_t *off;       // cells + 1 offsets into list
-    const uint16_t *list;      // surface indices
+// OT / LT: the integer types of the offsets and of the lists -- 16 bits for a grid that lives in LDS (at most 8192 cells and
+// 65535 entries), 32 bits for one in global memory (meshes of 1e5 faces and more)
+template <class OT, class LT>
+struct trc_grid_view_t {
+    const OT *off;             // cells + 1 offsets into list
+    const LT *list;            // surface indices
     int32_t nx, ny, nz;
     float lox, loy, loz;       // grid origin relative to cen
     float csx, csy, csz;       // cell size
     float ivx, ivy, ivz;       // 1 / cell size
 };
+typedef trc_grid_view_t<uint16_t, uint16_t> trc_grid_view;
+typedef trc_grid_view_t<uint32_t, uint32_t> trc_grid_view32;
 
 struct trc_dda {
     int32_t cx, cy, cz;
@@ -784,7 +789,8 @@ TRC_HD float trc_dda_plane_t(float lo, float cs, int32_t c, float o, float iv) {
     return (plane - o) * iv;
 }
 
-TRC_HD void trc_dda_start(const trc_grid_view &G, const trc_ray32 &r, float tmin, trc_dda *s) {
+template <class GV>
+TRC_HD void trc_dda_start(const GV &G, const trc_ray32 &r, float tmin, trc_dda *s) {
     float px = r.ox + tmin * (1.0f / r.ix), py = r.oy + tmin * (1.0f / r.iy), pz = r.oz + tmin * (1.0f / r.iz);
     int32_t cx = (int32_t)floorf((px - G.lox) * G.ivx), cy = (int32_t)floorf((py - G.loy) * G.ivy),
             cz = (int32_t)floorf((pz - G.loz) * G.ivz);
@@ -796,10 +802,12 @@ TRC_HD void trc_dda_start(const trc_grid_view &G, const trc_ray32 &r, float tmin
     s->tnz = trc_dda_plane_t(G.loz, G.csz, s->cz, r.oz, r.iz);
 }
 
-TRC_HD int32_t trc_dda_cell(const trc_grid_view &G, const trc_dda &s) { return (s.cz * G.ny + s.cy) * G.nx + s.cx; }
+template <class GV>
+TRC_HD int32_t trc_dda_cell(const GV &G, const trc_dda &s) { return (s.cz * G.ny + s.cy) * G.nx + s.cx; }
 
 // moves to the next cell; false when the ray has left the grid or passed tmax
-TRC_HD bool trc_dda_next(const trc_grid_view &G, const trc_ray32 &r, float tmax, trc_dda *s) {
+template <class GV>
+TRC_HD bool trc_dda_next(const GV &G, const trc_ray32 &r, float tmax, trc_dda *s) {
     if (s->tnx <= s->tny && s->tnx <= s->tnz) {
         if (!(s->tnx <= tmax)) return false;
         s->cx += (r.ix >= 0.0f) ? 1 : -1;

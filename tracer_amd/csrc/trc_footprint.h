@@ -105,7 +105,7 @@ struct trc_fp_host {
     trc_fp_params P;
     std::vector<uint32_t> mask;       // M * M / 32 words, bit (iy * M + ix)
     std::vector<uint32_t> coff;       // Mc * Mc + 1
-    std::vector<uint16_t> clist;
+    std::vector<uint32_t> clist;
     double coverage;                  // fraction of mask cells set
     const char *why;                  // when !ok
 };
@@ -198,7 +198,6 @@ static inline void trc_fp_build(const trc_surface_desc *surfs, int n_surf, const
     F.mask.clear(); F.coff.clear(); F.clist.clear();
     F.coverage = 1.0;
     memset(&F.P, 0, sizeof(F.P));
-    if (n_surf > 65535) { F.why = "more than 65535 surfaces"; return; }
     if (!A.unbounded.empty()) { F.why = "the scene has unbounded surfaces"; return; }
     if (!A.any_bounded) { F.why = "no bounded surface"; return; }
     double half = 0.0, theta_c = 0.0;
@@ -223,7 +222,7 @@ static inline void trc_fp_build(const trc_surface_desc *surfs, int n_surf, const
     const double hd = 0.5 * cell * std::sqrt(2.0), chd = 0.5 * ccell * std::sqrt(2.0);
     P.M = M; P.Mc = Mc; P.half = (float)half; P.inv_cell = (float)(M / (2.0 * half));
     F.mask.assign((size_t)M * M / 32, 0u);
-    std::vector<std::vector<uint16_t>> lists((size_t)Mc * Mc);
+    std::vector<std::vector<uint32_t>> lists((size_t)Mc * Mc);
     double depth_min = INFINITY;
     std::vector<double> hx, hy;
     for (int s = 0; s < n_surf; ++s) {
@@ -265,7 +264,7 @@ static inline void trc_fp_build(const trc_surface_desc *surfs, int n_surf, const
             for (int iy = y0; iy <= y1; ++iy)
                 for (int ix = x0; ix <= x1; ++ix) {
                     const double cx = -half + (ix + 0.5) * ccell, cy = -half + (iy + 0.5) * ccell;
-                    if (trc_fp_dist_poly(hx, hy, cx, cy) <= margin + chd) lists[(size_t)iy * Mc + ix].push_back((uint16_t)s);   // ascending s
+                    if (trc_fp_dist_poly(hx, hy, cx, cy) <= margin + chd) lists[(size_t)iy * Mc + ix].push_back((uint32_t)s);   // ascending s
                 }
     }
     size_t total = 0, bits = 0;
@@ -277,7 +276,7 @@ static inline void trc_fp_build(const trc_surface_desc *surfs, int n_surf, const
     size_t k = 0;
     for (size_t c = 0; c < lists.size(); ++c) {
         F.coff[c] = (uint32_t)k;
-        for (uint16_t s : lists[c]) F.clist[k++] = s;
+        for (uint32_t s : lists[c]) F.clist[k++] = s;
     }
     F.coff[lists.size()] = (uint32_t)k;
     // a ray can be advanced to just before the nearest depth of any box: a point at parameter t has depth

@@ -127,6 +127,8 @@ class TracerEngine(object):
             self._dev.reset_tallies()
 
     # -- the entry point ------------------------------------------------------------------------------
+    KD_BUILD_MAX = 8192      # surfaces beyond which accel=True does not build the reference's Kd-tree for the fast engine
+
     def ray_tracer(self, bundle, reps=100, min_energy=1e-10, tree=True, accel=False, Kd_Tree=None, **kwargs):
         """
         Trace `bundle` through the assembly for at most `reps` interactions per ray, dropping rays
@@ -159,7 +161,12 @@ class TracerEngine(object):
             logging.log(self.loglevel, 'protocol engine: %s' % err)
             return self._trace_protocol(bundle, reps, min_energy, tree)
 
-        if accel:
+        if accel and Kd_Tree is None and dev.n_surf > self.KD_BUILD_MAX and engine in ('auto', 'fast') and not (tree or dev.compiled.splits):
+            # A mesh of 1e5 faces: the reference's SAH build (accel_tree.py:42-204, Python) would take minutes and the fast
+            # engine does not walk it anyway -- it searches its own uniform grid over the same geometry boxes
+            # (csrc/trc_bounds.h).  engine.Kd_Tree stays None.
+            self.Kd_Tree = None
+        elif accel:
             if Kd_Tree is None:
                 num_surfs = dev.n_surf
                 max_depth = 8 + 1.3 * N.log(num_surfs)
@@ -194,6 +201,8 @@ class TracerEngine(object):
             dev.lib.trc_scene_clear_hits(dev.handle)
         t0 = time.time()
         stream = {'auto': None, 'stream': True, 'megakernel': False}[fast_kernel]
+        if stream is None and accel and dev.n_surf > self.KD_BUILD_MAX:
+            stream = True       # the streaming form has the grid for large scenes; the megakernel would test every box
         # Rays still alive after `reps` interactions come back as the call's result (tracer_engine.py:293-295).  Bundles beyond
         # 2^24 rays get room for 2^22 of them unless the caller says otherwise (last_capacity=...): 1e8 rays would cost 5.6 GB
         # of host arrays per call for a result that is empty in most scenes.  More rays left than room is an error of the
