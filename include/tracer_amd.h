@@ -102,7 +102,10 @@ typedef enum trc_optics_kind {
     TRC_OPT_SEMI_LAMBERTIAN = 12,       /* SemiLambertian          :506-531   opt: absorptivity,angular_range -- as the class
                                            describes itself: mirror for incidence angles above angular_range, Lambertian
                                            below (its __call__ indexes the direction array by rows, :525, and cannot run) */
-    TRC_OPT_KIND_COUNT = 13
+    TRC_OPT_REFRACTIVE_SCATTERING = 13, /* RefractiveScatteringHomogenous :1350-1376 on Scattering :946-1036: RefractiveHomogenous
+                                           (single_ray) in media that scatter; opt as REFRACTIVE_HOMOGENOUS;
+                                           extra: s_c1, s_c2 (scattering coefficients, 1/m), g1, g2 (Henyey-Greenstein) */
+    TRC_OPT_KIND_COUNT = 14
 } trc_optics_kind;
 
 /* surface flags */

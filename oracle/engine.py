@@ -56,6 +56,7 @@ def trace(scene, v, d, e, ref, wl, rid, reps, min_energy, seed):
     levels = [dict(vertices=v, directions=d, energy=e, parents=N.zeros(v.shape[1], dtype=int), surf=-N.ones(v.shape[1], dtype=int),
                    ref=ref, n_live=v.shape[1])]
     segments = 0
+    events = 0          # interactions: surface hits and volume events (the device's `hits` statistic)
     for it in range(reps):
         n = v.shape[1]
         if n == 0:
@@ -72,14 +73,19 @@ def trace(scene, v, d, e, ref, wl, rid, reps, min_energy, seed):
             blocks = optics.shade(s['opt_kind'], s['opt'], s['extra'], s['frame'][:3, 2], d[:, sel], e[sel], ref[sel], wl[sel],
                                   nrm, seed, rid[sel], it + 1, path=N.sqrt(N.sum((pts - v[:, sel]) ** 2, axis=0)))
             e_out = N.zeros(len(sel))
+            reached = N.ones(len(sel), dtype=bool)      # False: scattered in the medium on the way -- the surface records nothing
             for b in blocks:
                 N.add.at(e_out, b['sel'], b['energy'])
-            absorbed[si] += N.sum(e[sel] - e_out)
-            received[si] += N.sum(e[sel])
-            hits[si] += len(sel)
+                if 'back' in b:
+                    reached[b['sel']] = False
+            absorbed[si] += N.sum((e[sel] - e_out)[reached])
+            received[si] += N.sum(e[sel][reached])
+            hits[si] += int(reached.sum())
+            events += len(sel)
             for b in blocks:
                 k = b['sel']
-                outs.append(dict(vertices=pts[:, k], directions=b['directions'], energy=b['energy'], parents=sel[k],
+                start = pts[:, k] if 'back' not in b else pts[:, k] - b['back'][None, :] * d[:, sel][:, k]
+                outs.append(dict(vertices=start, directions=b['directions'], energy=b['energy'], parents=sel[k],
                                  surf=N.full(len(k), si), ref=b['ref'], wl=wl[sel][k], rid=b['rid']))
         if not outs:                      # every ray escaped: "Ray bundle depleted" (tracer_engine.py:277-280)
             v, d, e = N.zeros((3, 0)), N.zeros((3, 0)), N.zeros(0)
@@ -93,7 +99,7 @@ def trace(scene, v, d, e, ref, wl, rid, reps, min_energy, seed):
         levels.append(rec)
         v, d, e = rec['vertices'][:, :n_live], rec['directions'][:, :n_live], rec['energy'][:n_live]
         ref, wl, rid = rec['ref'][:n_live], rec['wl'][:n_live], rec['rid'][:n_live]
-    return dict(levels=levels, absorbed=absorbed, received=received, hits=hits, segments=segments,
+    return dict(levels=levels, absorbed=absorbed, received=received, hits=hits, segments=segments, events=events,
                 last_vertices=v, last_directions=d, last_energy=e)
 
 

@@ -123,6 +123,24 @@ def fresnel_to_attenuating(n1, m2, theta1):
     return R_p, R_s, theta2
 
 
+def scattering(sigma, path, R):
+    """tracer/optics.py:214-239 with the draw given: free path -ln(R) / sigma (sigma == 0: the way to the surface itself, i.e.
+    no scattering); scattered where it is shorter than the way to the surface.  Returns (scattered, free paths)."""
+    with N.errstate(divide='ignore', invalid='ignore'):
+        lengths = -N.log(R) / sigma
+    lengths = N.where(sigma == 0., path, lengths)
+    return lengths < path, lengths
+
+
+def hg_theta(g, R):
+    """ray_trace_utils/sampling.py:160-168: polar angle of a Henyey-Greenstein event from its uniform (g may be an array)"""
+    g = N.asarray(g, dtype=float) * N.ones_like(R)
+    s = 2. * R - 1.
+    gs = N.where(g == 0., 1., g)
+    c = 1. / (2. * gs) * (1. + gs ** 2 - ((1. - gs ** 2) / (1. + gs * s)) ** 2)
+    return N.arccos(N.clip(N.where(g == 0., s, c), -1., 1.))
+
+
 def iam(opt, ia, ic, d, nrm):
     """IAM.__call__ (optics_callables.py:276-281) as a factor on e (1 - abs); a_r = opt[ia] (0 or absent: 1), c = opt[ic]"""
     if len(opt) <= ic or opt[ia] == 0.:
@@ -223,6 +241,33 @@ def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event, path=N
         theta1 = N.arccos(N.abs((nrm * d).sum(axis=0)))
         R_p, R_s, _ = fresnel_to_attenuating(opt[0], m2, theta1)
         return [dict(sel=allsel, directions=reflections(d, nrm), energy=e * (R_p + R_s) / 2., ref=ref.copy(), rid=rid)]
+    if opt_kind == OPT_REFRACTIVE_SCATTERING:
+        # optics_callables.py:946-1036 / :1350-1376 as their docstrings and the body kept in comments at :1385-1470 describe them
+        # (the classes do not run in the reference): a free path -ln(R) / s_c (optics.py:214-239) shorter than the way to the
+        # surface scatters the ray there into a Henyey-Greenstein direction about its own (sampling.py:150-168), the others are
+        # refracted as by RefractiveHomogenous.  Blocks: scattered, reflected, refracted.  Draws: block 2 = (R, R_hg), block 3 = (azimuth, -).
+        s_c = N.where(ref == opt[0], extra[0], extra[1])
+        g = N.where(ref == opt[0], extra[2], extra[3])
+        r0, r1 = philox.uniform_pair(seed, rid, event, 2)
+        r2, _ = philox.uniform_pair(seed, rid, event, 3)
+        scat, lengths = scattering(s_c, path, r0)
+        blocks = []
+        if scat.any():
+            th = hg_theta(g[scat], r1[scat])
+            ph = 2. * N.pi * r2[scat]
+            loc = N.vstack((N.sin(th) * N.cos(ph), N.sin(th) * N.sin(ph), N.cos(th)))
+            dirs = rotate_z_to_normal(loc, d[:, scat])
+            blocks.append(dict(sel=allsel[scat], directions=dirs, energy=e[scat].copy(), ref=ref[scat].copy(), rid=rid[scat],
+                               back=(path - lengths)[scat]))
+        keep = ~scat
+        if keep.any():
+            sub = shade(OPT_REFRACTIVE_HOMOGENOUS, opt, extra, up, d[:, keep], e[keep], ref[keep], wl[keep], nrm[:, keep], seed, rid[keep],
+                        event, path=path[keep])
+            idx = allsel[keep]
+            for b in sub:
+                b['sel'] = idx[b['sel']]
+                blocks.append(b)
+        return blocks
     if opt_kind == OPT_REFRACTIVE_HOMOGENOUS:                    # :1226-1296 on :836-858
         na, nb, single, sigma = opt[0], opt[1], opt[2] != 0., opt[3]
         u0, u1 = philox.uniform_pair(seed, rid, event, 0)

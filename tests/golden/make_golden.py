@@ -881,6 +881,34 @@ def make_host_samplers(ref, amd, out):
     out['edge_bundle_vertices'], out['edge_bundle_directions'], out['edge_bundle_energy'] = b.get_vertices(), b.get_directions(), b.get_energy()
 
 
+def make_scattering(ref, amd, out):
+    """
+    Participating media: the two pure functions of the reference's scattering optics that run --
+    ray_trace_utils/sampling.py:150-168 Henyey_Greenstein.sample (draws R, then the azimuths) and tracer/optics.py:214-239
+    scattering (one draw per ray; sigma = 0 never scatters) -- with numpy's draws recorded, so that the device's variate -> sample
+    maps are checked against the reference's with only the generator differing.  (The classes built on them,
+    optics_callables.py:946-1036 / :1108-1172 / :1350-1376, do not run in the reference: Scattering._scatter reads names it
+    never defines, RefractiveScattering.__init__ an undefined g_HG.)
+    """
+    import ray_trace_utils.sampling as sampling
+    gs = N.array([0., 0.3, -0.6, 0.9, -0.95])
+    n = 4000
+    out['hg_g'] = gs
+    for k, g in enumerate(gs):
+        N.random.seed(100 + k)
+        draws = N.random.uniform(size=2 * n)            # what sample() will draw: R (n), then the azimuth uniforms (n)
+        N.random.seed(100 + k)
+        th, phi = sampling.Henyey_Greenstein(g).sample(n)
+        out['hg%d_R' % k], out['hg%d_U' % k], out['hg%d_theta' % k], out['hg%d_phi' % k] = draws[:n], draws[n:], th, phi
+    sigma = N.r_[N.full(1500, 0.7), N.full(1500, 12.), N.zeros(500)]
+    paths = N.random.RandomState(5).uniform(0.01, 3., size=len(sigma))
+    N.random.seed(77)
+    R = N.random.uniform(size=len(sigma))
+    N.random.seed(77)
+    scat, lengths = ref.optics.scattering(sigma.copy(), paths.copy())
+    out['sc_sigma'], out['sc_paths'], out['sc_R'], out['sc_scattered'], out['sc_lengths'] = sigma, paths, R, scat, lengths
+
+
 def main():
     import_reference()
     if '--mc' in sys.argv:
@@ -891,7 +919,7 @@ def main():
     only = [a[len('--only='):] for a in sys.argv if a.startswith('--only=')]
     for fname, maker in (('geometry.npz', make_geometry), ('optics.npz', make_optics), ('sources.npz', make_sources),
                          ('engine.npz', make_engine), ('emissive.npz', lambda ref, amd, out: make_emissive(out)),
-                         ('host_samplers.npz', make_host_samplers)):
+                         ('host_samplers.npz', make_host_samplers), ('scattering.npz', make_scattering)):
         if only and fname not in only:
             continue
         out = {}

@@ -310,4 +310,10 @@ long hc_obb(const trc_surface_desc *s, const double *extra, long n, const double
     return bad;
 }
 
+// Henyey-Greenstein polar angle of the scattering optics (trc_hg_theta) for the reference's recorded draws
+int hc_hg_theta(double g, long n, const double *Rv, double *theta) {
+    for (long i = 0; i < n; ++i) theta[i] = trc_hg_theta(g, Rv[i]);
+    return 0;
+}
+
 }  // extern "C"

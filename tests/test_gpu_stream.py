@@ -445,3 +445,75 @@ def test_mesh_of_1e5_triangles(ctx, tmp_path):
     eng2.ray_tracer(sources.buie_sunshape(n, center, direction, 12., 0.05, flux=1., seed=23), reps=6, min_energy=1e-10, tree=False, accel=True, seed=23)
     a4, r4, h4 = eng2.get_tallies()
     assert abs(a4[:nf].sum() / a0[:nf].sum() - 1.) < 1e-3 and abs(a4[nf] / a0[nf] - 1.) < 1e-3
+
+
+def test_scattering_slab_vs_oracle(ctx):
+    """
+    SURVEY 8(f)2, participating media: RefractiveScatteringHomogenous (optics_callables.py:1350-1376 on Scattering :946-1036,
+    Henyey-Greenstein sampling.py:150-168).  A slab of a scattering glass (n = 1.5, s_c = 2.5 / m, g = 0.6) in air between two
+    large plates, a black floor under it, rays from above:
+      * fast engine (streaming form and megakernel) == oracle on the same Philox streams: per-surface hit counts, interactions
+        (surface hits + scattering events) and segments exactly, energies to 1e-9; scattered rays leave no trace on the surfaces;
+      * ordered engine == oracle level by level (vertices of the scattering events inside the slab, directions, parents);
+      * known answer: of the rays refracted into the slab at normal incidence, the share that crosses its 0.8 m unscattered is
+        exp(-s_c L) (3 sigma).
+    """
+    from tracer_amd import sources, optics_callables as opt
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM
+    from tracer_amd.spatial_geometry import translate
+    from tracer_amd.scene import compile_scene, DeviceScene
+    from tracer_amd.ray_bundle import RayBundle
+    from oracle import engine as oracle_engine
+    s_c, g, L = 2.5, 0.6, 0.8
+    mk = lambda: opt.RefractiveScatteringHomogenous(1., 1.5, 0., s_c, 0., g)
+    top = AssembledObject(surfs=[Surface(RectPlateGM(40., 40.), mk())], transform=translate(0., 0., L))
+    bottom = AssembledObject(surfs=[Surface(RectPlateGM(40., 40.), mk())], transform=translate(0., 0., 0.))
+    floor = AssembledObject(surfs=[Surface(RectPlateGM(60., 60.), opt.LambertianReceiver(1.))], transform=translate(0., 0., -1.))
+    cs = compile_scene(Assembly(objects=[top, bottom, floor]))
+    n = 200000
+    rng = N.random.RandomState(4)
+    v = N.vstack((rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), N.full(n, 3.)))
+    d = N.tile(N.c_[[0., 0., -1.]], (1, n))
+    e = N.ones(n) / n
+    reps = 30
+    with N.errstate(all='ignore'):
+        o = oracle_engine.trace_bundle(cs, v, d, e, reps, 1e-10, 11)
+    assert o['events'] > o['hits'].sum() > 2 * n            # scattering events on top of the surface hits
+    for stream in (True, False):
+        dev = DeviceScene(cs, ctx)
+        st, _ = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e, ref_index=N.ones(n)), reps, 1e-10, 11, stream=stream)
+        a, r, h = dev.get_tallies()
+        dev.close()
+        assert N.array_equal(h, o['hits']) and st.segments == o['segments'] and st.hits == o['events'], stream
+        assert N.allclose(a, o['absorbed'], rtol=1e-9, atol=1e-12) and N.allclose(r, o['received'], rtol=1e-9, atol=1e-12), stream
+    # the ordered engine's recorded tree
+    m = 20000
+    with N.errstate(all='ignore'):
+        o2 = oracle_engine.trace_bundle(cs, v[:, :m], d[:, :m], e[:m], reps, 1e-10, 11)
+    dev = DeviceScene(cs, ctx)
+    res, st = dev.trace_ordered(RayBundle(vertices=v[:, :m], directions=d[:, :m], energy=e[:m], ref_index=N.ones(m)), reps, 1e-10, 11)
+    levels = [res.level(k) for k in range(res.num_levels())]
+    res.close(); dev.close()
+    assert len(levels) == len(o2['levels'])
+    inside = 0
+    for k in range(1, len(levels)):
+        Ld, Lo = levels[k], o2['levels'][k]
+        assert N.array_equal(Ld['parents'], Lo['parents']) and N.array_equal(Ld['surf'], Lo['surf']), k
+        assert N.allclose(Ld['vertices'], Lo['vertices'], rtol=1e-9, atol=1e-9) and N.allclose(Ld['directions'], Lo['directions'], rtol=1e-9, atol=1e-9), k
+        assert N.allclose(Ld['energy'], Lo['energy'], rtol=1e-12)
+        z = Ld['vertices'][2]
+        inside += int(((z > 1e-6) & (z < L - 1e-6)).sum())
+    assert inside > m                                        # scattering events start inside the slab, not on a surface
+    # Beer-Lambert: level 1 = the first interaction (all at the top plate, z = L): reflected or refracted; the refracted ones
+    # (directions still (0, 0, -1)) either scatter inside (level 2 vertex with 0 < z < L) or reach the bottom plate (z = 0)
+    L1, L2 = o2['levels'][1], o2['levels'][2]
+    went_in = N.nonzero(L1['directions'][2] < 0)[0]
+    par = L2['parents']
+    from_in = N.isin(par, went_in)
+    crossed = from_in & (N.abs(L2['vertices'][2]) < 1e-9)
+    share = crossed.sum() / float(from_in.sum())
+    sigma = N.sqrt(N.exp(-s_c * L) * (1 - N.exp(-s_c * L)) / from_in.sum())
+    assert abs(share - N.exp(-s_c * L)) < 3.5 * sigma, (share, N.exp(-s_c * L), sigma)

@@ -331,3 +331,13 @@ def test_oriented_box_never_rejects_a_hit(hc):
         assert bad == 0, (names[ci], bad)
         tested += int(N.isfinite(g[pre + 't']).sum())
     assert tested > 2000
+
+
+def test_core_henyey_greenstein_vs_reference(hc):
+    """trc_hg_theta (the device's scattering angle) on the reference's recorded draws, sampling.py:160-168"""
+    g = load('scattering.npz')
+    for k, gv in enumerate(g['hg_g']):
+        R = N.ascontiguousarray(g['hg%d_R' % k])
+        th = N.empty_like(R)
+        hc.hc_hg_theta(C.c_double(float(gv)), C.c_long(len(R)), _p(R), _p(th))
+        assert N.allclose(th, g['hg%d_theta' % k], rtol=0., atol=1e-12), gv

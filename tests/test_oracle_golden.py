@@ -256,3 +256,20 @@ def test_accountant_name_table():
     for k in ref:
         assert mine[k] == ref[k], k
     assert [type(a).__name__ for a in oc.OneSidedReflectiveReceiver(1.).accountants] == ['AbsorptionAccountant', 'LocationAccountant']
+
+
+def test_scattering_maps_vs_reference():
+    """
+    Participating media: the two pure functions under the reference's scattering optics, with numpy's draws
+    replayed -- Henyey_Greenstein.sample (sampling.py:150-168) and optics.scattering (optics.py:214-239).  The oracle's
+    restatements must give the reference's angles, free paths and scattered / not scattered decisions.
+    """
+    from oracle import optics
+    g = load('scattering.npz')
+    for k, gv in enumerate(g['hg_g']):
+        th = optics.hg_theta(gv, g['hg%d_R' % k])
+        assert N.allclose(th, g['hg%d_theta' % k], rtol=0., atol=1e-12), gv
+        assert N.allclose(2. * N.pi * g['hg%d_U' % k], g['hg%d_phi' % k], rtol=0., atol=1e-14)
+    scat, lengths = optics.scattering(g['sc_sigma'], g['sc_paths'], g['sc_R'])
+    assert N.array_equal(scat, g['sc_scattered']) and 500 < scat.sum() < 3000
+    assert N.allclose(lengths, g['sc_lengths'], rtol=1e-14, atol=0.)

@@ -39,7 +39,7 @@ SURF_CAPTURE_HITS = 0x1
 (OPT_TRANSPARENT, OPT_REFLECTIVE, OPT_ONE_SIDED_REFLECTIVE, OPT_REAL_REFLECTIVE,
  OPT_ONE_SIDED_REAL_REFLECTIVE, OPT_LAMBERTIAN, OPT_LAMBERTIAN_SPECULAR, OPT_REFRACTIVE_HOMOGENOUS,
  OPT_REFLECTIVE_SPECTRAL, OPT_LAMBERTIAN_DIRECTIONAL, OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL,
- OPT_FRESNEL_CONDUCTOR, OPT_SEMI_LAMBERTIAN) = range(13)
+ OPT_FRESNEL_CONDUCTOR, OPT_SEMI_LAMBERTIAN, OPT_REFRACTIVE_SCATTERING) = range(14)
 
 # enum trc_source_kind
 SRC_PILLBOX_DISK, SRC_PILLBOX_RECT, SRC_BUIE_DISK, SRC_BUIE_RECT, SRC_PILLBOX_TRIANGLE, SRC_VF_CYLINDER, SRC_VF_FRUSTUM = range(7)

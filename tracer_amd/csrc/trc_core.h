@@ -938,7 +938,10 @@ struct trc_ray_out {
     double dx, dy, dz;
     double e;
     double ref;
-    int blk;   // 0: reflected block, 1: refracted block (ordering inside a surface's output bundle)
+    int blk;   // 0: reflected block, 1: refracted block (ordering inside a surface's output bundle); scattering optics: 0 scattered,
+               // 1 reflected, 2 refracted (optics_callables.py:1136-1168: "stacking together the scattered, reflected and refracted rays")
+    double back;   // 0: the ray leaves from the hit point.  > 0: a volume event on the way -- the ray never reached the surface, it
+                   // leaves from the point `back` before the hit along its old direction, and the surface records nothing
 };
 
 TRC_HD void trc_reflect(double dx, double dy, double dz, double nx, double ny, double nz, double *ox,
@@ -1105,6 +1108,73 @@ TRC_HD double trc_iam(double a_r, double c, double dx, double dy, double dz, dou
     return (1.0 - exp(-pow(cos_aoi, c) / a_r)) / (1.0 - exp(-1.0 / a_r));
 }
 
+// RefractiveHomogenous (optics_callables.py:1226-1296 on :836-858): the body of its case in trc_shade, shared with the
+// scattering optics, whose rays that reach the surface are refracted like this
+TRC_HD int trc_shade_refractive(const double *opt, double dx, double dy, double dz, double e, double ref, double path, double nx,
+                                double ny, double nz, uint64_t seed, uint64_t rid, uint32_t event, trc_ray_out out[2]) {
+    double na = opt[0], nb = opt[1];
+    bool single = opt[2] != 0.0;
+    double sigma = opt[3];
+    double u0, u1, u2, u3;
+    trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
+    trc_uniform_pair(seed, rid, event, 1, &u2, &u3);
+    if (sigma >= 0.0) {                                         // normal perturbation :1227-1239
+        double g0, g1;
+        trc_normal_pair(u0, u1, &g0, &g1);
+        double th = sigma * g0, phi = TRC_TWO_PI * u2;
+        double st, ct, sp, cp;
+        trc_sincos(th, &st, &ct);
+        trc_sincos(phi, &sp, &cp);
+        double ex = st * cp, ey = st * sp, ez = ct;
+        double rx, ry, rz;
+        trc_rotation_to_z_apply(nx, ny, nz, ex, ey, ez, &rx, &ry, &rz);
+        nx = rx; ny = ry; nz = rz;
+    }
+    // attenuation in the medium the ray arrives through (RefractiveTransmissiveHomogenous :1326-1348 on Absorbant.attenuate
+    // :874-889): coefficient opt[4] in the medium of index n1 = opt[0], opt[5] in the other, path scaled by opt[6]
+    if (opt[7] != 0.0) e *= exp(-((ref == nb) ? opt[5] : opt[4]) * (path * opt[6]));
+    double n1 = ref;
+    double n2 = (n1 == na) ? nb : na;                           // :1217-1218
+    double eta = n2 / n1;
+    double cos1 = nx * dx + ny * dy + nz * dz;
+    bool refracted = (cos1 * cos1) >= (1.0 - eta * eta);        // optics.py:180
+    double R = 1.0;
+    double tx = 0.0, ty = 0.0, tz = 0.0;
+    if (refracted) {
+        tx = (dx - cos1 * nx) / eta; ty = (dy - cos1 * ny) / eta; tz = (dz - cos1 * nz) / eta;   // :188
+        double cos2 = sqrt(1.0 - 1.0 / (eta * eta) * (1.0 - cos1 * cos1));                        // :189
+        double sg = (cos1 < 0.0) ? -1.0 : 1.0;
+        tx += nx * cos2 * sg; ty += ny * cos2 * sg; tz += nz * cos2 * sg;                         // :190
+        R = trc_fresnel(fabs(cos1), n1, n2);
+    }
+    if (single) {                                               // :1254-1280
+        if (u3 <= R) {
+            trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);
+            out[0].e = e; out[0].ref = ref;
+        } else {
+            out[0].dx = tx; out[0].dy = ty; out[0].dz = tz;
+            out[0].e = e; out[0].ref = n2; out[0].blk = 1;
+        }
+        return 1;
+    }
+    trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);     // :1284-1294
+    out[0].e = e * R; out[0].ref = ref;
+    if (!refracted) return 1;
+    out[1].dx = tx; out[1].dy = ty; out[1].dz = tz;
+    out[1].e = e * (1.0 - R); out[1].ref = n2;
+    return 2;
+}
+
+// polar angle of a Henyey-Greenstein scattering event from its uniform (sampling.py:160-168; the closed form of the CDF)
+TRC_HD double trc_hg_theta(double g, double Rv) {
+    const double s = 2.0 * Rv - 1.0;
+    if (g == 0.0) return acos(s);
+    const double q = (1.0 - g * g) / (1.0 + g * s);
+    double c = 1.0 / (2.0 * g) * (1.0 + g * g - q * q);
+    c = c < -1.0 ? -1.0 : (c > 1.0 ? 1.0 : c);      // rounding at the ends of the range (the reference's arccos would give nan)
+    return acos(c);
+}
+
 TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int extra_off, int extra_len,
                      double ux, double uy, double uz, double dx, double dy, double dz, double e, double ref,
                      double wl, double path, double nx, double ny, double nz, uint64_t seed, uint64_t rid,
@@ -1113,6 +1183,8 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
     out[0].ref = ref;
     out[0].blk = 0;
     out[1].blk = 1;
+    out[0].back = 0.0;
+    out[1].back = 0.0;
     switch (opt_kind) {
     case TRC_OPT_TRANSPARENT:                                       // :106-113
         out[0].dx = dx; out[0].dy = dy; out[0].dz = dz; out[0].e = e;
@@ -1239,59 +1311,39 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
         out[0].e = e * R;
         return 1;
     }
-    case TRC_OPT_REFRACTIVE_HOMOGENOUS: {                           // :1226-1296 on :836-858
-        double na = opt[0], nb = opt[1];
-        bool single = opt[2] != 0.0;
-        double sigma = opt[3];
-        double u0, u1, u2, u3;
-        trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
-        trc_uniform_pair(seed, rid, event, 1, &u2, &u3);
-        if (sigma >= 0.0) {                                         // normal perturbation :1227-1239
-            double g0, g1;
-            trc_normal_pair(u0, u1, &g0, &g1);
-            double th = sigma * g0, phi = TRC_TWO_PI * u2;
+    case TRC_OPT_REFRACTIVE_SCATTERING: {
+        // Scattering in the medium the ray arrives through (optics_callables.py:946-1036 as its docstrings and the body kept in
+        // comments at :1385-1470 describe it; the class itself does not run in the reference): a free path l = -ln(R) / s_c is
+        // drawn (optics.py:214-239; s_c = 0 never scatters); l < path: the ray is scattered at prev + l d into a direction drawn
+        // from the medium's Henyey-Greenstein function about d (sampling.py:150-168, rotate_z_to_normal as :1012-1013), energy
+        // and index unchanged.  Otherwise it reaches the surface: RefractiveHomogenous below.  The medium is told by the index
+        // the ray carries (the reference tells it by the scattering coefficient it carries, toggled with the index).
+        // Draws: block 2 = (R, R_hg), block 3 = (azimuth, -); blocks 0-1 are the refraction's.
+        const double *x = extra + extra_off;
+        const int med = (ref == opt[0]) ? 0 : 1;
+        const double s_c = extra_len >= 4 ? x[med] : 0.0, g = extra_len >= 4 ? x[2 + med] : 0.0;
+        double r0, r1, r2, r3;
+        trc_uniform_pair(seed, rid, event, 2, &r0, &r1);
+        trc_uniform_pair(seed, rid, event, 3, &r2, &r3);
+        (void)r3;
+        const double l = s_c != 0.0 ? -log(r0) / s_c : path;        // optics.py:229-230
+        if (l < path) {                                             // :233
+            const double th = trc_hg_theta(g, r1);
+            const double ph = TRC_TWO_PI * r2;
             double st, ct, sp, cp;
             trc_sincos(th, &st, &ct);
-            trc_sincos(phi, &sp, &cp);
-            double ex = st * cp, ey = st * sp, ez = ct;
-            double rx, ry, rz;
-            trc_rotation_to_z_apply(nx, ny, nz, ex, ey, ez, &rx, &ry, &rz);
-            nx = rx; ny = ry; nz = rz;
-        }
-        // attenuation in the medium the ray arrives through (RefractiveTransmissiveHomogenous :1326-1348 on Absorbant.attenuate
-        // :874-889): coefficient opt[4] in the medium of index n1 = opt[0], opt[5] in the other, path scaled by opt[6]
-        if (opt[7] != 0.0) e *= exp(-((ref == nb) ? opt[5] : opt[4]) * (path * opt[6]));
-        double n1 = ref;
-        double n2 = (n1 == na) ? nb : na;                           // :1217-1218
-        double eta = n2 / n1;
-        double cos1 = nx * dx + ny * dy + nz * dz;
-        bool refracted = (cos1 * cos1) >= (1.0 - eta * eta);        // optics.py:180
-        double R = 1.0;
-        double tx = 0.0, ty = 0.0, tz = 0.0;
-        if (refracted) {
-            tx = (dx - cos1 * nx) / eta; ty = (dy - cos1 * ny) / eta; tz = (dz - cos1 * nz) / eta;   // :188
-            double cos2 = sqrt(1.0 - 1.0 / (eta * eta) * (1.0 - cos1 * cos1));                        // :189
-            double sg = (cos1 < 0.0) ? -1.0 : 1.0;
-            tx += nx * cos2 * sg; ty += ny * cos2 * sg; tz += nz * cos2 * sg;                         // :190
-            R = trc_fresnel(fabs(cos1), n1, n2);
-        }
-        if (single) {                                               // :1254-1280
-            if (u3 <= R) {
-                trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);
-                out[0].e = e; out[0].ref = ref;
-            } else {
-                out[0].dx = tx; out[0].dy = ty; out[0].dz = tz;
-                out[0].e = e; out[0].ref = n2; out[0].blk = 1;
-            }
+            trc_sincos(ph, &sp, &cp);
+            trc_rotate_z_to_normal(st * cp, st * sp, ct, dx, dy, dz, &out[0].dx, &out[0].dy, &out[0].dz);
+            out[0].e = e; out[0].ref = ref; out[0].blk = 0;
+            out[0].back = path - l;
             return 1;
         }
-        trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);     // :1284-1294
-        out[0].e = e * R; out[0].ref = ref;
-        if (!refracted) return 1;
-        out[1].dx = tx; out[1].dy = ty; out[1].dz = tz;
-        out[1].e = e * (1.0 - R); out[1].ref = n2;
-        return 2;
+        const int n_out = trc_shade_refractive(opt, dx, dy, dz, e, ref, path, nx, ny, nz, seed, rid, event, out);
+        out[0].blk += 1; out[1].blk += 1;          // behind the scattered block
+        return n_out;
     }
+    case TRC_OPT_REFRACTIVE_HOMOGENOUS:                             // :1226-1296 on :836-858
+        return trc_shade_refractive(opt, dx, dy, dz, e, ref, path, nx, ny, nz, seed, rid, event, out);
     default:
         out[0].dx = dx; out[0].dy = dy; out[0].dz = dz; out[0].e = 0.0;
         return 1;

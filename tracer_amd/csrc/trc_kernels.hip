@@ -336,11 +336,14 @@ template <bool LDS_TALLY>
 __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, int s, double e_in,
                                            double e_abs, double hx, double hy, double hz, double dx,
                                            double dy, double dz, bool capture_enabled, int prev, WaveChunk *hc = nullptr,
-                                           double *lds_fm = nullptr) {
+                                           double *lds_fm = nullptr, bool volume = false) {
+    // volume: the ray was scattered in the medium before it reached the surface -- nothing is recorded, but the lane takes part
+    // in the appends of the wave below (their bookkeeping is per wave)
     const int S = sc.n_surf;
     // energy carried from the surface the ray left (S = the source) to the one it lands on
-    if (sc.tr_off >= 0) atomicAdd(&sc.tally[sc.tr_off + (long long)prev * S + s], e_in);
-    if (LDS_TALLY) {
+    if (sc.tr_off >= 0 && !volume) atomicAdd(&sc.tally[sc.tr_off + (long long)prev * S + s], e_in);
+    if (volume) {
+    } else if (LDS_TALLY) {
         atomicAdd(&lds_tally[s], e_abs);
         atomicAdd(&lds_tally[S + s], e_in);
         atomicAdd(&lds_tally[2 * S + s], 1.0);
@@ -349,7 +352,7 @@ __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, 
         atomicAdd(&sc.tally[S + s], e_in);
         atomicAdd(&sc.tally[2 * S + s], 1.0);
     }
-    int fm = sc.fm_of_surf ? sc.fm_of_surf[s] : -1;
+    int fm = (!volume && sc.fm_of_surf) ? sc.fm_of_surf[s] : -1;
     if (fm >= 0) {
         const FluxMapDev &m = sc.fms[fm];
         double u = m.proj[0] * hx + m.proj[1] * hy + m.proj[2] * hz + m.proj[3];
@@ -366,7 +369,7 @@ __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, 
     if (capture_enabled && hc) {
         // chunked append (streaming engine): one atomic per 256 captured hits instead of one per wave and iteration --
         // the cursor of the hit buffer is a single word, and a word sustains only ~88 returning atomics per microsecond
-        bool want = (sc.sflags[s] & TRC_SURF_CAPTURE_HITS) != 0;
+        bool want = !volume && (sc.sflags[s] & TRC_SURF_CAPTURE_HITS) != 0;
         unsigned long long slot = chunk_append(&sc.counters[0], *hc, want, nullptr, 0);
         if (want) {
             if ((long long)slot < sc.hit_cap) {
@@ -380,7 +383,7 @@ __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, 
         }
     } else if (capture_enabled) {
         // wave-aggregated append: one atomic per wave per iteration
-        bool want = (sc.sflags[s] & TRC_SURF_CAPTURE_HITS) != 0;
+        bool want = !volume && (sc.sflags[s] & TRC_SURF_CAPTURE_HITS) != 0;
         unsigned long long mask = __ballot(want);
         if (mask) {
             int leader = __ffsll((long long)mask) - 1;
@@ -613,9 +616,13 @@ __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *re
     int n_out = trc_shade(trc_rec_opt_kind(rec), sc.opt + (size_t)s * 8, sc.extra, trc_rec_extra_off(rec), trc_rec_extra_len(rec),
                           rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, path, nx, ny, nz, P.seed, rid, (uint32_t)bounce, out);
     (void)n_out;  // scenes whose optics split rays are routed to the ordered engine by the host
+    // a volume event (scattering in the medium): the ray never reached the surface -- it goes on from a point before the hit,
+    // the surface records nothing, the surface the ray left stays the one it left
+    const bool volume = out[0].back > 0.0;
+    if (volume) { hx -= out[0].back * dx; hy -= out[0].back * dy; hz -= out[0].back * dz; }
     double e_abs = e - out[0].e;
-    record_hit<LDS_TALLY>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0, prev, hc, lds_fm);
-    prev = s;
+    record_hit<LDS_TALLY>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0, prev, hc, lds_fm, volume);
+    if (!volume) prev = s;
     px = hx; py = hy; pz = hz;
     dx = out[0].dx; dy = out[0].dy; dz = out[0].dz;
     e = out[0].e; ref = out[0].ref;
@@ -1059,7 +1066,7 @@ struct OrdParams {
     // outputs, 2n slots: child 0 of ray i at slot i, child 1 at slot n+i
     double *ox, *oy, *oz, *odx, *ody, *odz, *oe, *oref, *owl;
     uint64_t *orid;
-    uint32_t *key;  // (culled << 30) | (surface << 1) | block, 0xFFFFFFFF = empty slot
+    uint32_t *key;  // (culled << 30) | (surface << 2) | block, 0xFFFFFFFF = empty slot
 };
 
 #define ORD_EMPTY 0xFFFFFFFFu
@@ -1094,12 +1101,16 @@ __global__ __launch_bounds__(256) void k_ord_bounce(OrdParams P) {
                               trc_rec_extra_len(rec), rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, path, nx, ny,
                               nz, P.seed, rid, (uint32_t)P.event, out);
         double e_out = out[0].e + (n_out > 1 ? out[1].e : 0.0);
+        const bool volume = out[0].back > 0.0;      // scattered in the medium before the surface: nothing recorded there
+        if (volume) { hx -= out[0].back * dx; hy -= out[0].back * dy; hz -= out[0].back * dz; }
         // tallies (no wave-aggregated capture here: lanes may have exited)
         const int S = sc.n_surf;
-        atomicAdd(&sc.tally[s], e - e_out);
-        atomicAdd(&sc.tally[S + s], e);
-        atomicAdd(&sc.tally[2 * S + s], 1.0);
-        int fm = sc.fm_of_surf ? sc.fm_of_surf[s] : -1;
+        if (!volume) {
+            atomicAdd(&sc.tally[s], e - e_out);
+            atomicAdd(&sc.tally[S + s], e);
+            atomicAdd(&sc.tally[2 * S + s], 1.0);
+        }
+        int fm = (!volume && sc.fm_of_surf) ? sc.fm_of_surf[s] : -1;
         if (fm >= 0) {
             const FluxMapDev &m = sc.fms[fm];
             double u = m.proj[0] * hx + m.proj[1] * hy + m.proj[2] * hz + m.proj[3];
@@ -1114,7 +1125,7 @@ __global__ __launch_bounds__(256) void k_ord_bounce(OrdParams P) {
             P.odx[slot] = out[c].dx; P.ody[slot] = out[c].dy; P.odz[slot] = out[c].dz;
             P.oe[slot] = out[c].e; P.oref[slot] = out[c].ref; P.owl[slot] = wl;
             P.orid[slot] = (c == 0) ? rid : trc_child_rid(rid, (uint32_t)P.event);
-            uint32_t k = ((uint32_t)s << 1) | (uint32_t)out[c].blk;
+            uint32_t k = ((uint32_t)s << 2) | (uint32_t)out[c].blk;
             if (out[c].e <= P.min_energy) k |= ORD_CULLED_BIT;   // tracer_engine.py:242, :270-274
             if (c == 0) k0 = k; else k1 = k;
         }
@@ -1227,7 +1238,7 @@ __global__ __launch_bounds__(256) void k_ord_gather(GatherParams G) {
     G.e[j] = G.oe[slot]; G.ref[j] = G.oref[slot]; G.wl[j] = G.owl[slot];
     G.rid[j] = G.orid[slot];
     G.parent[j] = (int64_t)(slot >= G.n_parent ? slot - G.n_parent : slot);   // tracer_engine.py:235-236
-    G.surf[j] = (int32_t)((k & ~ORD_CULLED_BIT) >> 1);
+    G.surf[j] = (int32_t)((k & ~ORD_CULLED_BIT) >> 2);
 }
 
 __global__ void k_fill_f64(double *p, long long n, double v) {
@@ -1363,6 +1374,13 @@ static int validate_surface(const trc_surface_desc &s, int idx, int n_extra) {
         return trc_fail(TRC_ERR_UNSUPPORTED, "surface %d: geometry kind %d is not in the native table", idx, s.gm_kind);
     if (s.optics_kind < 0 || s.optics_kind >= TRC_OPT_KIND_COUNT)
         return trc_fail(TRC_ERR_UNSUPPORTED, "surface %d: optics kind %d is not in the native table", idx, s.optics_kind);
+    if (s.optics_kind == TRC_OPT_REFRACTIVE_SCATTERING) {
+        if (s.opt[2] == 0.0) return trc_fail(TRC_ERR_UNSUPPORTED, "surface %d: scattering optics emit one ray per interaction (single_ray)", idx);
+        if (s.extra_off < 0 || s.extra_len < 4 || s.extra_off + s.extra_len > n_extra)
+            return trc_fail(TRC_ERR_INVALID, "surface %d: scattering optics need s_c1, s_c2, g1, g2 in the extra values", idx);
+        if (s.gm_kind == TRC_GM_RECT_PERFORATED || s.gm_kind == TRC_GM_POLYGON)
+            return trc_fail(TRC_ERR_UNSUPPORTED, "surface %d: scattering optics share the extra range with the geometry", idx);
+    }
     bool opt_table = s.optics_kind == TRC_OPT_REFLECTIVE_SPECTRAL || s.optics_kind == TRC_OPT_LAMBERTIAN_DIRECTIONAL ||
                      s.optics_kind == TRC_OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL || s.optics_kind == TRC_OPT_FRESNEL_CONDUCTOR;
     bool needs_extra = s.gm_kind == TRC_GM_RECT_PERFORATED || opt_table;

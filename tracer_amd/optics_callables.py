@@ -375,6 +375,42 @@ class RefractiveAbsorbantHomogenous(RefractiveTransmissiveHomogenous):
         RefractiveTransmissiveHomogenous.__init__(self, m1, m2, [attenuation_coefficient_1, attenuation_coefficient_2], single_ray, sigma, scaling)
 
 
+class RefractiveScatteringHomogenous(RefractiveHomogenous):
+    """
+    RefractiveHomogenous between two media that scatter (optics_callables.py:1350-1376 on Scattering :946-1036 and
+    RefractiveScattering :1108-1172): on its way to the surface a ray draws a free path -ln(R) / s_c in the medium it travels
+    through (optics.py:214-239); if that is shorter than the way, it is scattered there into a direction drawn from the medium's
+    Henyey-Greenstein phase function about its own direction (sampling.py:150-168) and keeps its energy and medium; otherwise
+    it meets the surface like a ray of RefractiveHomogenous (reflected or refracted, one ray).  A scattered ray never reached the
+    surface: tallies, flux maps and accountants of the surface do not see it.
+
+    s_c1, s_c2: scattering coefficients (1/m) of the media of index n1, n2; g_HG_1, g_HG_2: their asymmetry factors (-1..1).
+    The medium is told by the refractive index the ray carries, so n1 != n2 is required (the reference tells it by a
+    scattering-coefficient column toggled together with the index).  The reference's classes do not run (Scattering._scatter
+    and RefractiveScattering.__init__ read names they never define): this follows their docstrings and the body kept in comments
+    at :1385-1470; the two pure functions they are built on are pinned by tests/golden/scattering.npz.
+    Device only (fast and ordered engines); single_ray=True.
+    """
+    def __init__(self, n1, n2, s_c1, s_c2, g_HG_1, g_HG_2, single_ray=True, sigma=None):
+        if not single_ray:
+            raise NotImplementedError('scattering optics emit one ray per interaction (single_ray=True)')
+        if n1 == n2:
+            raise ValueError('the media are told apart by their refractive indices: n1 != n2')
+        RefractiveHomogenous.__init__(self, n1, n2, True, sigma)
+        self._s_cs = [float(s_c1), float(s_c2)]
+        self._g = [float(g_HG_1), float(g_HG_2)]
+
+    def get_media(self, current_ref_idx):
+        return N.array(N.asarray(current_ref_idx) != self._ref_idxs[0], dtype=int)
+
+    def _native(self):
+        kind, params, extra = RefractiveHomogenous._native(self)
+        return _cabi.OPT_REFRACTIVE_SCATTERING, list(params) + [0., 0., 1., 0.], self._s_cs + self._g
+
+    def __call__(self, geometry, rays, selector):
+        raise NotImplementedError('scattering optics run on the device engines (ray_tracer with engine "auto", "fast" or "ordered")')
+
+
 # --------------------------------------------------------------------------------------------------
 # optics composed on the host.  They are ordinary optics callables of the four-step protocol (their scenes are traced by
 # TracerEngine with engine='protocol', the native surfaces and the optics they wrap still running on the device per call).
