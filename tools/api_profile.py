@@ -1,0 +1,23 @@
+"""Where the time of one TracerEngine.ray_tracer(tree=False, accel=True) call on the bench workload goes (host side): cProfile,
+top entries by cumulative time.  usage: api_profile.py [rays]"""
+import cProfile, pstats, sys, os, io
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as N
+from tracer_amd import scenes
+from tracer_amd.tracer_engine import TracerEngine
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100000000
+plant, field, rec, src = scenes.nsttf_field()
+eng = TracerEngine(plant)
+ue, ve = scenes.nsttf_fluxmap_edges()
+eng.set_fluxmap(218, ue, ve)
+mk = lambda k: scenes.nsttf_source(n, src, seed=2024, ray_offset=k * n)
+eng.ray_tracer(mk(0), reps=100, min_energy=1e-10, tree=False, accel=True, seed=2024)
+plant.reset_all_optics()
+pr = cProfile.Profile()
+pr.enable()
+eng.ray_tracer(mk(1), reps=100, min_energy=1e-10, tree=False, accel=True, seed=2024)
+pr.disable()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(18)
+print(s.getvalue())

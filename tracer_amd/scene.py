@@ -227,11 +227,12 @@ class DeviceScene(object):
         _cabi.check(self.lib.trc_scene_get_hits(self.handle, C.byref(n), None, nul, nul, nul, nul, nul, nul, nul, nul))
         k = n.value
         surf = N.empty(k, dtype=N.int32)
-        cols = [N.empty(k) for _ in range(8)]
+        e_abs, e_in, points, directions = N.empty(k), N.empty(k), N.empty((3, k)), N.empty((3, k))
+        cols = [e_abs, e_in, points[0], points[1], points[2], directions[0], directions[1], directions[2]]   # rows: no copy afterwards
         if k:
             _cabi.check(self.lib.trc_scene_get_hits(self.handle, C.byref(n), surf.ctypes.data_as(C.POINTER(C.c_int32)),
                                                     *[_cabi.ptr(c) for c in cols]))
-        return dict(surf=surf, e_abs=cols[0], e_in=cols[1], points=N.vstack(cols[2:5]), directions=N.vstack(cols[5:8]))
+        return dict(surf=surf, e_abs=e_abs, e_in=e_in, points=points, directions=directions)
 
     def bin_hits(self, surf_lo, surf_hi, ranges, mode):
         """
@@ -391,15 +392,19 @@ def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavele
     surf_ids = N.asarray(surf_ids)
     if len(surf_ids) == 0:
         return
-    order = N.argsort(surf_ids, kind='stable')
-    sorted_ids = surf_ids[order]
-    uniq, start = N.unique(sorted_ids, return_index=True)
-    stop = list(start[1:]) + [len(order)]
+    if surf_ids[0] == surf_ids[-1] and (surf_ids == surf_ids[0]).all():
+        # one capturing surface (the receiver of a field): no sorting, no gathering of 1e7 hits
+        order, uniq, start, stop = None, [int(surf_ids[0])], [0], [len(surf_ids)]
+    else:
+        order = N.argsort(surf_ids, kind='stable')
+        sorted_ids = surf_ids[order]
+        uniq, start = N.unique(sorted_ids, return_index=True)
+        stop = list(start[1:]) + [len(order)]
     for s, a, b in zip(uniq, start, stop):
         opt = surfaces[s].get_optics_manager()
         if not isinstance(opt, OpticsCallable) or not opt.accountants:
             continue
-        idx = order[a:b]
+        idx = slice(None) if order is None else order[a:b]
         surf = surfaces[s]
         pts = points[:, idx]
         dirs = directions[:, idx]
