@@ -599,8 +599,15 @@ __device__ __forceinline__ void coop_drain_leaves(const trc_accel_view &A, const
     WAVE_SYNC();
 }
 
+// optics kinds of the "mirrors and diffuse walls" family: what a heliostat field, a dish or a cavity of opaque walls is made of.
+// A scene of flat surfaces with only these gets an instance of k_s_shade that carries nothing else (SIMPLE below).
+#define TRC_OPT_SIMPLE_MASK ((1u << TRC_OPT_TRANSPARENT) | (1u << TRC_OPT_REFLECTIVE) | (1u << TRC_OPT_ONE_SIDED_REFLECTIVE) | \
+                             (1u << TRC_OPT_REAL_REFLECTIVE) | (1u << TRC_OPT_ONE_SIDED_REAL_REFLECTIVE) | (1u << TRC_OPT_LAMBERTIAN) | \
+                             (1u << TRC_OPT_LAMBERTIAN_SPECULAR))
+
 // shading + bookkeeping of one hit, shared by the two fast kernels.  Returns false when the ray stops here.
-template <bool LDS_TALLY>
+// SIMPLE promises a flat geometry kind and an optics kind of TRC_OPT_SIMPLE_MASK on every surface: the compiler drops the rest.
+template <bool LDS_TALLY, bool SIMPLE = false>
 __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *recs, double *l_tally, double t, int s, double &px,
                                            double &py, double &pz, double &dx, double &dy, double &dz, double &e, double &ref,
                                            double wl, unsigned long long rid, int &bounce, int &prev, WaveChunk *hc = nullptr,
@@ -610,9 +617,11 @@ __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *re
     const double *rec = recs + (size_t)s * sc.stride;
     double hx = px + t * dx, hy = py + t * dy, hz = pz + t * dz;
     double nx, ny, nz;
+    if (SIMPLE && !trc_gm_is_flat(trc_rec_gm_kind(rec))) __builtin_unreachable();
     trc_normal(rec, hx, hy, hz, dx, dy, dz, &nx, &ny, &nz);
     trc_ray_out out[2];
     const double path = sqrt((hx - px) * (hx - px) + (hy - py) * (hy - py) + (hz - pz) * (hz - pz));
+    if (SIMPLE && !((TRC_OPT_SIMPLE_MASK >> trc_rec_opt_kind(rec)) & 1u)) __builtin_unreachable();
     int n_out = trc_shade(trc_rec_opt_kind(rec), sc.opt + (size_t)s * 8, sc.extra, trc_rec_extra_off(rec), trc_rec_extra_len(rec),
                           rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, path, nx, ny, nz, P.seed, rid, (uint32_t)bounce, out);
     (void)n_out;  // scenes whose optics split rays are routed to the ordered engine by the host
