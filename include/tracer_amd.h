@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TRC_ABI_VERSION 1
+#define TRC_ABI_VERSION 2
 
 typedef enum trc_status {
     TRC_OK = 0,
@@ -105,7 +105,17 @@ typedef enum trc_optics_kind {
     TRC_OPT_REFRACTIVE_SCATTERING = 13, /* RefractiveScatteringHomogenous :1350-1376 on Scattering :946-1036: RefractiveHomogenous
                                            (single_ray) in media that scatter; opt as REFRACTIVE_HOMOGENOUS;
                                            extra: s_c1, s_c2 (scattering coefficients, 1/m), g1, g2 (Henyey-Greenstein) */
-    TRC_OPT_KIND_COUNT = 14
+    TRC_OPT_REFRACTIVE_MATERIAL = 14,   /* Refractive :726-858 between two media of wavelength-dependent complex index m = n + ik
+                                           (ray_trace_utils/optical_constants.py materials), and RefractiveAbsorbant :908-944
+                                           (Absorbant.attenuate :874-889 with k = Im m, optics.py:205-212).  Rays carry a complex index
+                                           (trc_rays.ref_index_im), a wavelength, and the materials' indices at it (trc_rays.mat).
+                                           opt: single_ray, sigma(<0:none), attenuate(0|1), scaling, k0, k1 (rows of trc_rays.mat of
+                                           material_1, material_2).  Ordered engine and per-surface protocol. */
+    TRC_OPT_LAMBERTIAN_POLYCHROMATIC = 15, /* Lambertian_directional_axisymmetric_piecewise_Polychromatic :393-425: every ray carries a
+                                           spectrum (trc_rays.spectra over trc_rays.spec_wl); each sample is scaled by 1 - absorptance(theta_in,
+                                           lambda_w), the ray energy is the trapezoid integral of the result.  extra as
+                                           LAMBERTIAN_DIRECTIONAL_SPECTRAL.  Ordered engine and protocol. */
+    TRC_OPT_KIND_COUNT = 16
 } trc_optics_kind;
 
 /* surface flags */
@@ -131,7 +141,8 @@ typedef struct trc_surface_desc {
 
 /*
  * A ray bundle as structure-of-arrays (reference: RayBundle, ray_bundle.py:6-195).
- * Required: x..e.  Optional (NULL when absent): parent, ref_index, wavelength, rid.
+ * Required: x..e.  Optional (NULL when absent): parent, ref_index, wavelength, rid, ref_index_im, spec_wl + spectra, mat.
+ * Rows of the 2-D columns are `n` apart, n being this struct's n when it is handed over (an output's capacity).
  * `rid` is the 64-bit random-stream id of a ray (RNG); when NULL
  * it is ray_offset + index.  on_device != 0 means the pointers are device
  * pointers valid in this process (e.g. torch tensors on the context's GPU).
@@ -139,7 +150,7 @@ typedef struct trc_surface_desc {
 typedef struct trc_rays {
     int64_t n;
     int32_t on_device;
-    int32_t reserved;
+    int32_t n_spec;             /* polychromatic bundles (ray_bundle.py `spectra`, `wavelengths` as 2-D columns): samples per ray, 0 = none */
     double *x, *y, *z;
     double *dx, *dy, *dz;
     double *e;
@@ -147,6 +158,12 @@ typedef struct trc_rays {
     double *ref_index;
     double *wavelength;
     uint64_t *rid;
+    double *ref_index_im;       /* imaginary part of a complex refractive index (attenuating media); NULL = 0 */
+    double *spec_wl;            /* n_spec x n: wavelength of sample w of ray i at spec_wl[w * n + i] (n = the bundle's ray count) */
+    double *spectra;            /* n_spec x n: spectral power, same layout; its trapezoid integral over spec_wl is the ray energy */
+    int64_t n_mat;              /* TRC_OPT_REFRACTIVE_MATERIAL: number of materials, and                                          */
+    double *mat;                /* 2 n_mat x n: Re m_k(lambda_i) at mat[2k * n + i], Im at mat[(2k + 1) * n + i] -- material k's own
+                                   m() evaluated by the caller at the wavelength of ray i (children inherit the wavelength)     */
 } trc_rays;
 
 /* ---- sources (reference: tracer/sources.py) -------------------------------- */

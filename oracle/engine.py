@@ -44,12 +44,15 @@ def intersect_ray(scene, v, d):
     return earliest, mins
 
 
-def trace(scene, v, d, e, ref, wl, rid, reps, min_energy, seed):
+def trace(scene, v, d, e, ref, wl, rid, reps, min_energy, seed, mat=None, spec=None, swl=None):
     """
     Returns dict(levels=[dict(vertices, directions, energy, parents, surf, ref, n_live)...] (level 0 = input),
     absorbed(S), received(S), hits(S), segments, hit_records=[per level dict(surf, e_in, e_out, points, directions)])
+    mat (K, n) complex: the scene's materials at each ray's wavelength; spec, swl (W, n): polychromatic bundle.  Children
+    inherit all three (RayBundle.inherit); levels then carry `spectra` and `swl`.
     """
     S = len(scene)
+    carried = dict((k, a) for k, a in (('mat', mat), ('spec', spec), ('swl', swl)) if a is not None)
     absorbed = N.zeros(S)
     received = N.zeros(S)
     hits = N.zeros(S, dtype=N.int64)
@@ -71,7 +74,8 @@ def trace(scene, v, d, e, ref, wl, rid, reps, min_energy, seed):
             pts = v[:, sel] + tmin[sel][None, :] * d[:, sel]
             nrm = geometry.normals(s['kind'], s['frame'], s['gm'], pts, d[:, sel])
             blocks = optics.shade(s['opt_kind'], s['opt'], s['extra'], s['frame'][:3, 2], d[:, sel], e[sel], ref[sel], wl[sel],
-                                  nrm, seed, rid[sel], it + 1, path=N.sqrt(N.sum((pts - v[:, sel]) ** 2, axis=0)))
+                                  nrm, seed, rid[sel], it + 1, path=N.sqrt(N.sum((pts - v[:, sel]) ** 2, axis=0)),
+                                  ext=dict((k, a[:, sel]) for k, a in carried.items()))
             e_out = N.zeros(len(sel))
             reached = N.ones(len(sel), dtype=bool)      # False: scattered in the medium on the way -- the surface records nothing
             for b in blocks:
@@ -85,8 +89,14 @@ def trace(scene, v, d, e, ref, wl, rid, reps, min_energy, seed):
             for b in blocks:
                 k = b['sel']
                 start = pts[:, k] if 'back' not in b else pts[:, k] - b['back'][None, :] * d[:, sel][:, k]
-                outs.append(dict(vertices=start, directions=b['directions'], energy=b['energy'], parents=sel[k],
-                                 surf=N.full(len(k), si), ref=b['ref'], wl=wl[sel][k], rid=b['rid']))
+                o = dict(vertices=start, directions=b['directions'], energy=b['energy'], parents=sel[k],
+                         surf=N.full(len(k), si), ref=b['ref'], wl=wl[sel][k], rid=b['rid'])
+                if 'mat' in carried:
+                    o['mat'] = carried['mat'][:, sel][:, k]
+                if 'spec' in carried:
+                    o['spectra'] = b['spectra']
+                    o['swl'] = carried['swl'][:, sel][:, k]
+                outs.append(o)
         if not outs:                      # every ray escaped: "Ray bundle depleted" (tracer_engine.py:277-280)
             v, d, e = N.zeros((3, 0)), N.zeros((3, 0)), N.zeros(0)
             break
@@ -99,6 +109,9 @@ def trace(scene, v, d, e, ref, wl, rid, reps, min_energy, seed):
         levels.append(rec)
         v, d, e = rec['vertices'][:, :n_live], rec['directions'][:, :n_live], rec['energy'][:n_live]
         ref, wl, rid = rec['ref'][:n_live], rec['wl'][:n_live], rec['rid'][:n_live]
+        for k, name in (('mat', 'mat'), ('spec', 'spectra'), ('swl', 'swl')):
+            if k in carried:
+                carried[k] = rec[name][:, :n_live]
     return dict(levels=levels, absorbed=absorbed, received=received, hits=hits, segments=segments, events=events,
                 last_vertices=v, last_directions=d, last_energy=e)
 
@@ -111,11 +124,23 @@ def trace_from_compiled(cs, source_args, reps, min_energy):
     return trace(scene, v, d, e, N.ones(n), N.zeros(n), rid, reps, min_energy, seed)
 
 
-def trace_bundle(cs, vertices, directions, energy, reps, min_energy, seed, ref_index=None, wavelengths=None, offset=0):
+def trace_bundle(cs, vertices, directions, energy, reps, min_energy, seed, ref_index=None, wavelengths=None, offset=0,
+                 spectra=None):
+    """ref_index may be complex (media that attenuate); spectra (W, n) with wavelengths (W, n): a polychromatic bundle; scenes that
+    refract between materials (cs.materials) get the materials' m() at the rays' wavelengths, as the product hands them over."""
     scene = scene_from_compiled(cs)
     n = vertices.shape[1]
     rid = N.arange(n, dtype=N.uint64) + N.uint64(offset)
-    ref = N.ones(n) if ref_index is None else N.asarray(ref_index, dtype=float)
-    wl = N.zeros(n) if wavelengths is None else N.asarray(wavelengths, dtype=float)
+    ref = N.ones(n) if ref_index is None else N.asarray(ref_index)
+    ref = ref.astype(complex) if N.iscomplexobj(ref) or getattr(cs, 'materials', None) else ref.astype(float)
+    swl = spec = mat = None
+    if spectra is not None:
+        spec, swl = N.asarray(spectra, float), N.asarray(wavelengths, float)
+        wl = N.zeros(n)
+    else:
+        wl = N.zeros(n) if wavelengths is None else N.asarray(wavelengths, dtype=float)
+    if getattr(cs, 'materials', None):
+        with N.errstate(all='ignore'):
+            mat = N.array([N.asarray(m.m(wl), dtype=complex) for m in cs.materials])
     return trace(scene, N.asarray(vertices, float), N.asarray(directions, float), N.asarray(energy, float), ref, wl, rid,
-                 reps, min_energy, seed)
+                 reps, min_energy, seed, mat=mat, spec=spec, swl=swl)

@@ -150,7 +150,118 @@ def iam(opt, ia, ic, d, nrm):
     return (1. - N.exp(-cos_aoi ** opt[ic] / opt[ia])) / (1. - N.exp(-1. / opt[ia]))
 
 
-def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event, path=None):
+def attenuations(path_lengths, k, lambda_0, energy):
+    """optics.py:205-212"""
+    return N.exp(-4. * N.pi * path_lengths * k / lambda_0) * energy
+
+
+def interp2(tab, th, lam):
+    """RegularGridInterpolator (linear) over (theta, lambda), arguments clamped to the grid; tab as csrc/trc_core.h trc_interp2"""
+    nt, nl = int(tab[0]), int(tab[1])
+    ts, ls = tab[2:2 + nt], tab[2 + nt:2 + nt + nl]
+    v = N.asarray(tab[2 + nt + nl:]).reshape(nt, nl)
+
+    def cell(xs, x):
+        x = N.clip(x, xs[0], xs[-1])
+        i = N.clip(N.searchsorted(xs, x, side='right') - 1, 0, len(xs) - 2)
+        return i, (x - xs[i]) / (xs[i + 1] - xs[i])
+    it, wt = cell(ts, th)
+    il, wl = cell(ls, lam)
+    return (1. - wt) * ((1. - wl) * v[it, il] + wl * v[it, il + 1]) + wt * ((1. - wl) * v[it + 1, il] + wl * v[it + 1, il + 1])
+
+
+def spectral_factor(opt_kind, opt, extra, d, nrm):
+    """What the optics classes do to the spectrum a polychromatic ray carries (`outg._spectra *= ...`): 1 - absorptivity for
+    Reflective :137-138, Lambertian :173-174 (LambertianAbsorbant builds its Lambertian with 0, :897) and RealReflective :266-267
+    with their one-sided and IAM children; 1 - absorptance(theta) for Lambertian_directional_axisymmetric_piecewise :358-359;
+    every other class hands the spectrum on unchanged (RayBundle.inherit)."""
+    H = d.shape[1]
+    if opt_kind in (OPT_REFLECTIVE, OPT_ONE_SIDED_REFLECTIVE, OPT_REAL_REFLECTIVE, OPT_ONE_SIDED_REAL_REFLECTIVE):
+        return N.full(H, 1. - opt[0])
+    if opt_kind == OPT_LAMBERTIAN:
+        return N.full(H, 1. - opt[0]) if not (len(opt) > 2 and opt[2] != 0.) else N.ones(H)
+    if opt_kind == OPT_LAMBERTIAN_DIRECTIONAL and int(opt[0]) == 0:
+        vert = N.sum(d * nrm, axis=0) * nrm
+        th = N.arccos(N.sqrt(N.sum(vert ** 2, axis=0)))
+        k = len(extra) // 2
+        return 1. - N.interp(th, extra[:k], extra[k:2 * k])
+    return N.ones(H)
+
+
+def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event, path=None, ext=None):
+    """
+    shade_core plus what the rays of the ordered engine carry (csrc/trc_core.h trc_shade_x).  ext: dict with
+    mat (K, H) complex: the scene's materials at each ray's wavelength; spec, swl (W, H): spectrum and its wavelength grid.
+    Blocks then carry `spectra` (W, k) too; `ref` is complex when the rays' is.
+    """
+    H = d.shape[1]
+    allsel = N.arange(H)
+    ext = ext or {}
+    spec, swl = ext.get('spec'), ext.get('swl')
+    if opt_kind == OPT_REFRACTIVE_MATERIAL:                      # Refractive :726-858, RefractiveAbsorbant :908-944
+        single, sigma, atten, scaling, k0, k1 = opt[0] != 0., opt[1], opt[2] != 0., opt[3], int(opt[4]), int(opt[5])
+        mat0, mat1 = ext['mat'][k0], ext['mat'][k1]
+        u0, u1 = philox.uniform_pair(seed, rid, event, 0)
+        u2, u3 = philox.uniform_pair(seed, rid, event, 1)
+        nrm = nrm.copy()
+        if sigma >= 0.:                                          # :767-781
+            g0, _ = philox.normal_pair(u0, u1)
+            th = sigma * g0
+            phi = 2. * N.pi * u2
+            err = N.vstack((N.sin(th) * N.cos(phi), N.sin(th) * N.sin(phi), N.cos(th)))
+            rots = rotation_to_z(nrm.T)
+            for i in range(H):
+                nrm[:, i] = N.dot(rots[i], err[:, i])
+        m1 = N.asarray(ref, dtype=complex)
+        m2 = N.where(m1 == mat0, mat1, mat0)                     # :750-751
+        with N.errstate(all='ignore'):
+            refr, out_dirs = refractions(m1.real, m2.real, d, nrm)   # :786
+            R = N.ones(H)
+            R[refr] = N.real(fresnel(d[:, refr], nrm[:, refr], m1[refr], m2[refr]))     # :838-840 (the cast keeps the real part)
+        refl_dirs = reflections(d, nrm)
+        if single:                                               # :796-823
+            refl = u3 <= R
+            dirs_refr = N.zeros((3, H))
+            dirs_refr[:, refr] = out_dirs
+            blocks = []
+            if refl.any():
+                blocks.append(dict(sel=allsel[refl], directions=refl_dirs[:, refl], energy=e[refl], ref=m1[refl], rid=rid[refl]))
+            if (~refl).any():
+                blocks.append(dict(sel=allsel[~refl], directions=dirs_refr[:, ~refl], energy=e[~refl], ref=m2[~refl], rid=rid[~refl]))
+        else:                                                    # :825-835
+            blocks = [dict(sel=allsel, directions=refl_dirs, energy=e * R, ref=m1.copy(), rid=rid)]
+            if refr.any():
+                blocks.append(dict(sel=allsel[refr], directions=out_dirs, energy=e[refr] * (1. - R[refr]), ref=m2[refr],
+                                   rid=philox.child_rid(rid[refr], event)))
+        for b in blocks:
+            if atten:                                            # Absorbant.attenuate :874-882: k and lambda of the new bundle
+                b['energy'] = attenuations(path[b['sel']] * scaling, b['ref'].imag, wl[b['sel']], b['energy'])
+            if spec is not None:
+                b['spectra'] = spec[:, b['sel']].copy()
+        return blocks
+    if opt_kind == OPT_LAMBERTIAN_POLYCHROMATIC:                 # :406-425
+        vert = N.sum(d * nrm, axis=0) * nrm
+        th = N.arccos(N.sqrt(N.sum(vert ** 2, axis=0)))
+        ab = interp2(extra, N.tile(th, (spec.shape[0], 1)), swl)
+        spectra = spec * (1. - ab)
+        energy = N.sum((swl[1:] - swl[:-1]) * (spectra[1:] + spectra[:-1]) / 2., axis=0)      # N.trapz(spectra, wavelengths, axis=0)
+        u0, u1 = philox.uniform_pair(seed, rid, event, 0)
+        dirs = lambertian_directions(nrm, 2. * N.pi * u0, u1, N.pi / 2.)
+        return [dict(sel=allsel, directions=dirs, energy=energy, ref=N.asarray(ref).copy(), rid=rid, spectra=spectra)]
+    cplx = N.iscomplexobj(ref)
+    blocks = shade_core(opt_kind, opt, extra, up, d, e, N.real(ref) if cplx else ref, wl, nrm, seed, rid, event, path=path)
+    if cplx:        # the other optics hand the index on unchanged, or set a real one (RefractiveHomogenous toggles real indices)
+        for b in blocks:
+            same = b['ref'] == N.real(ref)[b['sel']]
+            b['ref'] = N.where(same, N.asarray(ref)[b['sel']], b['ref'].astype(complex))
+    if spec is not None:
+        f = spectral_factor(opt_kind, opt, extra, d, nrm)
+        for b in blocks:
+            b['spectra'] = spec[:, b['sel']] * f[b['sel']]
+    return blocks
+
+
+def shade_core(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event, path=None):
     """
     One optics call on H hits.  Returns a list of blocks (reflected block first, refracted second), each a dict
     with sel (indices into the H hits), directions (3,k), energy (k,), ref (k,), rid (k,).

@@ -241,12 +241,14 @@ def make_optics(ref, amd, out):
     oc = ref.optics_callables
     cases = []
 
-    def run(name, opt_ref, opt_amd, ref_index=None, draws=None, wavelengths=None, lengths=None):
+    def run(name, opt_ref, opt_amd, ref_index=None, draws=None, wavelengths=None, lengths=None, spectra=None):
         kw = {}
         if ref_index is not None:
             kw['ref_index'] = ref_index
         if wavelengths is not None:
             kw['wavelengths'] = wavelengths
+        if spectra is not None:           # polychromatic bundle: spectra (W,H) over wavelengths (W,H)
+            kw['spectra'] = spectra.copy()
         # ray origins: `lengths` behind the hit points (1 when the optics does not look at the path)
         L = N.ones(H) if lengths is None else lengths
         bund = ref.ray_bundle.RayBundle(vertices=pts - d * L, directions=d.copy(), energy=e.copy(), **kw)
@@ -264,13 +266,19 @@ def make_optics(ref, amd, out):
         out[pre + 'opt'] = p8
         out[pre + 'extra'] = N.asarray(extra, dtype=float)
         out[pre + 'ref_in'] = N.ones(H) if ref_index is None else ref_index
+        if hasattr(opt_amd, '_materials'):      # the materials' own m() at the rays' wavelengths: what travels as trc_rays.mat
+            out[pre + 'mat'] = N.array([m.m(wavelengths) for m in opt_amd._materials])
+        if spectra is not None:
+            out[pre + 'spec_in'], out[pre + 'spec_wl'] = spectra, wavelengths
+            out[pre + 'out_spectra'] = outg.get_spectra()
         out[pre + 'path'] = L
         out[pre + 'out_dirs'] = outg.get_directions()
         out[pre + 'out_energy'] = outg.get_energy()
         out[pre + 'out_parents'] = N.asarray(outg.get_parents())
         out[pre + 'out_vertices'] = outg.get_vertices()
         if ref_index is not None:
-            out[pre + 'out_ref'] = N.asarray(outg.get_ref_index(), dtype=float)
+            r = N.asarray(outg.get_ref_index())
+            out[pre + 'out_ref'] = r if N.iscomplexobj(r) else N.asarray(r, dtype=float)
         for k, val in rec.items():
             out[pre + 'draw_' + k] = val
         cases.append(name)
@@ -356,6 +364,47 @@ def make_optics(ref, amd, out):
     mk = N.array([2.0, 3.5, 5.0, 7.0, 9.5, 13., 18., 24.])
     mat = A.TabulatedMaterial(mlam, mn, mk)
     run('fresnel_conductor', oc.FresnelConductorHomogenous(1., mat), A.FresnelConductorHomogenous(1., mat), wavelengths=wl)
+
+    # Refractive / RefractiveAbsorbant between tabulated materials (complex indices; optics_callables.py:726-858, :908-944)
+    tl = N.linspace(0.2e-6, 3e-6, 6)
+    air = A.TabulatedMaterial(tl, N.ones(6), N.zeros(6))
+    glass = A.TabulatedMaterial(tl, [1.56, 1.53, 1.51, 1.50, 1.49, 1.47], [4e-8, 2e-8, 1e-8, 6e-8, 3e-7, 9e-7])
+    m_in = N.where(N.arange(H) % 2 == 0, air.m(wl), glass.m(wl))
+    m_in[5] = 1.2 + 0.j                                      # a ray in neither medium enters material_1 (:750-751)
+    run('material_split', oc.Refractive(air, glass, single_ray=False), A.Refractive(air, glass, single_ray=False),
+        ref_index=m_in, wavelengths=wl)
+    run('material_single', oc.Refractive(air, glass, single_ray=True), A.Refractive(air, glass, single_ray=True),
+        ref_index=glass.m(wl), wavelengths=wl, draws=lambda: dict(u=N.random.uniform(size=H)))
+    run('material_split_sigma', oc.Refractive(air, glass, single_ray=False, sigma=2e-3), A.Refractive(air, glass, single_ray=False, sigma=2e-3),
+        ref_index=m_in, wavelengths=wl,
+        draws=lambda: dict(g0=N.random.normal(scale=2e-3, size=H), phi=N.random.uniform(low=0., high=2. * N.pi, size=H)))
+    run('material_absorbant_split', oc.RefractiveAbsorbant(air, glass, single_ray=False, attenuation_coefficient_1=1., attenuation_coefficient_2=1.),
+        A.RefractiveAbsorbant(air, glass, single_ray=False, attenuation_coefficient_1=1., attenuation_coefficient_2=1.),
+        ref_index=m_in, wavelengths=wl, lengths=Lr)
+    run('material_absorbant_scaled', oc.RefractiveAbsorbant(air, glass, single_ray=False, attenuation_coefficient_1=1., scaling=0.3),
+        A.RefractiveAbsorbant(air, glass, single_ray=False, attenuation_coefficient_1=1., scaling=0.3),
+        ref_index=m_in, wavelengths=wl, lengths=Lr)
+
+    # polychromatic bundles (`spectra` over `wavelengths`, both (W,H)): the wall that integrates them (:393-425) and the classes
+    # that scale them
+    W = 7
+    swl = N.sort(rng.uniform(0.3e-6, 2.5e-6, size=(W, H)), axis=0)
+    spec = rng.uniform(0.2, 3., size=(W, H)) * 1e6
+    lamb = lambda: dict(xi1=N.random.uniform(low=0., high=2. * N.pi, size=H), xi2=N.random.uniform(size=H))
+    run('polychromatic_wall', oc.Lambertian_directional_axisymmetric_piecewise_Polychromatic(ths, grid, wls),
+        A.Lambertian_directional_axisymmetric_piecewise_Polychromatic(ths, grid, wls), wavelengths=swl, spectra=spec, draws=lamb)
+    run('poly_transparent', oc.Transparent(), A.Transparent(), wavelengths=swl, spectra=spec)
+    run('poly_reflective', oc.Reflective(0.1), A.Reflective(0.1), wavelengths=swl, spectra=spec)
+    run('poly_one_sided_reflective', oc.OneSidedReflective(0.2), A.OneSidedReflective(0.2), wavelengths=swl, spectra=spec)
+    run('poly_real_reflective', oc.RealReflective(0.05, 0., True), A.RealReflective(0.05, 0., True), wavelengths=swl, spectra=spec)
+    run('poly_lambertian', oc.Lambertian(0.3), A.Lambertian(0.3), wavelengths=swl, spectra=spec, draws=lamb)
+    run('poly_lambertian_absorbant', oc.LambertianAbsorbant(0.3, [0.7], 1.2), A.LambertianAbsorbant(0.3, [0.7], 1.2), lengths=Lr,
+        wavelengths=swl, spectra=spec, draws=lamb)
+    run('poly_lambertian_directional', oc.Lambertian_directional_axisymmetric_piecewise(ths, abth), A.Lambertian_directional_axisymmetric_piecewise(ths, abth),
+        wavelengths=swl, spectra=spec, draws=lamb)
+    run('poly_lambertian_specular', oc.LambertianSpecular(0.1, 0.4), A.LambertianSpecular(0.1, 0.4), wavelengths=swl, spectra=spec, draws=ls_draws)
+    run('poly_refractive_split', oc.RefractiveHomogenous(1.0, 1.5, single_ray=False), A.RefractiveHomogenous(1.0, 1.5, single_ray=False),
+        ref_index=n_in, wavelengths=swl, spectra=spec)
 
     # O1: optics.fresnel_to_attenuating on a grid of incidence angles x complex indices (optics.py:63-81)
     th = N.tile(N.linspace(0., N.pi / 2. - 1e-3, 40), 6)

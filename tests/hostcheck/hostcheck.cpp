@@ -70,6 +70,38 @@ int hc_shade_path(const trc_surface_desc *s, const double *extra, long n, const 
     return 0;
 }
 
+// trc_shade_x: the same with what rays of the ordered engine carry.  ref_im (n) or null; mat (2 n_mat x n) or null; swl, spec (W x n) or
+// null; outputs o_im (2n), o_spec (W x 2n).
+int hc_shade_x(const trc_surface_desc *s, const double *extra, long n, const double *dx, const double *dy, const double *dz,
+               const double *e, const double *ref, const double *wl, const double *nx, const double *ny, const double *nz,
+               const uint64_t *rid, uint64_t seed, int event, double *odx, double *ody, double *odz, double *oe, double *oref,
+               int *oblk, const double *path, const double *ref_im, int n_mat, const double *mat, int W, const double *swl,
+               const double *spec, double *o_im, double *o_spec) {
+    for (long i = 0; i < n; ++i) {
+        trc_ray_out out[2];
+        trc_ray_ext X;
+        X.ref_im = ref_im ? ref_im[i] : 0.0; X.W = W; X.n_mat = n_mat; X.stride = n;
+        X.mat = mat ? mat + i : nullptr; X.wl = swl ? swl + i : nullptr; X.spec = spec ? spec + i : nullptr;
+        double out_im[2], poly_th;
+        int no = trc_shade_x(s->optics_kind, s->opt, extra, s->extra_off, s->extra_len, s->frame[2], s->frame[6], s->frame[10],
+                             dx[i], dy[i], dz[i], e[i], ref[i], wl[i], path ? path[i] : 0.0, nx[i], ny[i], nz[i], seed, rid[i],
+                             (uint32_t)event, X, out, out_im, &poly_th);
+        for (int c = 0; c < 2; ++c) {
+            long slot = c == 0 ? i : n + i;
+            if (c < no) {
+                odx[slot] = out[c].dx; ody[slot] = out[c].dy; odz[slot] = out[c].dz; oe[slot] = out[c].e; oref[slot] = out[c].ref;
+                oblk[slot] = out[c].blk;
+                if (o_im) o_im[slot] = out_im[c];
+                for (int w = 0; w < W && o_spec; ++w) {
+                    const double f = poly_th >= 0.0 ? 1.0 - trc_poly_absorptance(extra + s->extra_off, poly_th, X.wl[(long)w * n]) : out[c].sf;
+                    o_spec[(long)w * 2 * n + slot] = X.spec[(long)w * n] * f;
+                }
+            } else oblk[slot] = -1;
+        }
+    }
+    return 0;
+}
+
 int hc_shade(const trc_surface_desc *s, const double *extra, long n, const double *dx, const double *dy, const double *dz,
              const double *e, const double *ref, const double *wl, const double *nx, const double *ny, const double *nz,
              const uint64_t *rid, uint64_t seed, int event, double *odx, double *ody, double *odz, double *oe, double *oref,

@@ -39,7 +39,7 @@ def test_binding_covers_the_header(lib_path):
     from tracer_amd import _cabi
     assert sorted(_cabi.SIGNATURES) == declared_functions()
     lib = _cabi.load_library()
-    assert lib.trc_abi_version() == 1
+    assert lib.trc_abi_version() == 2
 
 
 def test_enum_values_match_header():

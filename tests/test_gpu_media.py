@@ -1,0 +1,219 @@
+"""
+SURVEY 8(f)2, rest -- what rays carry beyond position, direction and energy:
+  * complex, wavelength-dependent refractive indices of tabulated materials (Refractive, optics_callables.py:726-858) and the
+    attenuation that follows from their imaginary part (RefractiveAbsorbant :908-944 on Absorbant.attenuate :874-889);
+  * polychromatic bundles: a spectrum per ray (`spectra` over `wavelengths`, both (W,N)), integrated by the polychromatic wall
+    (Lambertian_directional_axisymmetric_piecewise_Polychromatic :393-425) and scaled by the classes that have the line
+    `outg._spectra *= ...`.
+Per-call parity with the reference's own outputs is in test_gpu_parity.test_optics_vs_reference_and_oracle; here whole traces through
+TracerEngine.ray_tracer are compared with the oracle level by level, and with known answers.
+"""
+import numpy as N
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from tracer_amd import _cabi
+    return _cabi.get_context()
+
+
+def _materials():
+    from tracer_amd import optics_callables as opt
+    tl = N.linspace(0.3e-6, 2.5e-6, 6)
+    air = opt.TabulatedMaterial(tl, N.ones(6), N.zeros(6))
+    glass = opt.TabulatedMaterial(tl, [1.55, 1.53, 1.51, 1.50, 1.49, 1.47], [3e-8, 2e-8, 1e-8, 5e-8, 2e-7, 6e-7])
+    return air, glass
+
+
+def _slab_scene(single_ray, absorb=True):
+    from tracer_amd import optics_callables as opt
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM
+    from tracer_amd.spatial_geometry import translate
+    air, glass = _materials()
+    cls = opt.RefractiveAbsorbant if absorb else opt.Refractive
+    kw = dict(attenuation_coefficient_1=1.) if absorb else {}
+    top = AssembledObject(surfs=[Surface(RectPlateGM(40., 40.), cls(air, glass, single_ray=single_ray, **kw))], transform=translate(0., 0., 0.5))
+    bottom = AssembledObject(surfs=[Surface(RectPlateGM(40., 40.), cls(air, glass, single_ray=single_ray, **kw))], transform=translate(0., 0., 0.))
+    floor = AssembledObject(surfs=[Surface(RectPlateGM(60., 60.), opt.LambertianReceiver(1.))], transform=translate(0., 0., -1.))
+    return Assembly(objects=[top, bottom, floor]), air, glass
+
+
+def _bundle(n, air, seed=3, tilt=0.3):
+    from tracer_amd.ray_bundle import RayBundle
+    rng = N.random.RandomState(seed)
+    v = N.vstack((rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), N.full(n, 3.)))
+    d = N.vstack((rng.uniform(-tilt, tilt, n), rng.uniform(-tilt, tilt, n), -N.ones(n)))
+    d /= N.sqrt(N.sum(d ** 2, axis=0))
+    wl = rng.uniform(0.4e-6, 2.4e-6, n)
+    return RayBundle(vertices=v, directions=d, energy=N.ones(n) / n, ref_index=air.m(wl), wavelengths=wl), wl
+
+
+def _compare_levels(tree, o, complex_index=True, spectra=False):
+    for k in range(1, min(tree.num_bunds(), len(o['levels']))):
+        B, Lo = tree[k], o['levels'][k]
+        assert N.array_equal(B.get_parents(), Lo['parents']), k
+        assert N.allclose(B.get_vertices(), Lo['vertices'], rtol=1e-9, atol=1e-9), k
+        assert N.allclose(B.get_directions(), Lo['directions'], rtol=1e-9, atol=1e-9), k
+        assert N.allclose(B.get_energy(), Lo['energy'], rtol=1e-9, atol=1e-15), k
+        if complex_index:
+            assert N.iscomplexobj(B.get_ref_index()) and N.allclose(B.get_ref_index(), Lo['ref'], rtol=1e-12, atol=0), k
+        if spectra:
+            assert N.allclose(B.get_spectra(), Lo['spectra'], rtol=1e-12, atol=0), k
+            assert N.array_equal(B.get_wavelengths(), Lo['swl']), k
+    assert tree.num_bunds() == len(o['levels'])
+
+
+def test_absorbing_slab_between_tabulated_materials(ctx):
+    """
+    A glass slab (complex index tabulated over the wavelength) in air, rays of mixed wavelengths from above, a black floor below.
+    ray_tracer picks the ordered engine by itself (the rays carry complex indices); every level of the tree equals the oracle's,
+    complex indices included, for ray splitting and for one ray per hit; the energy arriving on the floor through the slab at normal
+    incidence follows Fresnel twice and Beer-Lambert with 4 pi k / lambda once.
+    """
+    from tracer_amd.tracer_engine import TracerEngine
+    from tracer_amd.scene import compile_scene
+    from oracle import engine as oracle_engine
+    n = 4000
+    for single in (False, True):
+        asm, air, glass = _slab_scene(single)
+        b, wl = _bundle(n, air)
+        eng = TracerEngine(asm)
+        eng.ray_tracer(b, reps=6, min_energy=1e-9, tree=True, seed=21)
+        assert eng.stats['engine'] == 'ordered'
+        cs = compile_scene(asm)
+        assert len(cs.materials) == 2 and cs.carries
+        with N.errstate(all='ignore'):
+            o = oracle_engine.trace_bundle(cs, b.get_vertices(), b.get_directions(), b.get_energy(), 6, 1e-9, 21,
+                                           ref_index=b.get_ref_index(), wavelengths=wl)
+        _compare_levels(eng.tree, o)
+        # rays are in glass between the plates and nowhere else
+        B2 = eng.tree[2]
+        z0 = eng.tree[1].get_vertices()[2][B2.get_parents()]
+        going_down_inside = (N.abs(z0 - 0.5) < 1e-9) & (eng.tree[1].get_directions()[2][B2.get_parents()] < 0) & (N.abs(B2.get_vertices()[2]) < 1e-9)
+        assert going_down_inside.sum() > n // 2
+    # known answer at normal incidence, one wavelength, splitting optics, no second-order paths (reps = 3: top, bottom, floor)
+    asm, air, glass = _slab_scene(False)
+    from tracer_amd.ray_bundle import RayBundle
+    m = 64
+    lam = 2.0e-6
+    wl = N.full(m, lam)
+    b = RayBundle(vertices=N.vstack((N.linspace(-1, 1, m), N.zeros(m), N.full(m, 3.))), directions=N.tile(N.c_[[0., 0., -1.]], (1, m)),
+                  energy=N.ones(m), ref_index=air.m(wl), wavelengths=wl)
+    eng = TracerEngine(asm)
+    eng.ray_tracer(b, reps=3, min_energy=1e-12, tree=True, seed=5)
+    mg = glass.m(N.array([lam]))[0]
+    R = ((1. - mg) / (1. + mg)) ** 2
+    R = R.real                                   # what the reference keeps (optics_callables.py:838-840)
+    # RefractiveAbsorbant takes k from the index of the OUTGOING ray (:882): the refracted ray leaving the slab is in air (k = 0),
+    # the one entering it pays for the 2.5 m of air above with the glass's k -- the reference's behaviour, reproduced.
+    T_in = N.exp(-4. * N.pi * 2.5 * mg.imag / lam)
+    B2 = eng.tree[2]
+    leaving = (N.abs(B2.get_vertices()[2]) < 1e-9) & (B2.get_directions()[2] < 0)       # out of the slab's underside, towards the floor
+    assert leaving.sum() == m and N.allclose(B2.get_energy()[leaving], (1. - R) * T_in * (1. - R), rtol=1e-12)
+    assert N.allclose(B2.get_ref_index()[leaving], 1.) and T_in < 0.5
+    absorbed, hits = asm.get_surfaces()[2].get_optics_manager().get_all_hits()
+    assert N.allclose(N.sort(absorbed)[-m:], (1. - R) * T_in * (1. - R), rtol=1e-12) and N.allclose(hits[2], -1.)
+
+
+def test_engines_refuse_what_they_do_not_carry(ctx):
+    from tracer_amd.tracer_engine import TracerEngine
+    from tracer_amd._cabi import TracerAmdError
+    asm, air, glass = _slab_scene(True)
+    b, wl = _bundle(100, air)
+    eng = TracerEngine(asm)
+    with pytest.raises(TracerAmdError) as err:
+        eng.ray_tracer(b, reps=3, min_energy=1e-9, tree=False, engine='fast')
+    assert 'trc_trace_ordered' in str(err.value)
+    from tracer_amd.ray_bundle import RayBundle
+    plain = RayBundle(vertices=b.get_vertices(), directions=b.get_directions(), energy=b.get_energy(), ref_index=N.ones(100))
+    with pytest.raises(ValueError):                      # no wavelengths: the materials cannot be evaluated
+        eng.ray_tracer(plain, reps=3, min_energy=1e-9)
+
+
+def _poly_scene():
+    from tracer_amd import optics_callables as opt
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM
+    from tracer_amd.spatial_geometry import translate, rotx
+    ths = N.linspace(0., N.pi / 2., 7)
+    wls = N.linspace(0.25e-6, 2.6e-6, 5)
+    grid = 0.2 + 0.7 * N.outer(N.cos(ths) ** 0.5, 1. / (1. + (wls * 1e6 - 1.) ** 2))
+    wall = lambda: opt.Lambertian_directional_axisymmetric_piecewise_PolychromaticAbsorberPolychromatic(ths, grid, wls)
+    floor = AssembledObject(surfs=[Surface(RectPlateGM(4., 4.), wall())], transform=translate(0., 0., 0.))
+    roof = AssembledObject(surfs=[Surface(RectPlateGM(4., 4.), opt.Reflective(0.1))], transform=N.dot(translate(0., 0., 1.5), rotx(N.pi)))
+    side = AssembledObject(surfs=[Surface(RectPlateGM(4., 1.5), opt.Lambertian(0.3))], transform=N.dot(translate(0., 2., 0.75), rotx(N.pi / 2.)))
+    return Assembly(objects=[floor, roof, side]), (ths, wls, grid)
+
+
+def test_polychromatic_bundle_through_a_cavity(ctx):
+    """
+    Rays carrying spectra bounce between a polychromatic wall (floor), a mirror (roof) and a diffuse side wall.  Every level of the
+    ordered engine's tree equals the oracle's: spectra (W,n), their wavelength grids, energies.  Energy bookkeeping: after the
+    polychromatic wall a ray's energy IS the integral of its spectrum; the mirror scales both by 0.9; the accountant of the wall
+    collects incident minus outgoing spectra.
+    """
+    from tracer_amd.tracer_engine import TracerEngine
+    from tracer_amd.scene import compile_scene
+    from tracer_amd.ray_bundle import RayBundle
+    from oracle import engine as oracle_engine
+    asm, (ths, wls, grid) = _poly_scene()
+    n, W = 3000, 9
+    rng = N.random.RandomState(8)
+    v = N.vstack((rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), N.full(n, 1.)))
+    d = N.vstack((rng.uniform(-0.4, 0.4, n), rng.uniform(-0.4, 0.4, n), -N.ones(n)))
+    d /= N.sqrt(N.sum(d ** 2, axis=0))
+    swl = N.sort(rng.uniform(0.3e-6, 2.5e-6, size=(W, n)), axis=0)
+    spec = rng.uniform(0.5, 2., size=(W, n)) * 1e6
+    e = N.trapezoid(spec, swl, axis=0)
+    b = RayBundle(vertices=v, directions=d, energy=e, spectra=spec, wavelengths=swl)
+    eng = TracerEngine(asm)
+    eng.ray_tracer(b, reps=5, min_energy=1e-9, tree=True, seed=33)
+    assert eng.stats['engine'] == 'ordered'
+    cs = compile_scene(asm)
+    with N.errstate(all='ignore'):
+        o = oracle_engine.trace_bundle(cs, v, d, e, 5, 1e-9, 33, wavelengths=swl, spectra=spec)
+    _compare_levels(eng.tree, o, complex_index=False, spectra=True)
+    # level 1: every ray met the floor; its energy is the integral of the spectrum it leaves with
+    B1 = eng.tree[1]
+    assert B1.get_num_rays() == n
+    assert N.allclose(B1.get_energy(), N.trapezoid(B1.get_spectra(), B1.get_wavelengths(), axis=0), rtol=1e-12)
+    assert (B1.get_spectra() < spec).all()
+    # the mirror keeps the ratio
+    B2 = eng.tree[2]
+    on_roof = N.abs(B2.get_vertices()[2] - 1.5) < 1e-9
+    assert on_roof.sum() > 100
+    assert N.allclose(B2.get_spectra()[:, on_roof], 0.9 * B1.get_spectra()[:, B2.get_parents()[on_roof]], rtol=1e-12)
+    assert N.allclose(B2.get_energy()[on_roof], 0.9 * B1.get_energy()[B2.get_parents()[on_roof]], rtol=1e-12)
+    # accountants of the wall: absorbed energy per hit, then (wavelengths, absorbed spectra) -- the canonical order
+    floor_opt = asm.get_surfaces()[0].get_optics_manager()
+    absorbed, (hw, hs) = floor_opt.get_all_hits()
+    assert hs.shape[0] == W and hs.shape == hw.shape and hs.shape[1] == len(absorbed) >= n
+    assert N.allclose(hs[:, :n], spec - B1.get_spectra(), rtol=1e-12)
+    assert N.allclose(absorbed[:n], e - B1.get_energy(), rtol=1e-9)
+
+    # the per-surface protocol (the reference's own loop over Surface objects, optics still on the device) carries spectra too:
+    # the first interaction is deterministic in energy and spectrum
+    eng2 = TracerEngine(_poly_scene()[0])
+    eng2.ray_tracer(RayBundle(vertices=v, directions=d, energy=e, spectra=spec.copy(), wavelengths=swl), reps=2, min_energy=1e-9, tree=True, engine='protocol')
+    P1 = eng2.tree[1]
+    assert N.array_equal(P1.get_parents(), B1.get_parents())
+    assert N.allclose(P1.get_spectra(), B1.get_spectra(), rtol=1e-12) and N.allclose(P1.get_energy(), B1.get_energy(), rtol=1e-12)
+
+
+def test_polychromatic_wall_without_spectra_is_an_error(ctx):
+    from tracer_amd.tracer_engine import TracerEngine
+    from tracer_amd._cabi import TracerAmdError
+    from tracer_amd.ray_bundle import RayBundle
+    asm, _ = _poly_scene()
+    b = RayBundle(vertices=N.c_[[0., 0., 1.]], directions=N.c_[[0., 0., -1.]], energy=N.ones(1))
+    with pytest.raises(TracerAmdError) as err:
+        TracerEngine(asm).ray_tracer(b, reps=2, min_energy=1e-9)
+    assert 'spectra' in str(err.value)

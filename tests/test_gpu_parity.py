@@ -115,24 +115,44 @@ def test_geometry_vs_oracle_large_fans(ctx):
             assert close.all(), (kind, int((~close).sum()))
 
 
-def optics_apply(ctx, kind, opt, extra, frame, d, e, ref, wl, nrm, pts, seed, event, path=None):
+def optics_apply(ctx, kind, opt, extra, frame, d, e, ref, wl, nrm, pts, seed, event, path=None, mat=None, spec=None, swl=None):
+    """trc_optics_apply on one surface's hits.  ref may be complex; mat (K, n) complex: the materials at the rays' wavelengths;
+    spec, swl (W, n): a polychromatic bundle.  Returns dirs, energy, parents, ref, rid[, spectra]."""
     from tracer_amd import _cabi
     desc = _desc(0, frame, [], extra, kind, opt)
     n = d.shape[1]
-    d = _cabi.f64(d); e = _cabi.f64(e); ref = _cabi.f64(ref); wl = _cabi.f64(wl); nrm = _cabi.f64(nrm); pts = _cabi.f64(pts)
+    cplx = N.iscomplexobj(ref) or mat is not None
+    ref = N.asarray(ref)
+    d = _cabi.f64(d); e = _cabi.f64(e); wl = _cabi.f64(wl); nrm = _cabi.f64(nrm); pts = _cabi.f64(pts)
+    re_in, im_in = _cabi.f64(ref.real), (_cabi.f64(ref.imag) if cplx else None)
     extra = _cabi.f64(extra)
     rid = N.arange(n, dtype=N.uint64) + N.uint64(1000)
     org = _cabi.f64(pts - d * (N.ones(n) if path is None else path))      # ray origins: the attenuating optics measure the path
-    rin = _cabi.make_rays(n, org[0], org[1], org[2], dx=d[0], dy=d[1], dz=d[2], e=e, ref_index=ref, wavelength=wl, rid=rid)
+    matr = None
+    if mat is not None:
+        matr = N.empty((2 * len(mat), n))
+        matr[0::2], matr[1::2] = N.real(mat), N.imag(mat)
+    rin = _cabi.make_rays(n, org[0], org[1], org[2], dx=d[0], dy=d[1], dz=d[2], e=e, ref_index=re_in, wavelength=wl, rid=rid,
+                          ref_index_im=im_in, mat=matr, spec_wl=None if spec is None else _cabi.f64(swl),
+                          spectra=None if spec is None else _cabi.f64(spec))
     m = 2 * n
     o = dict((k, N.empty(m)) for k in ('x', 'y', 'z', 'dx', 'dy', 'dz', 'e', 'ref'))
     par = N.empty(m, dtype=N.int64)
-    rout = _cabi.make_rays(m, o['x'], o['y'], o['z'], o['dx'], o['dy'], o['dz'], o['e'], parent=par, ref_index=o['ref'])
+    oim = N.empty(m) if cplx else None
+    osp = N.empty((spec.shape[0], m)) if spec is not None else None
+    oswl = N.empty((spec.shape[0], m)) if spec is not None else None
+    rout = _cabi.make_rays(m, o['x'], o['y'], o['z'], o['dx'], o['dy'], o['dz'], o['e'], parent=par, ref_index=o['ref'],
+                           ref_index_im=oim, spec_wl=oswl, spectra=osp)
     _cabi.check(ctx.lib.trc_optics_apply(ctx.handle, C.byref(desc), len(extra), _cabi.ptr(extra) if len(extra) else None, C.byref(rin),
                                          _cabi.ptr(pts[0]), _cabi.ptr(pts[1]), _cabi.ptr(pts[2]), _cabi.ptr(nrm[0]), _cabi.ptr(nrm[1]),
                                          _cabi.ptr(nrm[2]), seed, event, C.byref(rout)))
     k = rout.n
-    return N.vstack((o['dx'][:k], o['dy'][:k], o['dz'][:k])), o['e'][:k], par[:k], o['ref'][:k], rid
+    ref_out = o['ref'][:k] + 1j * oim[:k] if cplx else o['ref'][:k]
+    res = (N.vstack((o['dx'][:k], o['dy'][:k], o['dz'][:k])), o['e'][:k], par[:k], ref_out, rid)
+    if spec is not None:
+        assert N.array_equal(oswl[:, :k], swl[:, par[:k]])
+        res = res + (osp[:, :k],)
+    return res
 
 
 def test_optics_vs_reference_and_oracle(ctx):
@@ -142,26 +162,52 @@ def test_optics_vs_reference_and_oracle(ctx):
     frame, nrm, d, pts, e, wl = o['frame'], o['normals'], o['dirs'], o['points'], o['energy'], o['wavelengths']
     up = frame[:3, 2]
     names = case_names(o)
+    deterministic = ('transparent', 'reflective', 'one_sided_reflective', 'real_reflective_sigma0', 'reflective_spectral',
+                     'refractive_split', 'fresnel_conductor', 'refractive_transmissive_split', 'refractive_transmissive_one_coefficient',
+                     # SURVEY 8(f)2, rest: complex indices of tabulated materials, attenuation from Im m; polychromatic bundles
+                     'material_split', 'material_absorbant_split', 'material_absorbant_scaled',
+                     'poly_transparent', 'poly_reflective', 'poly_one_sided_reflective', 'poly_real_reflective', 'poly_refractive_split')
+    seen = 0
     for i, name in enumerate(names):
         pre = 'o%d_' % i
         kind, opt, extra, ref_in = int(o[pre + 'kind']), list(o[pre + 'opt']), o[pre + 'extra'], o[pre + 'ref_in']
         path = o[pre + 'path']
-        dirs, en, par, ref, rid = optics_apply(ctx, kind, opt, extra, frame, d, e, ref_in, wl, nrm, pts, 4242, 3, path=path)
-        if name in ('transparent', 'reflective', 'one_sided_reflective', 'real_reflective_sigma0', 'reflective_spectral',
-                    'refractive_split', 'fresnel_conductor', 'refractive_transmissive_split', 'refractive_transmissive_one_coefficient'):
+        mat = o[pre + 'mat'] if (pre + 'mat') in o.files else None
+        spec = o[pre + 'spec_in'] if (pre + 'spec_in') in o.files else None
+        swl = o[pre + 'spec_wl'] if spec is not None else None
+        wl_i = N.zeros_like(wl) if spec is not None else wl          # a polychromatic bundle has no single wavelength per ray
+        res = optics_apply(ctx, kind, opt, extra, frame, d, e, ref_in, wl_i, nrm, pts, 4242, 3, path=path, mat=mat, spec=spec, swl=swl)
+        dirs, en, par, ref, rid = res[:5]
+        if name in deterministic:
+            seen += 1
             assert N.array_equal(par, o[pre + 'out_parents']), name
             assert N.allclose(dirs, o[pre + 'out_dirs'], rtol=RT, atol=1e-9), name
             assert N.allclose(en, o[pre + 'out_energy'], rtol=RT, atol=1e-12), name
             if (pre + 'out_ref') in o.files:
-                assert N.allclose(ref, o[pre + 'out_ref']), name
+                assert N.allclose(ref, o[pre + 'out_ref'], rtol=1e-12, atol=0), name
+                assert N.iscomplexobj(o[pre + 'out_ref']) == (mat is not None), name
+            if spec is not None:
+                assert N.allclose(res[5], o[pre + 'out_spectra'], rtol=1e-12, atol=0), name
         if name.startswith('lambertian_absorbant'):       # energies are deterministic: against the reference's own
             assert N.allclose(en, o[pre + 'out_energy'], rtol=RT, atol=1e-12), name
-        blocks = optics.shade(kind, opt, extra, up, d, e, ref_in, wl, nrm, 4242, rid, 3, path=path)
+        if name in ('polychromatic_wall', 'poly_lambertian', 'poly_lambertian_absorbant', 'poly_lambertian_directional', 'poly_lambertian_specular'):
+            # the directions are drawn; spectra and energies are not
+            assert N.allclose(res[5], o[pre + 'out_spectra'], rtol=1e-12, atol=0), name
+            assert N.allclose(en, o[pre + 'out_energy'], rtol=RT, atol=1e-12), name
+        ext = {}
+        if mat is not None:
+            ext['mat'] = mat
+        if spec is not None:
+            ext.update(spec=spec, swl=swl)
+        blocks = optics.shade(kind, opt, extra, up, d, e, ref_in, wl_i, nrm, 4242, rid, 3, path=path, ext=ext)
         assert N.array_equal(par, N.hstack([b['sel'] for b in blocks])), name
         # trig of ~2*pi*u on the device vs numpy differ in the last bits; 1e-9 still holds
         assert N.allclose(dirs, N.hstack([b['directions'] for b in blocks]), rtol=RT, atol=1e-9), name
         assert N.allclose(en, N.hstack([b['energy'] for b in blocks]), rtol=RT, atol=1e-12), name
         assert N.allclose(ref, N.hstack([b['ref'] for b in blocks])), name
+        if spec is not None:
+            assert N.allclose(res[5], N.hstack([b['spectra'] for b in blocks]), rtol=1e-12, atol=0), name
+    assert seen == len(deterministic)
 
 
 def test_sources_vs_oracle(ctx):

@@ -59,29 +59,57 @@ def test_core_geometry_vs_reference(hc):
 
 
 def test_core_optics_vs_oracle_same_streams(hc):
+    """every optics fixture case through the device code compiled for the host (trc_shade_x: complex indices, materials and spectra
+    included) against the oracle on the same Philox streams"""
     from oracle import optics
     o = load('optics.npz')
     frame = o['frame']
     nrm, d, e, wl = [N.ascontiguousarray(o[k]) for k in ('normals', 'dirs', 'energy', 'wavelengths')]
     H = d.shape[1]
     rid = N.arange(H, dtype=N.uint64) + N.uint64(2 ** 33 + 5)
+    carried = 0
     for i, name in enumerate(case_names(o)):
         pre = 'o%d_' % i
         kind, opt, extra = int(o[pre + 'kind']), list(o[pre + 'opt']), N.ascontiguousarray(o[pre + 'extra'])
-        ref_in = N.ascontiguousarray(o[pre + 'ref_in'])
+        ref_c = o[pre + 'ref_in']
+        ref_in = N.ascontiguousarray(N.real(ref_c))
+        mat = o[pre + 'mat'] if (pre + 'mat') in o.files else None
+        spec = N.ascontiguousarray(o[pre + 'spec_in']) if (pre + 'spec_in') in o.files else None
+        swl = N.ascontiguousarray(o[pre + 'spec_wl']) if spec is not None else None
+        W = 0 if spec is None else spec.shape[0]
+        wl_i = N.zeros(H) if spec is not None else wl
+        ref_im = N.ascontiguousarray(N.imag(ref_c)) if N.iscomplexobj(ref_c) else None
+        matr = None
+        if mat is not None:
+            matr = N.empty((2 * len(mat), H))
+            matr[0::2], matr[1::2] = N.real(mat), N.imag(mat)
         desc = _desc(0, frame, [], extra, kind, opt)
         out = [N.empty(2 * H) for _ in range(5)]
         blk = N.empty(2 * H, dtype=N.int32)
+        o_im = N.zeros(2 * H)
+        o_spec = N.zeros((max(W, 1), 2 * H))
         path = N.ascontiguousarray(o[pre + 'path'])
-        hc.hc_shade_path(C.byref(desc), _p(extra), C.c_long(H), _p(d[0]), _p(d[1]), _p(d[2]), _p(e), _p(ref_in), _p(wl), _p(nrm[0]), _p(nrm[1]),
-                         _p(nrm[2]), _p(rid, C.c_uint64), C.c_uint64(987654321012), 2, *([_p(a) for a in out] + [_p(blk, C.c_int32), _p(path)]))
-        blocks = optics.shade(kind, opt, extra, frame[:3, 2], d, e, ref_in, wl, nrm, 987654321012, rid, 2, path=path)
+        hc.hc_shade_x(C.byref(desc), _p(extra), C.c_long(H), _p(d[0]), _p(d[1]), _p(d[2]), _p(e), _p(ref_in), _p(wl_i), _p(nrm[0]), _p(nrm[1]),
+                      _p(nrm[2]), _p(rid, C.c_uint64), C.c_uint64(987654321012), 2, *([_p(a) for a in out] + [_p(blk, C.c_int32), _p(path)]),
+                      None if ref_im is None else _p(ref_im), 0 if matr is None else len(mat), None if matr is None else _p(matr),
+                      W, None if spec is None else _p(swl), None if spec is None else _p(spec), _p(o_im), _p(o_spec))
+        ext = {}
+        if mat is not None:
+            ext['mat'] = mat
+        if spec is not None:
+            ext.update(spec=spec, swl=swl)
+        with N.errstate(all='ignore'):
+            blocks = optics.shade(kind, opt, extra, frame[:3, 2], d, e, ref_c, wl_i, nrm, 987654321012, rid, 2, path=path, ext=ext)
         slots = N.concatenate([N.nonzero(blk == b)[0] for b in (0, 1)])
         par = N.where(slots < H, slots, slots - H)
         assert N.array_equal(par, N.hstack([b['sel'] for b in blocks])), name
         assert N.allclose(N.vstack([a[slots] for a in out[:3]]), N.hstack([b['directions'] for b in blocks]), rtol=1e-9, atol=1e-9), name
         assert N.allclose(out[3][slots], N.hstack([b['energy'] for b in blocks]), rtol=1e-9, atol=1e-12), name
-        assert N.allclose(out[4][slots], N.hstack([b['ref'] for b in blocks])), name
+        assert N.allclose(out[4][slots] + 1j * o_im[slots], N.hstack([b['ref'] for b in blocks]), rtol=1e-12, atol=0), name
+        if spec is not None:
+            assert N.allclose(o_spec[:, slots], N.hstack([b['spectra'] for b in blocks]), rtol=1e-12, atol=0), name
+        carried += int(mat is not None or spec is not None)
+    assert carried == 15
 
 
 def test_core_sources_vs_oracle(hc):

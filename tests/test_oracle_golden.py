@@ -165,6 +165,91 @@ def test_optics_variate_replay():
     assert sigma > 0
 
 
+def test_optics_carried_columns_replay():
+    """SURVEY 8(f)2, rest: refraction between materials of complex, wavelength-dependent index with attenuation from Im m
+    (Refractive, RefractiveAbsorbant), and polychromatic bundles (the wall that integrates spectra, the classes that scale them) --
+    the oracle against the reference's own outputs."""
+    o = load('optics.npz')
+    frame, nrm, d, pts, e = o['frame'], o['normals'], o['dirs'], o['points'], o['energy']
+    H = d.shape[1]
+    up = frame[:3, 2]
+    rid = N.arange(H, dtype=N.uint64)
+    wl1 = o['wavelengths']
+
+    def blocks_of(pre, ext, wl=None, path=None):
+        return optics.shade(int(o[pre + 'kind']), list(o[pre + 'opt']), o[pre + 'extra'], up, d, e, o[pre + 'ref_in'],
+                            wl1 if wl is None else wl, nrm, 1, rid, 1, path=o[pre + 'path'] if path is None else path, ext=ext)
+
+    def cat(blocks, key):
+        return N.hstack([b[key] for b in blocks])
+
+    # deterministic material cases: everything, the complex indices of the outgoing rays included
+    for name in ('material_split', 'material_absorbant_split', 'material_absorbant_scaled'):
+        pre = _optics_case(o, name)
+        b = blocks_of(pre, dict(mat=o[pre + 'mat']))
+        assert N.array_equal(cat(b, 'sel'), o[pre + 'out_parents']), name
+        assert N.allclose(cat(b, 'directions'), o[pre + 'out_dirs'], **TOL), name
+        assert N.allclose(cat(b, 'energy'), o[pre + 'out_energy'], rtol=1e-9, atol=1e-12), name
+        assert N.iscomplexobj(o[pre + 'out_ref']) and N.allclose(cat(b, 'ref'), o[pre + 'out_ref'], rtol=1e-12, atol=0), name
+    pre, pre_a = _optics_case(o, 'material_split'), _optics_case(o, 'material_absorbant_split')
+    ratio = o[pre_a + 'out_energy'] / o[pre + 'out_energy']
+    assert ratio.max() <= 1. and ratio.min() < 0.5 and (ratio == 1.).any(), "the fixture attenuates in glass, not in air"
+    # a ray in neither medium enters material_1
+    assert o[pre + 'ref_in'][5] == 1.2 and N.allclose(o[pre + 'out_ref'][H:][N.nonzero(o[pre + 'out_parents'][H:] == 5)[0]], o[pre + 'mat'][0][5])
+    # one ray per hit: replay the reflect-or-refract draw
+    pre = _optics_case(o, 'material_single')
+    m1, mat = o[pre + 'ref_in'], o[pre + 'mat']
+    m2 = N.where(m1 == mat[0], mat[1], mat[0])
+    refr, out_dirs = optics.refractions(m1.real, m2.real, d, nrm)
+    R = N.ones(H)
+    with N.errstate(all='ignore'):
+        R[refr] = N.real(optics.fresnel(d[:, refr], nrm[:, refr], m1[refr], m2[refr]))
+    refl = o[pre + 'draw_u'] <= R
+    dr = N.zeros((3, H))
+    dr[:, refr] = out_dirs
+    assert N.allclose(N.hstack((optics.reflections(d, nrm)[:, refl], dr[:, ~refl])), o[pre + 'out_dirs'], **TOL)
+    assert N.array_equal(N.hstack((N.nonzero(refl)[0], N.nonzero(~refl)[0])), o[pre + 'out_parents'])
+    assert N.allclose(N.hstack((m1[refl], m2[~refl])), o[pre + 'out_ref'], rtol=1e-12, atol=0)
+    assert refl.any() and (~refl).any() and (~refr).any()
+    # perturbed normals: replay theta, phi
+    pre = _optics_case(o, 'material_split_sigma')
+    th, phi = o[pre + 'draw_g0'], o[pre + 'draw_phi']
+    err = N.vstack((N.sin(th) * N.cos(phi), N.sin(th) * N.sin(phi), N.cos(th)))
+    rots = optics.rotation_to_z(nrm.T)
+    pn = N.array([N.dot(rots[i], err[:, i]) for i in range(H)]).T
+    m1, mat = o[pre + 'ref_in'], o[pre + 'mat']
+    m2 = N.where(m1 == mat[0], mat[1], mat[0])
+    refr, out_dirs = optics.refractions(m1.real, m2.real, d, pn)
+    R = N.ones(H)
+    with N.errstate(all='ignore'):
+        R[refr] = N.real(optics.fresnel(d[:, refr], pn[:, refr], m1[refr], m2[refr]))
+    assert N.allclose(N.hstack((optics.reflections(d, pn), out_dirs)), o[pre + 'out_dirs'], **TOL)
+    assert N.allclose(N.hstack((e * R, e[refr] * (1. - R[refr]))), o[pre + 'out_energy'], **TOL)
+
+    # polychromatic bundles
+    pre = _optics_case(o, 'polychromatic_wall')
+    b = blocks_of(pre, dict(spec=o[pre + 'spec_in'], swl=o[pre + 'spec_wl']), wl=N.zeros(H))
+    assert N.allclose(b[0]['spectra'], o[pre + 'out_spectra'], rtol=1e-12, atol=0)
+    assert N.allclose(b[0]['energy'], o[pre + 'out_energy'], rtol=1e-12, atol=0)
+    assert N.allclose(optics.lambertian_directions(nrm, o[pre + 'draw_xi1'], o[pre + 'draw_xi2'], N.pi / 2.), o[pre + 'out_dirs'], **TOL)
+    assert (o[pre + 'out_spectra'] < o[pre + 'spec_in']).all()
+    scaled = 0
+    for name in case_names(o):
+        if not name.startswith('poly_'):
+            continue
+        pre = _optics_case(o, name)
+        b = blocks_of(pre, dict(spec=o[pre + 'spec_in'], swl=o[pre + 'spec_wl']), wl=N.zeros(H))
+        if name == 'poly_lambertian_specular':      # which rays are mirrored is drawn; the spectrum is handed on unchanged either way
+            assert N.array_equal(o[pre + 'out_spectra'], o[pre + 'spec_in'])
+            assert N.allclose(cat(b, 'spectra'), o[pre + 'out_spectra'], rtol=1e-12, atol=0)
+            continue
+        assert N.array_equal(cat(b, 'sel'), o[pre + 'out_parents']), name
+        assert N.allclose(cat(b, 'spectra'), o[pre + 'out_spectra'], rtol=1e-12, atol=0), name
+        assert N.allclose(cat(b, 'energy'), o[pre + 'out_energy'], rtol=1e-9, atol=1e-12), name
+        scaled += int(not N.array_equal(o[pre + 'out_spectra'], o[pre + 'spec_in'][:, o[pre + 'out_parents']]))
+    assert scaled == 5, "Reflective, OneSidedReflective, RealReflective, Lambertian and the directional wall scale the spectrum"
+
+
 def test_fresnel_to_attenuating_grid():
     o = load('optics.npz')
     with N.errstate(all='ignore'):

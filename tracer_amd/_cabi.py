@@ -39,7 +39,8 @@ SURF_CAPTURE_HITS = 0x1
 (OPT_TRANSPARENT, OPT_REFLECTIVE, OPT_ONE_SIDED_REFLECTIVE, OPT_REAL_REFLECTIVE,
  OPT_ONE_SIDED_REAL_REFLECTIVE, OPT_LAMBERTIAN, OPT_LAMBERTIAN_SPECULAR, OPT_REFRACTIVE_HOMOGENOUS,
  OPT_REFLECTIVE_SPECTRAL, OPT_LAMBERTIAN_DIRECTIONAL, OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL,
- OPT_FRESNEL_CONDUCTOR, OPT_SEMI_LAMBERTIAN, OPT_REFRACTIVE_SCATTERING) = range(14)
+ OPT_FRESNEL_CONDUCTOR, OPT_SEMI_LAMBERTIAN, OPT_REFRACTIVE_SCATTERING, OPT_REFRACTIVE_MATERIAL,
+ OPT_LAMBERTIAN_POLYCHROMATIC) = range(16)
 
 # enum trc_source_kind
 SRC_PILLBOX_DISK, SRC_PILLBOX_RECT, SRC_BUIE_DISK, SRC_BUIE_RECT, SRC_PILLBOX_TRIANGLE, SRC_VF_CYLINDER, SRC_VF_FRUSTUM = range(7)
@@ -57,10 +58,11 @@ class SurfaceDesc(C.Structure):
 
 
 class Rays(C.Structure):
-    _fields_ = [('n', C.c_int64), ('on_device', C.c_int32), ('reserved', C.c_int32),
+    _fields_ = [('n', C.c_int64), ('on_device', C.c_int32), ('n_spec', C.c_int32),
                 ('x', _p_f64), ('y', _p_f64), ('z', _p_f64),
                 ('dx', _p_f64), ('dy', _p_f64), ('dz', _p_f64), ('e', _p_f64),
-                ('parent', _p_i64), ('ref_index', _p_f64), ('wavelength', _p_f64), ('rid', _p_u64)]
+                ('parent', _p_i64), ('ref_index', _p_f64), ('wavelength', _p_f64), ('rid', _p_u64),
+                ('ref_index_im', _p_f64), ('spec_wl', _p_f64), ('spectra', _p_f64), ('n_mat', C.c_int64), ('mat', _p_f64)]
 
 
 class SourceDesc(C.Structure):
@@ -162,8 +164,8 @@ def load_library(path=None):
             fn = getattr(lib, name)   # AttributeError here means the .so is stale vs the header
             fn.restype = res
             fn.argtypes = args
-        if lib.trc_abi_version() != 1:
-            raise TracerAmdError(-1, "ABI version mismatch: library %d, binding 1" % lib.trc_abi_version())
+        if lib.trc_abi_version() != 2:
+            raise TracerAmdError(-1, "ABI version mismatch: library %d, binding 2" % lib.trc_abi_version())
         if path is None:
             _lib = lib
         return lib
@@ -203,8 +205,8 @@ def ptr(a, typ=_p_f64):
 
 
 def make_rays(n, x=None, y=None, z=None, dx=None, dy=None, dz=None, e=None, parent=None, ref_index=None,
-              wavelength=None, rid=None):
-    """Fill a Rays struct from 1-D contiguous arrays (the caller keeps them alive)."""
+              wavelength=None, rid=None, ref_index_im=None, spec_wl=None, spectra=None, mat=None):
+    """Fill a Rays struct from 1-D contiguous arrays (the caller keeps them alive); spec_wl, spectra: C-contiguous (W, n)."""
     r = Rays()
     r.n = n
     r.on_device = 0
@@ -215,6 +217,16 @@ def make_rays(n, x=None, y=None, z=None, dx=None, dy=None, dz=None, e=None, pare
     r.ref_index = ptr(ref_index)
     r.wavelength = ptr(wavelength)
     r.rid = ptr(rid, _p_u64)
+    r.ref_index_im = ptr(ref_index_im)
+    if spectra is not None:
+        assert spec_wl is not None and spec_wl.shape == spectra.shape and spectra.ndim == 2 and spectra.shape[1] >= n
+        assert spectra.flags.c_contiguous and spec_wl.flags.c_contiguous
+        r.n_spec = spectra.shape[0]
+        r.spec_wl, r.spectra = ptr(spec_wl), ptr(spectra)
+    if mat is not None:
+        assert mat.ndim == 2 and mat.shape[0] % 2 == 0 and mat.shape[1] >= n and mat.flags.c_contiguous
+        r.n_mat = mat.shape[0] // 2
+        r.mat = ptr(mat)
     return r
 
 

@@ -942,6 +942,8 @@ struct trc_ray_out {
                // 1 reflected, 2 refracted (optics_callables.py:1136-1168: "stacking together the scattered, reflected and refracted rays")
     double back;   // 0: the ray leaves from the hit point.  > 0: a volume event on the way -- the ray never reached the surface, it
                    // leaves from the point `back` before the hit along its old direction, and the surface records nothing
+    double sf;     // factor on the spectrum a polychromatic ray carries (`outg._spectra *= ...` of the classes that have the line);
+                   // read by the ordered engine and the per-surface protocol only
 };
 
 TRC_HD void trc_reflect(double dx, double dy, double dz, double nx, double ny, double nz, double *ox,
@@ -1185,6 +1187,8 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
     out[1].blk = 1;
     out[0].back = 0.0;
     out[1].back = 0.0;
+    out[0].sf = 1.0;
+    out[1].sf = 1.0;
     switch (opt_kind) {
     case TRC_OPT_TRANSPARENT:                                       // :106-113
         out[0].dx = dx; out[0].dy = dy; out[0].dz = dz; out[0].e = e;
@@ -1195,6 +1199,7 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
         double eo = e * (1.0 - opt[0]) * trc_iam(opt[1], opt[2], dx, dy, dz, nx, ny, nz);       // Reflective_IAM :283-300
         if (opt_kind == TRC_OPT_ONE_SIDED_REFLECTIVE && (dx * ux + dy * uy + dz * uz) > 0.0) eo = 0.0;
         out[0].e = eo;
+        out[0].sf = 1.0 - opt[0];                                   // :137-138
         return 1;
     }
     case TRC_OPT_REFLECTIVE_SPECTRAL: {                             // :183-193
@@ -1223,6 +1228,7 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
         double eo = e * (1.0 - opt[0]) * trc_iam(opt[3], opt[4], dx, dy, dz, nx, ny, nz);       // RealReflective_IAM :320-329 (ideal normal)
         if (opt_kind == TRC_OPT_ONE_SIDED_REAL_REFLECTIVE && (dx * ux + dy * uy + dz * uz) > 0.0) eo = 0.0;
         out[0].e = eo;
+        out[0].sf = 1.0 - opt[0];                                   // :266-267
         return 1;
     }
     case TRC_OPT_LAMBERTIAN: {                                      // :154-176
@@ -1231,7 +1237,10 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
         trc_pillbox_dir(TRC_TWO_PI * u0, u1, opt[1], &ax, &ay, &az);
         trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
         if (opt[2] != 0.0) out[0].e = e * exp(-opt[2] * (path * opt[3])) * (1.0 - opt[0]);      // LambertianAbsorbant :895-906
-        else out[0].e = e * (1.0 - opt[0]) * trc_iam(opt[4], opt[5], dx, dy, dz, nx, ny, nz);  // Lambertian_IAM :302-318
+        else {
+            out[0].e = e * (1.0 - opt[0]) * trc_iam(opt[4], opt[5], dx, dy, dz, nx, ny, nz);   // Lambertian_IAM :302-318
+            out[0].sf = 1.0 - opt[0];                               // :173-174 (LambertianAbsorbant builds its Lambertian with 0, :897)
+        }
         return 1;
     }
     case TRC_OPT_SEMI_LAMBERTIAN: {                                 // :514-531 as documented (:507-509)
@@ -1293,6 +1302,7 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
             }
         }
         out[0].e = e * (1.0 - ab);
+        if (opt_kind == TRC_OPT_LAMBERTIAN_DIRECTIONAL && mode == 0) out[0].sf = 1.0 - ab;       // :358-359
         return 1;
     }
     case TRC_OPT_FRESNEL_CONDUCTOR: {                               // :1536-1558
@@ -1348,6 +1358,171 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
         out[0].dx = dx; out[0].dy = dy; out[0].dz = dz; out[0].e = 0.0;
         return 1;
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Rays of the ordered engine and of the per-surface protocol carry more than the fast engines' record: the imaginary part of a
+// complex refractive index (media that attenuate) and, for polychromatic bundles, a sampled spectrum.  trc_shade_x is trc_shade
+// plus the optics that read them.
+// ---------------------------------------------------------------------------------------------
+struct trc_ray_ext {
+    double ref_im;                 // Im of the index of the medium the ray travels in
+    int W;                         // samples of the spectrum the ray carries (0: none)
+    int n_mat;                     // materials evaluated at this ray's wavelength
+    const double *wl, *spec;       // sample w at wl[w * stride], spec[w * stride]
+    const double *mat;             // Re, Im of material k at mat[2k * stride], mat[(2k + 1) * stride]
+    long long stride;
+};
+
+struct trc_cplx { double re, im; };
+TRC_HD trc_cplx trc_c(double re, double im) { trc_cplx z; z.re = re; z.im = im; return z; }
+TRC_HD trc_cplx trc_cadd(trc_cplx a, trc_cplx b) { return trc_c(a.re + b.re, a.im + b.im); }
+TRC_HD trc_cplx trc_csub(trc_cplx a, trc_cplx b) { return trc_c(a.re - b.re, a.im - b.im); }
+TRC_HD trc_cplx trc_cmul(trc_cplx a, trc_cplx b) { return trc_c(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+TRC_HD trc_cplx trc_cscale(trc_cplx a, double s) { return trc_c(a.re * s, a.im * s); }
+TRC_HD trc_cplx trc_cdiv(trc_cplx a, trc_cplx b) {         // Smith's form, what numpy's complex division does
+    if (fabs(b.re) >= fabs(b.im)) {
+        if (b.re == 0.0 && b.im == 0.0) return trc_c(a.re / fabs(b.re), a.im / fabs(b.im));
+        const double r = b.im / b.re, den = 1.0 / (b.re + b.im * r);
+        return trc_c((a.re + a.im * r) * den, (a.im - a.re * r) * den);
+    }
+    const double r = b.re / b.im, den = 1.0 / (b.re * r + b.im);
+    return trc_c((a.re * r + a.im) * den, (a.im * r - a.re) * den);
+}
+TRC_HD trc_cplx trc_csqrt(trc_cplx z) {                     // principal root
+    if (z.im == 0.0) return z.re >= 0.0 ? trc_c(sqrt(z.re), z.im) : trc_c(0.0, copysign(sqrt(-z.re), z.im));
+    const double m = hypot(z.re, z.im);
+    if (z.re >= 0.0) { const double t = sqrt(0.5 * (m + z.re)); return trc_c(t, z.im / (2.0 * t)); }
+    const double t = sqrt(0.5 * (m - z.re));
+    return trc_c(fabs(z.im) / (2.0 * t), copysign(t, z.im));
+}
+
+// Re of optics.fresnel (optics.py:13-39) evaluated with complex indices, as Refractive._make_refraction_bundle does (:838-840:
+// the complex reflectance is stored into a real array, numpy keeps its real part).  Squares, not squared moduli: reproduced.
+TRC_HD double trc_fresnel_complex_re(double cos_abs, trc_cplx n1, trc_cplx n2) {
+    const double th = acos(cos_abs);
+    const double foo = cos(th), sn = sin(th);
+    trc_cplx q = trc_cscale(trc_cdiv(n1, n2), sn);
+    trc_cplx bar = trc_csqrt(trc_csub(trc_c(1.0, 0.0), trc_cmul(q, q)));
+    trc_cplx a = trc_cscale(n1, foo), b = trc_cmul(n2, bar);
+    trc_cplx rs = trc_cdiv(trc_csub(a, b), trc_cadd(a, b));
+    trc_cplx c = trc_cmul(n1, bar), d = trc_cscale(n2, foo);
+    trc_cplx rp = trc_cdiv(trc_csub(c, d), trc_cadd(c, d));
+    rs = trc_cmul(rs, rs);
+    rp = trc_cmul(rp, rp);
+    return 0.5 * (rs.re + rp.re);
+}
+
+// Refractive (optics_callables.py:726-858) and RefractiveAbsorbant (:908-944)
+// mat0, mat1: materials[0].m(lambda), materials[1].m(lambda) at this ray's wavelength (evaluated by the caller of the C-ABI with the
+// material objects themselves, trc_rays.mat: tables, Sopra files and analytic models alike, and the comparison :750 stays exact)
+TRC_HD int trc_shade_material(const double *opt, trc_cplx mat0, trc_cplx mat1, double dx, double dy, double dz, double e, double ref,
+                              double ref_im, double wl, double path, double nx, double ny, double nz, uint64_t seed, uint64_t rid,
+                              uint32_t event, trc_ray_out out[2], double out_im[2]) {
+    const bool single = opt[0] != 0.0;
+    const double sigma = opt[1];
+    double u0, u1, u2, u3;
+    trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
+    trc_uniform_pair(seed, rid, event, 1, &u2, &u3);
+    if (sigma >= 0.0) {                                         // normal perturbation :767-781
+        double g0, g1;
+        trc_normal_pair(u0, u1, &g0, &g1);
+        double th = sigma * g0, phi = TRC_TWO_PI * u2;
+        double st, ct, sp, cp;
+        trc_sincos(th, &st, &ct);
+        trc_sincos(phi, &sp, &cp);
+        double rx, ry, rz;
+        trc_rotation_to_z_apply(nx, ny, nz, st * cp, st * sp, ct, &rx, &ry, &rz);
+        nx = rx; ny = ry; nz = rz;
+    }
+    const trc_cplx m1 = trc_c(ref, ref_im);
+    const trc_cplx m2 = (m1.re == mat0.re && m1.im == mat0.im) ? mat1 : mat0;     // toggle_ref_idx :750-751
+    const double eta = m2.re / m1.re;                           // refractions(m1.real, m2.real, ...) :786
+    const double cos1 = nx * dx + ny * dy + nz * dz;
+    const bool refracted = (cos1 * cos1) >= (1.0 - eta * eta);
+    double R = 1.0;
+    double tx = 0.0, ty = 0.0, tz = 0.0;
+    if (refracted) {
+        tx = (dx - cos1 * nx) / eta; ty = (dy - cos1 * ny) / eta; tz = (dz - cos1 * nz) / eta;
+        const double cos2 = sqrt(1.0 - 1.0 / (eta * eta) * (1.0 - cos1 * cos1));
+        const double sg = (cos1 < 0.0) ? -1.0 : 1.0;
+        tx += nx * cos2 * sg; ty += ny * cos2 * sg; tz += nz * cos2 * sg;
+        R = trc_fresnel_complex_re(fabs(cos1), m1, m2);
+    }
+    int n_out;
+    out[0].ref = ref; out_im[0] = ref_im;
+    if (single) {                                               // :796-823
+        if (u3 <= R) {
+            trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);
+            out[0].e = e;
+        } else {
+            out[0].dx = tx; out[0].dy = ty; out[0].dz = tz;
+            out[0].e = e; out[0].ref = m2.re; out_im[0] = m2.im; out[0].blk = 1;
+        }
+        n_out = 1;
+    } else {                                                    // :825-835
+        trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);
+        out[0].e = e * R;
+        n_out = 1;
+        if (refracted) {
+            out[1].dx = tx; out[1].dy = ty; out[1].dz = tz;
+            out[1].e = e * (1.0 - R); out[1].ref = m2.re; out_im[1] = m2.im;
+            n_out = 2;
+        }
+    }
+    if (opt[2] != 0.0)          // Absorbant.attenuate :874-882 with a_c None: k and the wavelength of the NEW ray, the path of the old
+        for (int c = 0; c < n_out; ++c)
+            out[c].e = exp(-4.0 * TRC_PI * (path * opt[3]) * out_im[c] / wl) * out[c].e;      // optics.py:210-211
+    return n_out;
+}
+
+// absorptance of the polychromatic Lambertian wall at sample wavelength wl_w (RegularGridInterpolator over (theta, lambda), :399-408)
+TRC_HD double trc_poly_absorptance(const double *tab, double th, double wl_w) { return trc_interp2(tab, th, wl_w); }
+
+// One interaction with everything a ray can carry.  Returns the number of outgoing rays; out_im[c]: Im of their index;
+// *poly_th >= 0: the surface is a polychromatic wall and sample w of the spectrum is scaled by 1 - trc_poly_absorptance(tab, *poly_th,
+// wl_w) (the energy in out[0].e is already the trapezoid integral of that); otherwise the whole spectrum by out[c].sf.
+TRC_HD int trc_shade_x(int opt_kind, const double *opt, const double *extra, int extra_off, int extra_len,
+                       double ux, double uy, double uz, double dx, double dy, double dz, double e, double ref,
+                       double wl, double path, double nx, double ny, double nz, uint64_t seed, uint64_t rid,
+                       uint32_t event, const trc_ray_ext &X, trc_ray_out out[2], double out_im[2], double *poly_th) {
+    *poly_th = -1.0;
+    out_im[0] = out_im[1] = X.ref_im;
+    if (opt_kind == TRC_OPT_REFRACTIVE_MATERIAL) {
+        out[0].blk = 0; out[1].blk = 1; out[0].back = out[1].back = 0.0; out[0].sf = out[1].sf = 1.0;
+        const int k0 = (int)opt[4], k1 = (int)opt[5];
+        trc_cplx m0 = trc_c(NAN, NAN), m1 = m0;
+        if (X.mat && k0 < X.n_mat && k1 < X.n_mat) {
+            m0 = trc_c(X.mat[(long long)(2 * k0) * X.stride], X.mat[(long long)(2 * k0 + 1) * X.stride]);
+            m1 = trc_c(X.mat[(long long)(2 * k1) * X.stride], X.mat[(long long)(2 * k1 + 1) * X.stride]);
+        }
+        return trc_shade_material(opt, m0, m1, dx, dy, dz, e, ref, X.ref_im, wl, path, nx, ny, nz, seed, rid, event, out, out_im);
+    }
+    if (opt_kind == TRC_OPT_LAMBERTIAN_POLYCHROMATIC) {         // :406-425
+        out[0].blk = 0; out[1].blk = 1; out[0].back = out[1].back = 0.0; out[0].sf = out[1].sf = 1.0;
+        out[0].ref = ref;
+        const double dn = dx * nx + dy * ny + dz * nz;
+        const double wx = dn * nx, wy = dn * ny, wz = dn * nz;
+        const double th = acos(sqrt(wx * wx + wy * wy + wz * wz));
+        const double *tab = extra + extra_off;
+        double en = 0.0, y0 = 0.0, x0 = 0.0;                    // N.trapz(spectra, wavelengths, axis=0) :413
+        for (int w = 0; w < X.W; ++w) {
+            const double xw = X.wl[(long long)w * X.stride];
+            const double yw = X.spec[(long long)w * X.stride] * (1.0 - trc_poly_absorptance(tab, th, xw));
+            if (w > 0) en += (xw - x0) * (yw + y0) / 2.0;
+            x0 = xw; y0 = yw;
+        }
+        double u0, u1, ax, ay, az;
+        trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
+        trc_pillbox_dir(TRC_TWO_PI * u0, u1, 1.57079632679489661923, &ax, &ay, &az);
+        trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
+        out[0].e = en;
+        *poly_th = th;
+        return 1;
+    }
+    return trc_shade(opt_kind, opt, extra, extra_off, extra_len, ux, uy, uz, dx, dy, dz, e, ref, wl, path, nx, ny, nz, seed, rid,
+                     event, out);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -135,6 +135,7 @@ struct trc_scene {
     std::vector<trc_surface_desc> surfs;
     std::vector<double> extra_h;
     bool splits;  // some optics can emit two rays per hit
+    bool carries; // some optics read what only rays of the ordered engine carry (complex indices, spectra)
     // device buffers
     double *d_recs, *d_opt, *d_extra;
     int32_t *d_sflags;
@@ -176,17 +177,29 @@ struct trc_scene {
     double *d_h[8];
 };
 
+// what rays of the ordered engine carry beyond the nine columns: rows of one matrix `pay` (row r of ray i at pay[r * n + i]):
+// [Im of the refractive index] [Re, Im of each material at the ray's wavelength] [wavelengths of the spectrum] [spectrum]
+struct PayLayout {
+    int has_im = 0, n_mat = 0, W = 0;
+    __host__ __device__ int rows() const { return has_im + 2 * n_mat + 2 * W; }
+    __host__ __device__ int r_mat() const { return has_im; }
+    __host__ __device__ int r_wl() const { return has_im + 2 * n_mat; }
+    __host__ __device__ int r_spec() const { return has_im + 2 * n_mat + W; }
+};
+
 struct Level {
     int64_t n_total, n_live;
     double *x, *y, *z, *dx, *dy, *dz, *e, *ref, *wl;
     uint64_t *rid;
     int64_t *parent;
     int32_t *surf;
+    double *pay;
 };
 
 struct trc_result {
     trc_ctx *ctx;
     std::vector<Level> levels;
+    PayLayout lay;
 };
 
 template <class T>
@@ -1076,6 +1089,11 @@ struct OrdParams {
     double *ox, *oy, *oz, *odx, *ody, *odz, *oe, *oref, *owl;
     uint64_t *orid;
     uint32_t *key;  // (culled << 30) | (surface << 2) | block, 0xFFFFFFFF = empty slot
+    const double *pay;      // PayLayout rows of the current bundle (null: none), rows pay_stride apart (the level's total ray count:
+                            // its culled rays sit behind the n live ones)
+    long long pay_stride;
+    double *opay;           // the children's, rows 2n apart
+    PayLayout lay;
 };
 
 #define ORD_EMPTY 0xFFFFFFFFu
@@ -1106,9 +1124,18 @@ __global__ __launch_bounds__(256) void k_ord_bounce(OrdParams P) {
         trc_normal(rec, hx, hy, hz, dx, dy, dz, &nx, &ny, &nz);
         trc_ray_out out[2];
         const double path = sqrt((hx - px) * (hx - px) + (hy - py) * (hy - py) + (hz - pz) * (hz - pz));
-        int n_out = trc_shade(trc_rec_opt_kind(rec), sc.opt + (size_t)s * 8, sc.extra, trc_rec_extra_off(rec),
-                              trc_rec_extra_len(rec), rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, path, nx, ny,
-                              nz, P.seed, rid, (uint32_t)P.event, out);
+        trc_ray_ext X;
+        X.ref_im = 0.0; X.W = P.lay.W; X.n_mat = P.lay.n_mat; X.stride = P.pay_stride; X.mat = X.wl = X.spec = nullptr;
+        if (P.pay) {
+            if (P.lay.has_im) X.ref_im = P.pay[i];
+            X.mat = P.pay + (size_t)P.lay.r_mat() * P.pay_stride + i;
+            X.wl = P.pay + (size_t)P.lay.r_wl() * P.pay_stride + i;
+            X.spec = P.pay + (size_t)P.lay.r_spec() * P.pay_stride + i;
+        }
+        double out_im[2], poly_th;
+        int n_out = trc_shade_x(trc_rec_opt_kind(rec), sc.opt + (size_t)s * 8, sc.extra, trc_rec_extra_off(rec),
+                                trc_rec_extra_len(rec), rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, path, nx, ny,
+                                nz, P.seed, rid, (uint32_t)P.event, X, out, out_im, &poly_th);
         double e_out = out[0].e + (n_out > 1 ? out[1].e : 0.0);
         const bool volume = out[0].back > 0.0;      // scattered in the medium before the surface: nothing recorded there
         if (volume) { hx -= out[0].back * dx; hy -= out[0].back * dy; hz -= out[0].back * dz; }
@@ -1134,6 +1161,18 @@ __global__ __launch_bounds__(256) void k_ord_bounce(OrdParams P) {
             P.odx[slot] = out[c].dx; P.ody[slot] = out[c].dy; P.odz[slot] = out[c].dz;
             P.oe[slot] = out[c].e; P.oref[slot] = out[c].ref; P.owl[slot] = wl;
             P.orid[slot] = (c == 0) ? rid : trc_child_rid(rid, (uint32_t)P.event);
+            if (P.opay) {       // children inherit what the ray carries (RayBundle.inherit, ray_bundle.py:117-143), the optics' changes applied
+                const size_t S2 = 2 * (size_t)P.n;
+                if (P.lay.has_im) P.opay[slot] = out_im[c];
+                for (int k = 0; k < 2 * P.lay.n_mat; ++k) P.opay[(size_t)(P.lay.r_mat() + k) * S2 + slot] = X.mat[(size_t)k * P.pay_stride];
+                const double *tab = sc.extra + trc_rec_extra_off(rec);
+                for (int w = 0; w < P.lay.W; ++w) {
+                    const double xw = X.wl[(size_t)w * P.pay_stride];
+                    const double f = poly_th >= 0.0 ? 1.0 - trc_poly_absorptance(tab, poly_th, xw) : out[c].sf;
+                    P.opay[(size_t)(P.lay.r_wl() + w) * S2 + slot] = xw;
+                    P.opay[(size_t)(P.lay.r_spec() + w) * S2 + slot] = X.spec[(size_t)w * P.pay_stride] * f;
+                }
+            }
             uint32_t k = ((uint32_t)s << 2) | (uint32_t)out[c].blk;
             if (out[c].e <= P.min_energy) k |= ORD_CULLED_BIT;   // tracer_engine.py:242, :270-274
             if (c == 0) k0 = k; else k1 = k;
@@ -1236,6 +1275,9 @@ struct GatherParams {
     uint64_t *rid;
     int64_t *parent;
     int32_t *surf;
+    const double *opay;     // n_pay rows, 2 n_parent apart
+    double *pay;            // n_pay rows, m apart
+    int n_pay;
 };
 
 __global__ __launch_bounds__(256) void k_ord_gather(GatherParams G) {
@@ -1248,6 +1290,7 @@ __global__ __launch_bounds__(256) void k_ord_gather(GatherParams G) {
     G.rid[j] = G.orid[slot];
     G.parent[j] = (int64_t)(slot >= G.n_parent ? slot - G.n_parent : slot);   // tracer_engine.py:235-236
     G.surf[j] = (int32_t)((k & ~ORD_CULLED_BIT) >> 2);
+    for (int r = 0; r < G.n_pay; ++r) G.pay[(size_t)r * G.m + j] = G.opay[(size_t)r * 2 * G.n_parent + slot];
 }
 
 __global__ void k_fill_f64(double *p, long long n, double v) {
@@ -1299,6 +1342,10 @@ struct OpticsParams {
     int event;
     double *odx, *ody, *odz, *oe, *oref;
     int32_t *oblk;  // 2n: -1 empty, else block id
+    // complex indices, material rows, spectra (trc_shade_x): inputs with rows n apart, outputs 2n apart
+    const double *ref_im, *mat, *spec_wl, *spec;
+    int n_mat, W;
+    double *o_im, *o_spec;
 };
 
 __global__ __launch_bounds__(256) void k_optics_apply(OpticsParams P) {
@@ -1307,15 +1354,30 @@ __global__ __launch_bounds__(256) void k_optics_apply(OpticsParams P) {
     trc_ray_out out[2];
     unsigned long long rid = P.rid ? P.rid[i] : (P.ray_offset + (unsigned long long)i);
     const double path = P.path ? P.path[i] : 0.0;
-    int n_out = trc_shade(trc_rec_opt_kind(P.rec), P.opt, P.extra, trc_rec_extra_off(P.rec),
-                          trc_rec_extra_len(P.rec), P.rec[2], P.rec[5], P.rec[8], P.dx[i], P.dy[i], P.dz[i],
-                          P.e[i], P.ref ? P.ref[i] : 1.0, P.wl ? P.wl[i] : 0.0, path, P.nx[i], P.ny[i], P.nz[i], P.seed,
-                          rid, (uint32_t)P.event, out);
+    trc_ray_ext X;
+    X.ref_im = P.ref_im ? P.ref_im[i] : 0.0;
+    X.W = P.W; X.n_mat = P.n_mat; X.stride = P.n;
+    X.mat = P.mat ? P.mat + i : nullptr;
+    X.wl = P.spec_wl ? P.spec_wl + i : nullptr;
+    X.spec = P.spec ? P.spec + i : nullptr;
+    double out_im[2], poly_th;
+    int n_out = trc_shade_x(trc_rec_opt_kind(P.rec), P.opt, P.extra, trc_rec_extra_off(P.rec),
+                            trc_rec_extra_len(P.rec), P.rec[2], P.rec[5], P.rec[8], P.dx[i], P.dy[i], P.dz[i],
+                            P.e[i], P.ref ? P.ref[i] : 1.0, P.wl ? P.wl[i] : 0.0, path, P.nx[i], P.ny[i], P.nz[i], P.seed,
+                            rid, (uint32_t)P.event, X, out, out_im, &poly_th);
     for (int c = 0; c < 2; ++c) {
         long long slot = c == 0 ? i : P.n + i;
         if (c < n_out) {
             P.odx[slot] = out[c].dx; P.ody[slot] = out[c].dy; P.odz[slot] = out[c].dz;
             P.oe[slot] = out[c].e; P.oref[slot] = out[c].ref; P.oblk[slot] = out[c].blk;
+            if (P.o_im) P.o_im[slot] = out_im[c];
+            if (P.o_spec) {
+                const double *tab = P.extra + trc_rec_extra_off(P.rec);
+                for (int w = 0; w < P.W; ++w) {
+                    const double f = poly_th >= 0.0 ? 1.0 - trc_poly_absorptance(tab, poly_th, X.wl[(size_t)w * P.n]) : out[c].sf;
+                    P.o_spec[(size_t)w * 2 * P.n + slot] = X.spec[(size_t)w * P.n] * f;
+                }
+            }
         } else {
             P.oblk[slot] = -1;
         }
@@ -1391,7 +1453,10 @@ static int validate_surface(const trc_surface_desc &s, int idx, int n_extra) {
             return trc_fail(TRC_ERR_UNSUPPORTED, "surface %d: scattering optics share the extra range with the geometry", idx);
     }
     bool opt_table = s.optics_kind == TRC_OPT_REFLECTIVE_SPECTRAL || s.optics_kind == TRC_OPT_LAMBERTIAN_DIRECTIONAL ||
-                     s.optics_kind == TRC_OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL || s.optics_kind == TRC_OPT_FRESNEL_CONDUCTOR;
+                     s.optics_kind == TRC_OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL || s.optics_kind == TRC_OPT_FRESNEL_CONDUCTOR ||
+                     s.optics_kind == TRC_OPT_LAMBERTIAN_POLYCHROMATIC;
+    if (s.optics_kind == TRC_OPT_REFRACTIVE_MATERIAL && (s.opt[4] < 0 || s.opt[5] < 0 || s.opt[4] >= 64 || s.opt[5] >= 64))
+        return trc_fail(TRC_ERR_INVALID, "surface %d: material rows out of range", idx);
     bool needs_extra = s.gm_kind == TRC_GM_RECT_PERFORATED || opt_table;
     if (needs_extra && (s.extra_off < 0 || s.extra_len <= 0 || s.extra_off + s.extra_len > n_extra))
         return trc_fail(TRC_ERR_INVALID, "surface %d: extra range [%d,+%d) outside the %d extra values", idx,
@@ -1500,12 +1565,14 @@ extern "C" int trc_scene_create(trc_ctx *ctx, int32_t n_surf, const trc_surface_
     *out = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
     int max_np = 0;
-    bool splits = false;
+    bool splits = false, carries = false;
     for (int i = 0; i < n_surf; ++i) {
         TRC_TRY(validate_surface(surfs[i], i, n_extra));
         int np = trc_gm_nparams(surfs[i].gm_kind);
         if (np > max_np) max_np = np;
         if (surfs[i].optics_kind == TRC_OPT_REFRACTIVE_HOMOGENOUS && surfs[i].opt[2] == 0.0) splits = true;
+        if (surfs[i].optics_kind == TRC_OPT_REFRACTIVE_MATERIAL && surfs[i].opt[0] == 0.0) splits = true;
+        if (surfs[i].optics_kind == TRC_OPT_REFRACTIVE_MATERIAL || surfs[i].optics_kind == TRC_OPT_LAMBERTIAN_POLYCHROMATIC) carries = true;
     }
     trc_scene *sc = new (std::nothrow) trc_scene();
     if (!sc) return trc_fail(TRC_ERR_NOMEM, "out of host memory");
@@ -1517,6 +1584,7 @@ extern "C" int trc_scene_create(trc_ctx *ctx, int32_t n_surf, const trc_surface_
     sc->surfs.assign(surfs, surfs + n_surf);
     if (n_extra > 0 && extra) sc->extra_h.assign(extra, extra + n_extra);
     sc->splits = splits;
+    sc->carries = carries;
     sc->has_kd = false;
     sc->hit_cap = 0;
     sc->fm_of_surf_h.assign(n_surf, -1);
@@ -2051,6 +2119,8 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
     if ((in == nullptr) == (src == nullptr)) return trc_fail(TRC_ERR_INVALID, "exactly one of `in` and `src` must be given");
     if (n < 0 || reps < 0) return trc_fail(TRC_ERR_INVALID, "n and reps must be >= 0");
     if (sc->splits) return trc_fail(TRC_ERR_UNSUPPORTED, "the scene has ray-splitting optics: use trc_trace_ordered");
+    if (sc->carries || (in && (in->ref_index_im || in->spectra || in->mat)))
+        return trc_fail(TRC_ERR_UNSUPPORTED, "complex refractive indices and spectra travel with the rays of trc_trace_ordered only");
     // TRC_TRACE_ACCEL without a Kd-tree: the streaming form searches its own grid; the megakernel tests every box
     trc_ctx *ctx = sc->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -2322,11 +2392,12 @@ extern "C" int trc_source_generate(trc_ctx *ctx, const trc_source_desc *src, int
 // ================================================================================================
 static void level_free(Level &L) {
     dev_free(L.x); dev_free(L.y); dev_free(L.z); dev_free(L.dx); dev_free(L.dy); dev_free(L.dz); dev_free(L.e);
-    dev_free(L.ref); dev_free(L.wl); dev_free(L.rid); dev_free(L.parent); dev_free(L.surf);
+    dev_free(L.ref); dev_free(L.wl); dev_free(L.rid); dev_free(L.parent); dev_free(L.surf); dev_free(L.pay);
 }
 
-static int level_alloc(Level &L, int64_t n) {
+static int level_alloc(Level &L, int64_t n, int n_pay) {
     memset(&L, 0, sizeof(L));
+    if (n_pay > 0) TRC_TRY(dev_alloc(&L.pay, (size_t)n * n_pay));
     L.n_total = n; L.n_live = n;
     double **p[9] = {&L.x, &L.y, &L.z, &L.dx, &L.dy, &L.dz, &L.e, &L.ref, &L.wl};
     for (int i = 0; i < 9; ++i) TRC_TRY(dev_alloc(p[i], (size_t)n));
@@ -2339,12 +2410,14 @@ static int level_alloc(Level &L, int64_t n) {
 struct OrdScratch {
     double *o[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint64_t *orid = nullptr;
+    double *opay = nullptr;
     uint32_t *key = nullptr, *ckey = nullptr, *cslot = nullptr, *skey = nullptr, *sslot = nullptr;
     unsigned *blk_cnt = nullptr, *blk_cul = nullptr;
     unsigned long long *blk_off = nullptr, *totals = nullptr;
     void *sort_tmp = nullptr;
     void release() {
         for (int i = 0; i < 9; ++i) dev_free(o[i]);
+        dev_free(opay);
         dev_free(orid); dev_free(key); dev_free(ckey); dev_free(cslot); dev_free(skey); dev_free(sslot);
         dev_free(blk_cnt); dev_free(blk_cul); dev_free(blk_off); dev_free(totals);
         if (sort_tmp) (void)hipFree(sort_tmp);
@@ -2372,9 +2445,31 @@ extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_so
     if (sc->n_surf >= (1 << 28)) return trc_fail(TRC_ERR_UNSUPPORTED, "too many surfaces for the ordering key");
     trc_ctx *ctx = sc->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
+    // what the rays carry beyond the nine columns (complex indices, material rows, spectra)
+    PayLayout lay;
+    {
+        int max_mat = -1;
+        bool poly = false;
+        for (const auto &sd : sc->surfs) {
+            if (sd.optics_kind == TRC_OPT_REFRACTIVE_MATERIAL) max_mat = std::max(max_mat, std::max((int)sd.opt[4], (int)sd.opt[5]));
+            if (sd.optics_kind == TRC_OPT_LAMBERTIAN_POLYCHROMATIC) poly = true;
+        }
+        if (in) {
+            lay.has_im = (in->ref_index_im != nullptr || max_mat >= 0) ? 1 : 0;
+            lay.n_mat = in->mat ? (int)in->n_mat : 0;
+            lay.W = (in->spectra && in->spec_wl) ? in->n_spec : 0;
+        }
+        if (max_mat >= 0 && (!in || !in->wavelength || lay.n_mat <= max_mat))
+            return trc_fail(TRC_ERR_INVALID, "the scene refracts between tabulated materials: the bundle needs wavelengths and the %d materials' indices at them (trc_rays.mat)", max_mat + 1);
+        if (poly && lay.W < 2)
+            return trc_fail(TRC_ERR_INVALID, "the scene has polychromatic optics: the bundle needs spectra (trc_rays.spectra, spec_wl)");
+        if (lay.W < 0 || lay.W > 4096 || lay.n_mat < 0 || lay.n_mat > 64) return trc_fail(TRC_ERR_INVALID, "trc_trace_ordered: n_spec or n_mat out of range");
+    }
+    const int n_pay = lay.rows();
     trc_result *res = new (std::nothrow) trc_result();
     if (!res) return trc_fail(TRC_ERR_NOMEM, "out of host memory");
     res->ctx = ctx;
+    res->lay = lay;
     trc_trace_stats s;
     memset(&s, 0, sizeof(s));
     OrdScratch sx;
@@ -2384,7 +2479,7 @@ extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_so
     do {
         // ---- level 0: the source bundle ----
         Level L0;
-        if ((st = level_alloc(L0, n))) { level_free(L0); break; }
+        if ((st = level_alloc(L0, n, n_pay))) { level_free(L0); break; }
         res->levels.push_back(L0);
         Level &B0 = res->levels.back();
         long long g0 = (n + 255) / 256; if (g0 > 8192) g0 = 8192; if (g0 < 1) g0 = 1;
@@ -2409,6 +2504,17 @@ extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_so
             else hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)g0), dim3(256), 0, ctx->stream, B0.wl, (long long)n, 0.0);
             if (in->rid) { if (n > 0 && hipMemcpy(B0.rid, in->rid, (size_t)n * 8, kind) != hipSuccess) bad = true; }
             else hipLaunchKernelGGL(k_fill_rid, dim3((unsigned)g0), dim3(256), 0, ctx->stream, B0.rid, (long long)n, (unsigned long long)ray_offset);
+            if (n_pay > 0 && n > 0) {       // rows of the caller's 2-D columns are in->n apart, ours n
+                if (lay.has_im) {
+                    if (in->ref_index_im) { if (hipMemcpy(B0.pay, in->ref_index_im, (size_t)n * 8, kind) != hipSuccess) bad = true; }
+                    else if (hipMemset(B0.pay, 0, (size_t)n * 8) != hipSuccess) bad = true;
+                }
+                struct { const double *src; int rows, r0; } blk[3] = {{in->mat, 2 * lay.n_mat, lay.r_mat()}, {in->spec_wl, lay.W, lay.r_wl()},
+                                                                      {in->spectra, lay.W, lay.r_spec()}};
+                for (auto &b : blk)
+                    if (b.rows > 0 && hipMemcpy2D(B0.pay + (size_t)b.r0 * n, (size_t)n * 8, b.src, (size_t)in->n * 8, (size_t)n * 8, (size_t)b.rows, kind) != hipSuccess)
+                        bad = true;
+            }
             if (bad) { st = trc_fail(TRC_ERR_DEVICE, "bundle upload failed"); break; }
         }
         if (n > 0) {
@@ -2425,6 +2531,7 @@ extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_so
             sx.release();
             for (int i = 0; i < 9 && st == TRC_OK; ++i) st = dev_alloc(&sx.o[i], (size_t)slots);
             if (st == TRC_OK) st = dev_alloc(&sx.orid, (size_t)slots);
+            if (st == TRC_OK && n_pay > 0) st = dev_alloc(&sx.opay, (size_t)slots * n_pay);
             if (st == TRC_OK) st = dev_alloc(&sx.key, (size_t)slots);
             const long long nblk = (slots + 255) / 256;
             if (st == TRC_OK) st = dev_alloc(&sx.blk_cnt, (size_t)nblk);
@@ -2441,6 +2548,7 @@ extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_so
             P.n = n_cur; P.event = it + 1; P.flags = flags; P.min_energy = min_energy; P.seed = seed;
             P.ox = sx.o[0]; P.oy = sx.o[1]; P.oz = sx.o[2]; P.odx = sx.o[3]; P.ody = sx.o[4]; P.odz = sx.o[5];
             P.oe = sx.o[6]; P.oref = sx.o[7]; P.owl = sx.o[8]; P.orid = sx.orid; P.key = sx.key;
+            P.pay = cur.pay; P.pay_stride = cur.n_total; P.opay = sx.opay; P.lay = lay;
 
             (void)hipEventRecord(ctx->ev0, ctx->stream);
             hipLaunchKernelGGL(k_ord_bounce, dim3((unsigned)((n_cur + 255) / 256)), dim3(256), 0, ctx->stream, P);
@@ -2472,7 +2580,7 @@ extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_so
             re = rocprim::radix_sort_pairs(sx.sort_tmp, tmp_bytes, sx.ckey, sx.skey, sx.cslot, sx.sslot, (size_t)m, 0, 31, ctx->stream);
             if (re != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "radix_sort_pairs failed: %s", hipGetErrorString(re)); break; }
             Level Ln;
-            if ((st = level_alloc(Ln, m))) { level_free(Ln); break; }
+            if ((st = level_alloc(Ln, m, n_pay))) { level_free(Ln); break; }
             Ln.n_live = m - n_culled;
             res->levels.push_back(Ln);
             GatherParams G;
@@ -2481,6 +2589,7 @@ extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_so
             G.m = m; G.n_parent = n_cur;
             G.x = Ln.x; G.y = Ln.y; G.z = Ln.z; G.dx = Ln.dx; G.dy = Ln.dy; G.dz = Ln.dz; G.e = Ln.e; G.ref = Ln.ref;
             G.wl = Ln.wl; G.rid = Ln.rid; G.parent = Ln.parent; G.surf = Ln.surf;
+            G.opay = sx.opay; G.pay = Ln.pay; G.n_pay = n_pay;
             hipLaunchKernelGGL(k_ord_gather, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, G);
             se = hipStreamSynchronize(ctx->stream);
             if (se != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "ordering of bounce %d failed: %s", it, hipGetErrorString(se)); break; }
@@ -2527,6 +2636,7 @@ extern "C" int trc_result_level_get(trc_result *res, int32_t level, trc_rays *ou
     if (out->on_device) return trc_fail(TRC_ERR_INVALID, "host output expected");
     HIP_TRY(hipSetDevice(res->ctx->device));
     const size_t n = (size_t)L.n_total;
+    const int64_t cap = out->n;
     out->n = L.n_total;
     if (n == 0) return TRC_OK;
     struct { void *dst; const void *src; size_t w; } cp[] = {
@@ -2535,6 +2645,17 @@ extern "C" int trc_result_level_get(trc_result *res, int32_t level, trc_rays *ou
         {out->rid, L.rid, 8}, {surf, L.surf, 4}};
     for (auto &c : cp)
         if (c.dst) HIP_TRY(hipMemcpy(c.dst, c.src, n * c.w, hipMemcpyDeviceToHost));
+    // what the rays carry beyond that (rows of the caller's 2-D columns: the capacity it handed over apart)
+    const PayLayout &lay = res->lay;
+    if (out->ref_index_im) {
+        if (lay.has_im) HIP_TRY(hipMemcpy(out->ref_index_im, L.pay, n * 8, hipMemcpyDeviceToHost));
+        else memset(out->ref_index_im, 0, n * 8);
+    }
+    if (out->spectra || out->spec_wl) {
+        if (out->n_spec != lay.W) return trc_fail(TRC_ERR_INVALID, "the level's rays carry %d spectral samples, the output has room for %d", lay.W, out->n_spec);
+        if (out->spec_wl && lay.W) HIP_TRY(hipMemcpy2D(out->spec_wl, (size_t)cap * 8, L.pay + (size_t)lay.r_wl() * n, n * 8, n * 8, (size_t)lay.W, hipMemcpyDeviceToHost));
+        if (out->spectra && lay.W) HIP_TRY(hipMemcpy2D(out->spectra, (size_t)cap * 8, L.pay + (size_t)lay.r_spec() * n, n * 8, n * 8, (size_t)lay.W, hipMemcpyDeviceToHost));
+    }
     return TRC_OK;
 }
 
@@ -2678,9 +2799,35 @@ extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int3
     double *d_path = nullptr;
     double *d_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int32_t *d_blk = nullptr;
+    // complex indices, material rows, spectra
+    const int W = (in->spectra && in->spec_wl) ? in->n_spec : 0;
+    const int n_mat = in->mat ? (int)in->n_mat : 0;
+    if (W < 0 || W > 4096 || n_mat < 0 || n_mat > 64) return trc_fail(TRC_ERR_INVALID, "trc_optics_apply: n_spec or n_mat out of range");
+    if (surf->optics_kind == TRC_OPT_LAMBERTIAN_POLYCHROMATIC && (W < 2 || !out->spectra))
+        return trc_fail(TRC_ERR_INVALID, "polychromatic optics: the bundles need spectra (trc_rays.spectra, spec_wl)");
+    if (surf->optics_kind == TRC_OPT_REFRACTIVE_MATERIAL && (!in->wavelength || n_mat <= std::max((int)surf->opt[4], (int)surf->opt[5]) || !out->ref_index_im))
+        return trc_fail(TRC_ERR_INVALID, "refraction between tabulated materials: the bundle needs wavelengths and the materials' indices at them (trc_rays.mat), the output ref_index_im");
+    if (W > 0 && out->spectra && out->n_spec != W) return trc_fail(TRC_ERR_INVALID, "trc_optics_apply: the output's n_spec differs from the input's");
+    const int64_t out_cap = out->n;
+    double *d_im = nullptr, *d_mat = nullptr, *d_swl = nullptr, *d_spec = nullptr, *d_oim = nullptr, *d_ospec = nullptr;
     int st = TRC_OK;
     do {
         if ((st = upload_record(surf, n_extra, extra, &d_rec, &d_opt, &d_extra))) break;
+        if (in->ref_index_im) {
+            if ((st = dev_alloc(&d_im, (size_t)n))) break;
+            if (hipMemcpy(d_im, in->ref_index_im, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        }
+        {
+            struct { const double *src; int rows; double **dst; } blk2[3] = {{in->mat, 2 * n_mat, &d_mat}, {in->spec_wl, W, &d_swl}, {in->spectra, W, &d_spec}};
+            for (auto &b : blk2) {
+                if (b.rows <= 0) continue;
+                if ((st = dev_alloc(b.dst, (size_t)n * b.rows))) break;
+                if (hipMemcpy2D(*b.dst, (size_t)n * 8, b.src, (size_t)in->n * 8, (size_t)n * 8, (size_t)b.rows, hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+            }
+            if (st) break;
+        }
+        if (out->ref_index_im && (st = dev_alloc(&d_oim, (size_t)(2 * n)))) break;
+        if (W > 0 && out->spectra && (st = dev_alloc(&d_ospec, (size_t)(2 * n) * W))) break;
         const double *src[9] = {in->dx, in->dy, in->dz, in->e, in->ref_index, in->wavelength, nx, ny, nz};
         for (int i = 0; i < 9; ++i) {
             if (!src[i]) continue;
@@ -2712,6 +2859,7 @@ extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int3
         P.nx = d_in[6]; P.ny = d_in[7]; P.nz = d_in[8]; P.path = d_path;
         P.seed = seed; P.event = bounce;
         P.odx = d_out[0]; P.ody = d_out[1]; P.odz = d_out[2]; P.oe = d_out[3]; P.oref = d_out[4]; P.oblk = d_blk;
+        P.ref_im = d_im; P.mat = d_mat; P.spec_wl = d_swl; P.spec = d_spec; P.n_mat = n_mat; P.W = W; P.o_im = d_oim; P.o_spec = d_ospec;
         hipLaunchKernelGGL(k_optics_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, P);
         hipError_t se = hipStreamSynchronize(ctx->stream);
         if (se != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "k_optics_apply failed: %s", hipGetErrorString(se)); break; }
@@ -2723,6 +2871,15 @@ extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int3
         }
         if (st) break;
         if (hipMemcpy(blk.data(), d_blk, (size_t)(2 * n) * 4, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        std::vector<double> h_im, h_spec;
+        if (d_oim) {
+            h_im.resize((size_t)(2 * n));
+            if (hipMemcpy(h_im.data(), d_oim, (size_t)(2 * n) * 8, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        }
+        if (d_ospec) {
+            h_spec.resize((size_t)(2 * n) * W);
+            if (hipMemcpy(h_spec.data(), d_ospec, h_spec.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        }
         // reflected block first, then refracted block, each in selector order (optics_callables.py:852-857)
         int64_t m = 0;
         for (int b = 0; b < 2; ++b)
@@ -2734,12 +2891,19 @@ extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int3
                 out->e[m] = h[3][(size_t)slot];
                 if (out->ref_index) out->ref_index[m] = h[4][(size_t)slot];
                 if (out->wavelength) out->wavelength[m] = in->wavelength ? in->wavelength[i] : 0.0;
+                if (out->ref_index_im) out->ref_index_im[m] = h_im[(size_t)slot];
+                if (d_ospec)
+                    for (int w = 0; w < W; ++w) {
+                        out->spectra[(size_t)w * out_cap + m] = h_spec[(size_t)w * 2 * n + slot];
+                        if (out->spec_wl) out->spec_wl[(size_t)w * out_cap + m] = in->spec_wl[(size_t)w * in->n + i];
+                    }
                 out->parent[m] = i;
                 ++m;
             }
         out->n = m;
     } while (0);
     dev_free(d_rec); dev_free(d_opt); dev_free(d_extra); dev_free(d_rid); dev_free(d_blk); dev_free(d_path);
+    dev_free(d_im); dev_free(d_mat); dev_free(d_swl); dev_free(d_spec); dev_free(d_oim); dev_free(d_ospec);
     for (int i = 0; i < 9; ++i) dev_free(d_in[i]);
     for (int i = 0; i < 5; ++i) dev_free(d_out[i]);
     return st;

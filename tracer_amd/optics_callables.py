@@ -55,18 +55,41 @@ class NativeOptics(object):
         n = len(selector)
         d = _cabi.f64(rays.get_directions(selector))
         e = _cabi.f64(rays.get_energy(selector))
-        ri = _cabi.f64(rays.get_ref_index(selector)) if rays._has_column('ref_index') else None
-        wl = _cabi.f64(rays.get_wavelengths(selector)) if rays._has_column('wavelengths') else None
+        ri = im = wl = swl = sp = mat = None
+        if rays._has_column('ref_index'):
+            ri = N.asarray(rays.get_ref_index(selector))
+            if N.iscomplexobj(ri):
+                ri, im = _cabi.f64(ri.real), _cabi.f64(ri.imag)
+            else:
+                ri = _cabi.f64(ri)
+        poly = rays._has_column('spectra')
+        if poly:                                    # a spectrum per ray over its own wavelength grid, both (W, N)
+            swl = _cabi.f64(N.asarray(rays.get_wavelengths())[:, selector])
+            sp = _cabi.f64(N.asarray(rays.get_spectra())[:, selector])
+        elif rays._has_column('wavelengths'):
+            wl = _cabi.f64(rays.get_wavelengths(selector))
+        mats = getattr(self, '_materials', None)
+        if mats is not None:
+            if wl is None or ri is None:
+                raise ValueError("refraction between materials needs `wavelengths` and `ref_index` columns on the bundle")
+            from .scene import material_rows
+            mat = material_rows(mats, wl)
+            if im is None:
+                im = N.zeros(n)
         nrm = _cabi.f64(geometry.get_normals())
         hit = _cabi.f64(geometry.get_intersection_points_global())
         rid = N.arange(n, dtype=N.uint64)
         org = _cabi.f64(rays.get_vertices(selector))          # origins: path lengths of the attenuating optics
-        rin = _cabi.make_rays(n, org[0], org[1], org[2], dx=d[0], dy=d[1], dz=d[2], e=e, ref_index=ri, wavelength=wl, rid=rid)
+        rin = _cabi.make_rays(n, org[0], org[1], org[2], dx=d[0], dy=d[1], dz=d[2], e=e, ref_index=ri, wavelength=wl, rid=rid,
+                              ref_index_im=im, spec_wl=swl, spectra=sp, mat=mat)
         m = 2 * n
         o = dict((k, N.empty(m)) for k in ('x', 'y', 'z', 'dx', 'dy', 'dz', 'e', 'ref', 'wl'))
         par = N.empty(m, dtype=N.int64)
+        oim = N.empty(m) if im is not None else None
+        osp = N.empty((sp.shape[0], m)) if poly else None
+        oswl = N.empty((sp.shape[0], m)) if poly else None
         rout = _cabi.make_rays(m, o['x'], o['y'], o['z'], o['dx'], o['dy'], o['dz'], o['e'], parent=par,
-                               ref_index=o['ref'], wavelength=o['wl'])
+                               ref_index=o['ref'], wavelength=o['wl'], ref_index_im=oim, spec_wl=oswl, spectra=osp)
         _cabi.check(ctx.lib.trc_optics_apply(
             ctx.handle, C.byref(desc), len(extra), _cabi.ptr(extra) if len(extra) else None, C.byref(rin),
             _cabi.ptr(hit[0]), _cabi.ptr(hit[1]), _cabi.ptr(hit[2]), _cabi.ptr(nrm[0]), _cabi.ptr(nrm[1]),
@@ -76,7 +99,9 @@ class NativeOptics(object):
         src = selector[par]
         kw = {}
         if ri is not None:
-            kw['ref_index'] = o['ref'][:k].copy()
+            kw['ref_index'] = o['ref'][:k].copy() if oim is None else o['ref'][:k] + 1j * oim[:k]
+        if poly:
+            kw['spectra'] = osp[:, :k].copy()
         return rays.inherit(src, vertices=N.vstack((o['x'][:k], o['y'][:k], o['z'][:k])),
                             direction=N.vstack((o['dx'][:k], o['dy'][:k], o['dz'][:k])),
                             energy=o['e'][:k].copy(), parents=src, **kw)
@@ -411,6 +436,75 @@ class RefractiveScatteringHomogenous(RefractiveHomogenous):
         raise NotImplementedError('scattering optics run on the device engines (ray_tracer with engine "auto", "fast" or "ordered")')
 
 
+class Refractive(NativeOptics):
+    """
+    Interface between two media whose complex refractive indices depend on the wavelength (optics_callables.py:726-858):
+    material_1, material_2 are objects with m(wavelengths) -> complex index, like those of the reference's
+    ray_trace_utils.optical_constants (TabulatedMaterial here).  Rays need `wavelengths` and a `ref_index` column holding the index
+    of the medium they start in (complex or real); a ray whose index equals material_1's at its wavelength enters material_2, any
+    other enters material_1 (:750-751).  Snell's law on the real parts, the real part of the complex Fresnel reflectance as the
+    reference computes it (:838-840); single_ray / sigma as RefractiveHomogenous.
+    The materials are evaluated by their own m() once per ray (the wavelength does not change along a path) and travel with the
+    rays (trc_rays.mat): ordered engine and per-surface protocol.
+    """
+    _attenuate = False
+    _scaling = 1.
+
+    def __init__(self, material_1, material_2, single_ray=True, sigma=None):
+        self._materials = [material_1, material_2]
+        self._single_ray = single_ray
+        self._sigma = sigma
+
+    @property
+    def _splits(self):
+        return not self._single_ray
+
+    def toggle_ref_idx(self, m1, wavelengths):
+        mat_0 = self._materials[0].m(wavelengths)
+        return N.where(m1 == mat_0, self._materials[1].m(wavelengths), mat_0)
+
+    def _native(self):
+        # opt[4], opt[5]: rows of the two materials in trc_rays.mat -- 0, 1 for a single call, the scene's numbering in a scene
+        return _cabi.OPT_REFRACTIVE_MATERIAL, [1. if self._single_ray else 0., -1. if self._sigma is None else self._sigma,
+                                               1. if self._attenuate else 0., self._scaling, 0., 1.], []
+
+
+class RefractiveAbsorbant(Refractive):
+    """
+    Refractive whose media attenuate (optics_callables.py:908-944 on Absorbant.attenuate :874-889): the outgoing rays lose
+    exp(-4 pi k L / lambda) of their energy over the path L the incident ray travelled, with k the imaginary part of the index the
+    OUTGOING ray carries (optics.attenuations, optics.py:205-212, is handed the new bundle's index, :882).
+    The constructor's coefficients are kept as the reference reads them: when either is given the attenuation follows the complex
+    indices (:929-933 stores None); when both are None the reference stores [None, None] and its attenuate() raises on the first
+    hit -- here the constructor does.
+    """
+    _attenuate = True
+
+    def __init__(self, material_1, material_2, single_ray=True, sigma=None, attenuation_coefficient_1=None,
+                 attenuation_coefficient_2=None, scaling=1.):
+        if attenuation_coefficient_1 is None and attenuation_coefficient_2 is None:
+            raise NotImplementedError("RefractiveAbsorbant without coefficients cannot run in the reference either (optics_callables.py:884 "
+                                      "reads an attribute the class never sets); pass any coefficient to attenuate by the complex indices")
+        Refractive.__init__(self, material_1, material_2, single_ray, sigma)
+        self._scaling = scaling
+
+
+class Lambertian_directional_axisymmetric_piecewise_Polychromatic(NativeOptics):
+    """
+    Diffuse wall for polychromatic bundles (optics_callables.py:393-425): every ray carries a spectrum `spectra` (W,N) sampled at
+    `wavelengths` (W,N); sample w is scaled by 1 - absorptance(theta_in, lambda_w) (bilinear on the (thetas, wavelengths) grid) and
+    the ray's energy becomes the trapezoid integral of the scaled spectrum.  Ordered engine and per-surface protocol.
+    """
+    def __init__(self, thetas, absorptance, wavelengths):
+        thetas, wavelengths = N.unique(thetas), N.unique(wavelengths)
+        self.thetas, self.wavelengths = thetas, wavelengths
+        self.absorptance = N.reshape(absorptance, (len(thetas), len(wavelengths)))
+
+    def _native(self):
+        tab = N.concatenate(([len(self.thetas), len(self.wavelengths)], self.thetas, self.wavelengths, self.absorptance.ravel()))
+        return _cabi.OPT_LAMBERTIAN_POLYCHROMATIC, [], tab.tolist()
+
+
 # --------------------------------------------------------------------------------------------------
 # optics composed on the host.  They are ordinary optics callables of the four-step protocol (their scenes are traced by
 # TracerEngine with engine='protocol', the native surfaces and the optics they wrap still running on the device per call).
@@ -463,6 +557,8 @@ class PeriodicBoundary(object):
         vertices = geometry.get_intersection_points_global()
         stopped = rays.inherit(selector, vertices=vertices, energy=N.zeros(len(selector)),
                                direction=rays.get_directions(selector), parents=selector)
+        if rays._has_column('spectra'):             # a polychromatic bundle: the stub's spectrum is cancelled too (:710-713)
+            stopped._spectra = N.zeros(N.asarray(rays.get_spectra())[:, selector].shape)
         moved = rays.inherit(selector, vertices=vertices + self.period * geometry.get_normals(), parents=selector)
         return stopped + moved
 
@@ -588,13 +684,26 @@ class SpectralAccountant(Accountant):
 
 
 class PolychromaticAccountant(Accountant):
+    """Spectral power absorbed by each hit of a polychromatic bundle, and the wavelengths it is sampled at
+    (optics_callables.py:1825-1848): get_data() -> (wavelengths (W,H), absorbed spectra (W,H))."""
     shorthand = 'Polychromatic'
 
+    def reset(self):
+        self._data = []
+        self._wavelengths = []
+
     def count(self, geometry, rays, selector, new_bundle):
-        raise NotImplementedError("polychromatic bundles are outside the native path")
+        self._wavelengths.append(N.asarray(new_bundle.get_wavelengths()))
+        self._data.append(N.asarray(rays.get_spectra())[:, selector] - N.asarray(new_bundle.get_spectra()))
 
     def feed(self, hit):
-        raise NotImplementedError("polychromatic bundles are outside the native path")
+        self._wavelengths.append(hit['wavelengths'])
+        self._data.append(hit['spectra_in'] - hit['spectra_out'])
+
+    def get_data(self):
+        if not self._data:
+            return N.array([]), N.array([]).reshape(2, 0)
+        return N.concatenate(self._wavelengths, axis=-1), N.concatenate(self._data, axis=-1)
 
 
 # canonical accountant order: energy -> spectral -> location -> directions (optics_callables.py:2060-2071)

@@ -119,6 +119,8 @@ class RayBundle(object):
         """
         dict of contiguous 1-D float64 arrays x,y,z,dx,dy,dz[,e,ref_index,wavelength] for the C-ABI.
         Rows of C-contiguous (3,N) float64 arrays are passed as views (no copy).
+        A complex `ref_index` (media that attenuate) adds ref_index_im; a polychromatic bundle -- `spectra` (W,N) over
+        `wavelengths` (W,N), optics_callables.py:406-413 -- gives spec_wl and spectra instead of wavelength.
         """
         from ._cabi import f64
         v = f64(self.get_vertices())
@@ -131,11 +133,28 @@ class RayBundle(object):
         if self._has_column('ref_index'):
             ri = N.asarray(self._cols['ref_index'])
             if N.iscomplexobj(ri):
-                raise NotImplementedError("complex refractive indices are not in the native table")
-            out['ref_index'] = f64(ri)
+                out['ref_index'] = f64(ri.real)
+                out['ref_index_im'] = f64(ri.imag)
+            else:
+                out['ref_index'] = f64(ri)
         if self._has_column('wavelengths'):
-            out['wavelength'] = f64(self._cols['wavelengths'])
+            wl = N.asarray(self._cols['wavelengths'])
+            if wl.ndim == 2:
+                out['spec_wl'] = f64(wl)
+            else:
+                out['wavelength'] = f64(wl)
+        if self._has_column('spectra'):
+            sp = f64(self._cols['spectra'])
+            if 'spec_wl' not in out or out['spec_wl'].shape != sp.shape:
+                raise ValueError("a polychromatic bundle carries `spectra` and `wavelengths` of the same (W, N) shape")
+            out['spectra'] = sp
         return out
+
+    def is_polychromatic(self):
+        return self._has_column('spectra')
+
+    def has_complex_index(self):
+        return self._has_column('ref_index') and N.iscomplexobj(self._cols['ref_index'])
 
 
 def concatenate_rays(bundles):

@@ -20,6 +20,17 @@ from .optics_callables import OpticsCallable, native_optics_of, LocationAccounta
     AbsorptionAccountant, ReceptionAccountant, ScatteringAccountant, NormalAccountant
 
 
+def material_rows(materials, wavelengths):
+    """trc_rays.mat: (2K, n), rows 2k, 2k+1 = Re, Im of materials[k].m(wavelengths)"""
+    wl = N.asarray(wavelengths, dtype=float)
+    out = N.empty((2 * len(materials), len(wl)))
+    for k, mat in enumerate(materials):
+        with N.errstate(all='ignore'):
+            m = N.asarray(mat.m(wl), dtype=complex)
+        out[2 * k], out[2 * k + 1] = m.real, m.imag
+    return out
+
+
 class NotNativeError(NotImplementedError):
     """The scene holds a geometry/optics plug-in that only exists in Python."""
 
@@ -33,6 +44,8 @@ class CompiledScene(object):
         self.descs = (_cabi.SurfaceDesc * n)()
         extra = []
         self.splits = False
+        self.carries = False        # optics that read what only rays of the ordered engine carry (complex indices, spectra)
+        self.materials = []         # materials of the Refractive surfaces; row k of trc_rays.mat is materials[k].m(wavelengths)
         self.capture = []
         for i, s in enumerate(self.surfaces):
             gm = s.get_geometry_manager()
@@ -49,6 +62,16 @@ class CompiledScene(object):
                 raise NotNativeError("surface %d: %s" % (i, err))
             if len(gextra) and len(oextra):
                 raise NotNativeError("surface %d: both geometry and optics carry tables" % i)
+            if okind == _cabi.OPT_REFRACTIVE_MATERIAL:      # opt[4], opt[5]: the scene's rows of this surface's two materials
+                opar = list(opar)
+                for j, mat in enumerate(nat._materials):
+                    known = [k for k, m in enumerate(self.materials) if m is mat]
+                    if not known:
+                        self.materials.append(mat)
+                        known = [len(self.materials) - 1]
+                    opar[4 + j] = float(known[0])
+            if okind in (_cabi.OPT_REFRACTIVE_MATERIAL, _cabi.OPT_LAMBERTIAN_POLYCHROMATIC):
+                self.carries = True
             ex = list(gextra) if len(gextra) else list(oextra)
             off = len(extra) if len(ex) else -1
             extra.extend(ex)
@@ -93,6 +116,8 @@ class TableScene(object):
         self.descs = (_cabi.SurfaceDesc * n)()
         self.extra = _cabi.f64(extra)
         self.splits = False
+        self.carries = False
+        self.materials = []
         self.capture = [False] * n
         for i in range(n):
             fill_desc(self.descs[i], N.asarray(frames[i]), int(gm_kind[i]), list(gm[i]), int(optics_kind[i]), list(opt[i]),
@@ -293,8 +318,17 @@ class DeviceScene(object):
             return None, desc, n, seed, off, None
         cols = bundle.columns_soa()
         n = cols['x'].shape[0]
+        mats = getattr(self.compiled, 'materials', [])
+        if mats:
+            # the materials' own m(lambda) at every ray's wavelength (children inherit the wavelength): tables, files and analytic
+            # models alike, and the device's comparison `index == material_1's` (optics_callables.py:750) stays exact
+            if 'wavelength' not in cols:
+                raise ValueError("the scene refracts between materials: the bundle needs a `wavelengths` column")
+            cols['mat'] = material_rows(mats, cols['wavelength'])
         rays = _cabi.make_rays(n, cols['x'], cols['y'], cols['z'], cols['dx'], cols['dy'], cols['dz'], cols['e'],
-                               ref_index=cols.get('ref_index'), wavelength=cols.get('wavelength'))
+                               ref_index=cols.get('ref_index'), wavelength=cols.get('wavelength'),
+                               ref_index_im=cols.get('ref_index_im'), spec_wl=cols.get('spec_wl'), spectra=cols.get('spectra'),
+                               mat=cols.get('mat'))
         return rays, None, n, None, 0, cols
 
     def trace_fast(self, bundle, reps, min_energy, seed, accel=False, keep_last=False, stream=None, last_capacity=None):
@@ -363,8 +397,10 @@ class OrderedResult(object):
         _cabi.check(self.lib.trc_result_level_size(self.handle, level, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def level(self, level, with_ref_index=True, with_wavelength=False):
-        """dict: vertices (3,n), directions (3,n), energy, parents, surf, ref_index[, wavelengths], n_live"""
+    def level(self, level, with_ref_index=True, with_wavelength=False, complex_index=False, n_spec=0):
+        """dict: vertices (3,n), directions (3,n), energy, parents, surf, ref_index[, wavelengths], n_live.
+        complex_index: ref_index comes back complex; n_spec = W > 0: `wavelengths` and `spectra` are the (W, n) columns of a
+        polychromatic bundle."""
         n, n_live = self.level_size(level)
         v = N.empty((3, n))
         d = N.empty((3, n))
@@ -373,18 +409,25 @@ class OrderedResult(object):
         ri = N.empty(n) if with_ref_index else None
         wl = N.empty(n) if with_wavelength else None
         surf = N.empty(n, dtype=N.int32)
-        rays = _cabi.make_rays(n, v[0], v[1], v[2], d[0], d[1], d[2], e, parent=par, ref_index=ri, wavelength=wl)
+        im = N.empty(n) if (complex_index and with_ref_index) else None
+        swl = N.empty((n_spec, n)) if n_spec else None
+        sp = N.empty((n_spec, n)) if n_spec else None
+        rays = _cabi.make_rays(n, v[0], v[1], v[2], d[0], d[1], d[2], e, parent=par, ref_index=ri, wavelength=wl,
+                               ref_index_im=im, spec_wl=swl, spectra=sp)
         _cabi.check(self.lib.trc_result_level_get(self.handle, level, C.byref(rays),
                                                   surf.ctypes.data_as(C.POINTER(C.c_int32))))
         out = dict(vertices=v, directions=d, energy=e, parents=par, surf=surf, n_live=n_live)
         if ri is not None:
-            out['ref_index'] = ri
+            out['ref_index'] = ri if im is None else ri + 1j * im
         if wl is not None:
             out['wavelengths'] = wl
+        if n_spec:
+            out['wavelengths'] = swl
+            out['spectra'] = sp
         return out
 
 
-def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavelengths=None):
+def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavelengths=None, spectra=None):
     """
     Hand per-hit data to the accountants of each surface's optics (fused engines).  Inside one call
     the hits of a surface are kept in the order given.
@@ -422,5 +465,7 @@ def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavele
             return out
         hit = dict(e_in=e_in[idx], e_out=e_out[idx], points=pts, directions=dirs, normals=normals,
                    wavelengths=None if wavelengths is None else wavelengths[idx])
+        if spectra is not None:     # polychromatic bundles: (spectra of the incident rays, of the outgoing ones, their wavelength grids)
+            hit['spectra_in'], hit['spectra_out'], hit['wavelengths'] = spectra[0][:, idx], spectra[1][:, idx], spectra[2][:, idx]
         for acc in opt.accountants:
             acc.feed(hit)

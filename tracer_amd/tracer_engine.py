@@ -185,7 +185,9 @@ class TracerEngine(object):
                 self._kd_on_device = self.Kd_Tree
 
         if engine == 'auto':
-            engine = 'ordered' if (tree or dev.compiled.splits) else 'fast'
+            # complex refractive indices and spectra travel with the rays of the ordered engine only
+            carries = dev.compiled.carries or (not _pending(bundle) and (bundle.is_polychromatic() or bundle.has_complex_index()))
+            engine = 'ordered' if (tree or dev.compiled.splits or carries) else 'fast'
         if engine == 'fast':
             return self._trace_fast(dev, bundle, reps, min_energy, seed, bool(accel), hit_capacity, fast_kernel, feed, last_capacity)
         if engine == 'ordered':
@@ -228,6 +230,10 @@ class TracerEngine(object):
     def _trace_ordered(self, dev, bundle, reps, min_energy, seed, accel, tree):
         has_ref = bundle._has_column('ref_index') if not _pending(bundle) else False
         has_wl = bundle._has_column('wavelengths') if not _pending(bundle) else False
+        n_spec = bundle.get_spectra().shape[0] if (not _pending(bundle) and bundle.is_polychromatic()) else 0
+        cplx = bool(dev.compiled.materials) or (not _pending(bundle) and bundle.has_complex_index())
+        if n_spec:
+            has_wl = False          # `wavelengths` is the (W, N) grid of the spectra
         t0 = time.time()
         res, stats = dev.trace_ordered(bundle, reps, min_energy, seed, accel=accel)
         wall = time.time() - t0
@@ -240,17 +246,19 @@ class TracerEngine(object):
             prev_surf = None
             last = None
             for lv in range(1, nlev):
-                L = res.level(lv, with_ref_index=True, with_wavelength=has_wl)
+                L = res.level(lv, with_ref_index=True, with_wavelength=has_wl, complex_index=cplx, n_spec=n_spec)
                 if prev is None:
                     prev = dict(energy=N.asarray(bundle.get_energy()), directions=N.asarray(bundle.get_directions()),
-                                wavelengths=bundle.get_wavelengths() if has_wl else None)
+                                wavelengths=bundle.get_wavelengths() if has_wl else None,
+                                spectra=N.asarray(bundle.get_spectra()) if n_spec else None)
                 # accountants: hits of a surface in the order the reference selects them (ascending parent)
                 par = L['parents']
                 order = N.lexsort((par, L['surf']))
                 po = par[order]
                 feed_accountants(dev.compiled.surfaces, L['surf'][order], prev['energy'][po], L['energy'][order],
                                  L['vertices'][:, order], prev['directions'][:, po],
-                                 None if prev['wavelengths'] is None else prev['wavelengths'][po])
+                                 None if prev['wavelengths'] is None else prev['wavelengths'][po],
+                                 spectra=None if not n_spec else (prev['spectra'][:, po], L['spectra'][:, order], L['wavelengths'][:, order]))
                 if self._transfer:
                     ns = dev.n_surf
                     left = N.full(len(prev['energy']), ns) if prev_surf is None else prev_surf
@@ -263,11 +271,15 @@ class TracerEngine(object):
                     kw['ref_index'] = L['ref_index']
                 if has_wl:
                     kw['wavelengths'] = L['wavelengths']
+                if n_spec:
+                    kw['wavelengths'] = L['wavelengths']
+                    kw['spectra'] = L['spectra']
                 rec = RayBundle(vertices=L['vertices'], directions=L['directions'], energy=L['energy'],
                                 parents=L['parents'], **kw)
                 if tree is True or lv == nlev - 1:
                     self.tree.append(rec)
-                prev = dict(energy=L['energy'], directions=L['directions'], wavelengths=L.get('wavelengths'))
+                prev = dict(energy=L['energy'], directions=L['directions'], wavelengths=L.get('wavelengths') if has_wl else None,
+                            spectra=L.get('spectra'))
                 last = L
         finally:
             res.close()
