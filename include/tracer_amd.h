@@ -319,6 +319,15 @@ int trc_scene_export_tallies(trc_scene *scene, double *dst, int32_t on_device);
 int trc_scene_import_tallies(trc_scene *scene, const double *src, int32_t on_device);
 
 /*
+ * KdTree.traversal(bundle) (accel_tree.py:213-312 on intersect_bounds :314-330): which surfaces each ray has to be tested
+ * against.  relevancy[s * n + r] = 1 when ray r crosses a leaf that holds surface s -- every leaf on its way through the
+ * root box, not only the first -- or when s is always relevant (no bounds).  Host arrays; relevancy holds n_surf * n bytes.
+ * *any_inter (may be NULL): the first value the reference returns.  Host bundles.
+ */
+int trc_kdtree_traversal(trc_ctx *ctx, const trc_kdtree_desc *kd, int32_t n_surf, const trc_rays *rays, int64_t n,
+                         uint8_t *relevancy, int32_t *any_inter);
+
+/*
  * TracerEngine.ray_tracer(bundle, reps, min_energy, tree=False, accel) (tracer_engine.py:124-295):
  * the persistent-wavefront engine.  Exactly one of `in` / `src` is non-NULL: `in` traces a given
  * bundle; `src` fuses source generation (sources.py) into the kernel, ray i of the call has

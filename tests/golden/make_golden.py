@@ -730,6 +730,39 @@ def make_kdtree(ref, out):
         out[tag + 'minpoint'] = N.ravel(kd.minpoint)
         out[tag + 'maxpoint'] = N.ravel(kd.maxpoint)
         print('kdtree%s: %d nodes, %d leaves' % (' (fast)' if fast else '', n, int((flag == 3).sum())))
+        if not fast:
+            # KdTree.traversal on its own (accel_tree.py:213-312): the relevancy matrix the reference returns for rays that come
+            # down on the field like the sun's, leave the receiver towards it, start inside the root box, run along an axis (a zero
+            # direction component: infinite inverse), or miss the box
+            rng = N.random.RandomState(31)
+            lo, hi = N.ravel(kd.minpoint), N.ravel(kd.maxpoint)
+            cen, ext = 0.5 * (lo + hi), (hi - lo)
+            k = 140
+            sun = N.array([0., N.sin(0.61), N.cos(0.61)])
+            v1 = cen[:, None] + 300. * sun[:, None] + N.vstack((rng.uniform(-1, 1, k) * ext[0], rng.uniform(-1, 1, k) * ext[1], N.zeros(k)))
+            d1 = N.tile(-sun[:, None], (1, k)) + 4e-3 * rng.normal(size=(3, k))
+            v2 = N.tile(N.c_[[0., 0., 60.]], (1, k)) + rng.uniform(-5, 5, size=(3, k))
+            d2 = N.vstack((rng.uniform(lo[0], hi[0], k), rng.uniform(lo[1], hi[1], k), N.zeros(k))) - v2
+            v3 = lo[:, None] + rng.uniform(0, 1, size=(3, k)) * ext[:, None]
+            d3 = rng.normal(size=(3, k))
+            v4 = lo[:, None] + rng.uniform(0, 1, size=(3, k)) * ext[:, None]
+            d4 = N.zeros((3, k))
+            d4[rng.randint(0, 3, k), N.arange(k)] = rng.choice([-1., 1.], k)
+            v4[2, :k // 2] = hi[2] + 5.                 # above the field, along x or y: parallel to the box, outside
+            v5 = cen[:, None] + 3. * ext.max() * rng.normal(size=(3, k))
+            d5 = rng.normal(size=(3, k))
+            v = N.hstack((v1, v2, v3, v4, v5))
+            d = N.hstack((d1, d2, d3, d4, d5))
+            d /= N.sqrt(N.sum(d ** 2, axis=0))
+            b = ref.ray_bundle.RayBundle(vertices=v, directions=d, energy=N.ones(v.shape[1]))
+            with N.errstate(all='ignore'):
+                any_inter, rel = kd.traversal(b)
+            out['trav_vertices'], out['trav_directions'] = v, d
+            out['trav_any'] = N.int32(bool(any_inter))
+            out['trav_relevancy_bits'] = N.packbits(rel, axis=1)
+            out['trav_n_surf'] = N.int32(S)
+            print('  traversal: %d rays, %d of them meet the root box, %.1f surfaces per such ray' %
+                  (v.shape[1], int(rel[:-1].any(axis=0).sum()), rel.sum() / max(1., float(rel[:-1].any(axis=0).sum()))))
 
 
 def make_accountant_names(ref):

@@ -463,6 +463,32 @@ def test_kd_accel_equals_brute_and_reference(ctx):
         assert N.array_equal(h, tl_b[2]) and N.allclose(a, tl_b[0], rtol=1e-12, atol=1e-9), accel
 
 
+def test_kdtree_traversal_standalone(ctx):
+    """KdTree.traversal(bundle) on the device == the reference's own relevancy matrix (fixture) and == the oracle on 20000 more rays"""
+    from tracer_amd import scenes
+    from tracer_amd.accel_tree import KdTree
+    from tracer_amd.ray_bundle import RayBundle
+    from oracle import accel
+    g = load('kdtree_nsttf.npz')
+    plant, field, rec, src = scenes.nsttf_field(sigma=0.)
+    S = len(plant.get_surfaces())
+    kd = KdTree(plant, 8 + 1.3 * N.log(S), min_leaf=1)
+    v, d = g['trav_vertices'], g['trav_directions']
+    any_inter, rel = kd.traversal(RayBundle(vertices=v, directions=d, energy=N.ones(v.shape[1])))
+    assert rel.dtype == bool and rel.shape == (S, v.shape[1])
+    assert any_inter == bool(g['trav_any'])
+    assert N.array_equal(rel, N.unpackbits(g['trav_relevancy_bits'], axis=1)[:, :v.shape[1]].astype(bool))
+    # more rays, against the restatement: the sun's rays over the whole field
+    b = scenes.nsttf_source(20000, src, seed=5)
+    any2, rel2 = kd.traversal(b)
+    with N.errstate(all='ignore'):
+        any_o, rel_o = accel.traversal(kd.flat(), S, N.asarray(b.get_vertices()), N.asarray(b.get_directions()))
+    assert any2 == any_o and N.array_equal(rel2, rel_o)
+    assert rel2[:-1].any(axis=0).sum() > 5000
+    with pytest.raises(NotImplementedError):
+        kd.traversal(b, lightweight=True)
+
+
 def test_full_size_properties(ctx):
     """
     Benchmark-size run (NSTTF, 1e7 rays -- the per-GPU share of configs[3]) checked through size-independent

@@ -331,6 +331,28 @@ def test_kdtree_build_matches_reference():
         assert N.array_equal(f['bounds'], N.concatenate((g[tag + 'minpoint'], g[tag + 'maxpoint'])))
 
 
+def _kd_fixture_tree(g):
+    tree = dict((k, g[k]) for k in ('flag', 'split', 'child', 'leaf_off', 'leaf_cnt', 'leaf_surfs', 'always_relevant'))
+    tree['bounds'] = N.concatenate((g['minpoint'], g['maxpoint']))
+    return tree
+
+
+def test_kdtree_traversal_matches_reference():
+    """KdTree.traversal restated (oracle/accel.py) == the relevancy matrix the reference returns: 700 rays on the NSTTF tree --
+    from the sun's side, from the receiver, from inside the root box, along the axes (infinite inverse directions), missing the box"""
+    from oracle import accel
+    g = load('kdtree_nsttf.npz')
+    S = int(g['trav_n_surf'])
+    v, d = g['trav_vertices'], g['trav_directions']
+    expected = N.unpackbits(g['trav_relevancy_bits'], axis=1)[:, :v.shape[1]].astype(bool)
+    any_inter, rel = accel.traversal(_kd_fixture_tree(g), S, v, d)
+    assert bool(any_inter) == bool(g['trav_any'])
+    assert N.array_equal(rel, expected)
+    crossed = expected[:-1].sum(axis=0)
+    assert (crossed == 0).sum() > 200 and crossed.max() > 20 and expected[-1].all()     # misses, long walks, the receiver always
+    assert (d == 0.).any()
+
+
 def test_accountant_name_table():
     import tracer_amd.optics_callables as oc
     with open(os.path.join(GOLDEN, 'accountant_names.json')) as f:

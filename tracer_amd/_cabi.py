@@ -124,6 +124,8 @@ SIGNATURES = {
                                      C.POINTER(C.c_float), _p_f64]),
     'trc_gm_find_intersections': (C.c_int, [_vp, C.POINTER(SurfaceDesc), C.c_int32, _p_f64, C.POINTER(Rays), _p_f64,
                                             _p_f64, _p_f64, _p_f64]),
+    'trc_kdtree_traversal': (C.c_int, [_vp, C.POINTER(KdTreeDesc), C.c_int32, C.POINTER(Rays), C.c_int64, C.POINTER(C.c_uint8),
+                                       C.POINTER(C.c_int32)]),
     'trc_gm_get_normals': (C.c_int, [_vp, C.POINTER(SurfaceDesc), C.c_int64] + [_p_f64] * 9),
     'trc_optics_apply': (C.c_int, [_vp, C.POINTER(SurfaceDesc), C.c_int32, _p_f64, C.POINTER(Rays)] + [_p_f64] * 6 +
                          [C.c_uint64, C.c_int32, C.POINTER(Rays)]),

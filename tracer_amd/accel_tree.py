@@ -148,6 +148,38 @@ class KdTree(object):
         return 3, Ns
 
     # ------------------------------------------------------------------------------------------
+    def traversal(self, bundle, lightweight=False):
+        """
+        Which surfaces each ray of `bundle` has to be tested against (accel_tree.py:213-312): (any_inter, relevancy), relevancy a
+        (n_surfs, n_rays) boolean array, True where the ray crosses a leaf holding the surface -- every leaf on its way through the
+        root box -- or the surface has no bounds.  Walked on the device, one ray per lane (trc_kdtree_traversal).
+        lightweight=True is the reference's list-of-lists scheduling of the same information (:227-233, :281-286, :301-305); the
+        engines here never consume it (the device walks front to back): not offered.
+        """
+        if lightweight:
+            raise NotImplementedError("the lightweight scheduling lists are a CPU artefact of the reference; use lightweight=False")
+        import ctypes as C
+        from . import _cabi
+        ctx = _cabi.get_context()
+        f = self.flat()
+        d = _cabi.KdTreeDesc()
+        d.n_nodes, d.n_leaf_surfs, d.n_always = len(f['flag']), len(f['leaf_surfs']), len(f['always_relevant'])
+        i32 = C.POINTER(C.c_int32)
+        for name in ('flag', 'child', 'leaf_off', 'leaf_cnt', 'leaf_surfs', 'always_relevant'):
+            setattr(d, name, f[name].ctypes.data_as(i32))
+        d.split = _cabi.ptr(f['split'])
+        for i in range(6):
+            d.bounds[i] = f['bounds'][i]
+        v, dr = _cabi.f64(bundle.get_vertices()), _cabi.f64(bundle.get_directions())
+        n = v.shape[1]
+        rays = _cabi.make_rays(n, v[0], v[1], v[2], dr[0], dr[1], dr[2])
+        rel = N.zeros((self.n_surfs, n), dtype=N.uint8)
+        any_inter = C.c_int32(0)
+        _cabi.check(ctx.lib.trc_kdtree_traversal(ctx.handle, C.byref(d), self.n_surfs, C.byref(rays), n,
+                                                 rel.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(any_inter)))
+        return bool(any_inter.value), rel.view(bool)
+
+    # ------------------------------------------------------------------------------------------
     def flat(self):
         """Arrays for trc_kdtree_desc."""
         n = len(self.nodes)

@@ -2660,6 +2660,143 @@ extern "C" int trc_result_level_get(trc_result *res, int32_t level, trc_rays *ou
 }
 
 // ================================================================================================
+// C-ABI: KdTree.traversal on its own (accel_tree.py:213-312)
+// ================================================================================================
+struct KdTravParams {
+    const int32_t *flag, *child, *leaf_off, *leaf_cnt, *leaf_surfs;
+    const double *split;
+    double lo[3], hi[3];
+    const double *x, *y, *z, *dx, *dy, *dz;
+    long long n;
+    uint8_t *rel;       // n_surf rows of n bytes
+    int *flags;         // [0]: some ray meets the root box; [1]: a ray needed more than KD_TRAV_STACK pending nodes
+};
+
+#define KD_TRAV_STACK 64
+
+// numpy's maximum / minimum hand a nan on (intersect_bounds :325-326)
+__device__ inline double np_maximum(double a, double b) { return (a != a || b != b) ? NAN : (a > b ? a : b); }
+__device__ inline double np_minimum(double a, double b) { return (a != a || b != b) ? NAN : (a < b ? a : b); }
+
+__global__ __launch_bounds__(256) void k_kd_traversal(KdTravParams P) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.n) return;
+    const double pos[3] = {P.x[r], P.y[r], P.z[r]}, dir[3] = {P.dx[r], P.dy[r], P.dz[r]};
+    const double inv[3] = {1.0 / dir[0], 1.0 / dir[1], 1.0 / dir[2]};     // :224
+    double t_lo = 0.0, t_hi = INFINITY;                                     // intersect_bounds :314-330
+    for (int i = 0; i < 3; ++i) {
+        const bool neg = dir[i] < 0.0;
+        double a = ((neg ? P.hi[i] : P.lo[i]) - pos[i]) * inv[i];
+        double b = ((neg ? P.lo[i] : P.hi[i]) - pos[i]) * inv[i];
+        if (a > b) { const double t = a; a = b; b = t; }
+        t_lo = np_maximum(t_lo, a);
+        t_hi = np_minimum(t_hi, b);
+    }
+    if (!(t_hi > 0.0) || (t_lo > t_hi)) return;
+    P.flags[0] = 1;
+    int node = 0, top = 0;
+    int st_node[KD_TRAV_STACK];
+    double st_min[KD_TRAV_STACK], st_max[KD_TRAV_STACK];
+    double t_min = t_lo, t_max = t_hi;
+    while (true) {
+        if (t_hi < t_min) break;                                            // :243 (the root's exit against the current entry)
+        const int f = P.flag[node];
+        if (f != 3) {
+            const double sp = P.split[node];
+            const double t_plane = (sp - pos[f]) * inv[f];                  // :249
+            int c1 = P.child[node], c2 = c1 + 1;
+            const bool below_first = (pos[f] < sp) || (pos[f] == sp && dir[f] <= 0.0);
+            if (!below_first) { const int t = c1; c1 = c2; c2 = t; }
+            if (t_plane > t_max || t_plane <= 0.0) node = c1;               // :258-259
+            else if (t_plane < t_min) node = c2;
+            else {
+                if (top >= KD_TRAV_STACK) { P.flags[1] = 1; return; }
+                st_node[top] = c2; st_min[top] = t_plane; st_max[top] = t_max;
+                ++top;
+                node = c1;
+                t_max = t_plane;
+            }
+        } else {
+            const int off = P.leaf_off[node], cnt = P.leaf_cnt[node];
+            for (int k = 0; k < cnt; ++k) P.rel[(size_t)P.leaf_surfs[off + k] * P.n + r] = 1;       // :288
+            if (top > 0) { --top; node = st_node[top]; t_min = st_min[top]; t_max = st_max[top]; }
+            else break;
+        }
+    }
+}
+
+extern "C" int trc_kdtree_traversal(trc_ctx *ctx, const trc_kdtree_desc *kd, int32_t n_surf, const trc_rays *rays, int64_t n,
+                                    uint8_t *relevancy, int32_t *any_inter) {
+    if (!ctx || !kd || !relevancy || n_surf <= 0 || n < 0) return trc_fail(TRC_ERR_INVALID, "trc_kdtree_traversal: bad arguments");
+    TRC_TRY(check_rays(rays, n, "trc_kdtree_traversal"));
+    if (rays->on_device) return trc_fail(TRC_ERR_INVALID, "trc_kdtree_traversal: host bundle expected");
+    if (kd->n_nodes <= 0 || !kd->flag || !kd->split || !kd->child || !kd->leaf_off || !kd->leaf_cnt || (kd->n_leaf_surfs > 0 && !kd->leaf_surfs))
+        return trc_fail(TRC_ERR_INVALID, "trc_kdtree_traversal: incomplete tree");
+    for (int i = 0; i < kd->n_nodes; ++i) {
+        if (kd->flag[i] < 0 || kd->flag[i] > 3) return trc_fail(TRC_ERR_INVALID, "node %d: flag %d", i, kd->flag[i]);
+        if (kd->flag[i] != 3 && (kd->child[i] <= i || kd->child[i] + 1 >= kd->n_nodes)) return trc_fail(TRC_ERR_INVALID, "node %d: children out of range", i);
+        if (kd->flag[i] == 3 && (kd->leaf_off[i] < 0 || kd->leaf_cnt[i] < 0 || kd->leaf_off[i] + kd->leaf_cnt[i] > kd->n_leaf_surfs))
+            return trc_fail(TRC_ERR_INVALID, "node %d: leaf list out of range", i);
+    }
+    for (int i = 0; i < kd->n_leaf_surfs; ++i)
+        if (kd->leaf_surfs[i] < 0 || kd->leaf_surfs[i] >= n_surf) return trc_fail(TRC_ERR_INVALID, "leaf surface %d out of range", kd->leaf_surfs[i]);
+    for (int i = 0; i < kd->n_always; ++i)
+        if (kd->always_relevant[i] < 0 || kd->always_relevant[i] >= n_surf) return trc_fail(TRC_ERR_INVALID, "always-relevant surface out of range");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int32_t *d_i32[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *d_split = nullptr, *d_r[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint8_t *d_rel = nullptr;
+    int *d_flags = nullptr;
+    int st = TRC_OK;
+    int any = 0;
+    do {
+        const int32_t *hs[5] = {kd->flag, kd->child, kd->leaf_off, kd->leaf_cnt, kd->leaf_surfs};
+        const size_t cnt[5] = {(size_t)kd->n_nodes, (size_t)kd->n_nodes, (size_t)kd->n_nodes, (size_t)kd->n_nodes, (size_t)std::max(kd->n_leaf_surfs, 1)};
+        for (int i = 0; i < 5 && st == TRC_OK; ++i) {
+            if ((st = dev_alloc(&d_i32[i], cnt[i]))) break;
+            if (hs[i] && (i < 4 || kd->n_leaf_surfs > 0) && hipMemcpy(d_i32[i], hs[i], cnt[i] * 4, hipMemcpyHostToDevice) != hipSuccess) st = trc_fail(TRC_ERR_DEVICE, "memcpy failed");
+        }
+        if (st) break;
+        if ((st = dev_alloc(&d_split, (size_t)kd->n_nodes))) break;
+        if (hipMemcpy(d_split, kd->split, (size_t)kd->n_nodes * 8, hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        if ((st = dev_alloc(&d_flags, 2))) break;
+        (void)hipMemset(d_flags, 0, 8);
+        const size_t nn = (size_t)std::max<int64_t>(n, 1);
+        if ((st = dev_alloc(&d_rel, (size_t)n_surf * nn))) break;
+        (void)hipMemset(d_rel, 0, (size_t)n_surf * nn);
+        for (int i = 0; i < kd->n_always; ++i) (void)hipMemset(d_rel + (size_t)kd->always_relevant[i] * nn, 1, nn);        // :236
+        if (n > 0) {
+            const double *src[6] = {rays->x, rays->y, rays->z, rays->dx, rays->dy, rays->dz};
+            for (int i = 0; i < 6 && st == TRC_OK; ++i) {
+                if ((st = dev_alloc(&d_r[i], (size_t)n))) break;
+                if (hipMemcpy(d_r[i], src[i], (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) st = trc_fail(TRC_ERR_DEVICE, "memcpy failed");
+            }
+            if (st) break;
+            KdTravParams P;
+            P.flag = d_i32[0]; P.child = d_i32[1]; P.leaf_off = d_i32[2]; P.leaf_cnt = d_i32[3]; P.leaf_surfs = d_i32[4]; P.split = d_split;
+            for (int i = 0; i < 3; ++i) { P.lo[i] = kd->bounds[i]; P.hi[i] = kd->bounds[3 + i]; }
+            P.x = d_r[0]; P.y = d_r[1]; P.z = d_r[2]; P.dx = d_r[3]; P.dy = d_r[4]; P.dz = d_r[5];
+            P.n = n; P.rel = d_rel; P.flags = d_flags;
+            hipLaunchKernelGGL(k_kd_traversal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, P);
+            hipError_t se = hipStreamSynchronize(ctx->stream);
+            if (se != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "k_kd_traversal failed: %s", hipGetErrorString(se)); break; }
+            int fl[2] = {0, 0};
+            if (hipMemcpy(fl, d_flags, 8, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+            if (fl[1]) { st = trc_fail(TRC_ERR_CAPACITY, "a ray had more than %d pending nodes: the tree is deeper than the traversal's stack", KD_TRAV_STACK); break; }
+            any = fl[0];
+            if (hipMemcpy(relevancy, d_rel, (size_t)n_surf * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        }
+        // `if inters.any() or self.always_relevant.any()` (:238): any() of the array of surface indices -- a non-zero index
+        for (int i = 0; i < kd->n_always; ++i) if (kd->always_relevant[i] != 0) any = 1;
+    } while (0);
+    for (int i = 0; i < 5; ++i) dev_free(d_i32[i]);
+    for (int i = 0; i < 6; ++i) dev_free(d_r[i]);
+    dev_free(d_split); dev_free(d_rel); dev_free(d_flags);
+    if (st == TRC_OK && any_inter) *any_inter = any;
+    return st;
+}
+
+// ================================================================================================
 // C-ABI: per-surface protocol
 // ================================================================================================
 static int upload_record(const trc_surface_desc *surf, int32_t n_extra, const double *extra, double **d_rec, double **d_opt,
