@@ -120,6 +120,9 @@ typedef enum trc_optics_kind {
 
 /* surface flags */
 #define TRC_SURF_CAPTURE_HITS 0x1  /* append every hit to the scene hit buffer (Location/Direction accountants) */
+#define TRC_SURF_CAPTURE_LEAN 0x2  /* with CAPTURE_HITS: only the absorbed energy and the hit point of this surface's hits are wanted
+                                      (Absorption + Location accountants, the "Receiver" classes): incident energy and direction are
+                                      not written -- 36 instead of 68 bytes per hit -- and read back as the absorbed energy and 0 */
 
 /*
  * One Surface of the flattened Assembly (reference: tracer/surface.py:6-112 +

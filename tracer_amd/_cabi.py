@@ -27,6 +27,7 @@ TRACE_STREAM = 0x4
 TRACE_MEGAKERNEL = 0x8
 # surface flags
 SURF_CAPTURE_HITS = 0x1
+SURF_CAPTURE_LEAN = 0x2
 
 # enum trc_gm_kind
 (GM_FLAT_INF, GM_RECT, GM_RECT_EXTRUDED, GM_RECT_PERFORATED, GM_ROUND, GM_ROUND_CUT, GM_TRIANGLE,

@@ -342,20 +342,24 @@ __device__ __forceinline__ unsigned long long chunk_append(unsigned long long *c
 #define SHADE_MAX_WAVES 4096     /* waves of one k_s_shade launch (at most n_cu * 4 workgroups of 4 waves, n_cu <= 256) */
 #define SQ_HIT_CHUNK 1024        /* entries of the hit buffer a wave of k_s_shade reserves per atomic: the cursor is one word (~88 returning
                                     atomics per microsecond), and at 256 the 12 000 reservations of an NSTTF batch were half of the kernel */
-#define TRC_HIT_SLACK (4ll * SHADE_MAX_WAVES * SQ_HIT_CHUNK + 64)   /* unused entries the open chunks of two slots can hold */
+#define TRC_HIT_SLACK (8ll * SHADE_MAX_WAVES * SQ_HIT_CHUNK + 64)   /* unused entries the open chunks of four slots can hold (k_s_shade and
+                                                                     k_s_absorb each keep one open chunk per wave and slot) */
+#define TRC_SURF_TERMINAL 0x10000   /* device copy of the surface flags only: every ray that lands here ends here -- the optics absorb all of
+                                       it whatever the angle (absorptivity 1, no incidence-angle factor): no direction needs to be drawn */
 
 // per-hit bookkeeping shared by both engines: tallies, flux map, hit capture
 template <bool LDS_TALLY>
 __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, int s, double e_in,
                                            double e_abs, double hx, double hy, double hz, double dx,
                                            double dy, double dz, bool capture_enabled, int prev, WaveChunk *hc = nullptr,
-                                           double *lds_fm = nullptr, bool volume = false) {
+                                           double *lds_fm = nullptr, bool volume = false, bool tallied = false) {
+    // tallied: the caller has added the three per-surface sums itself (k_s_absorb: once per wave)
     // volume: the ray was scattered in the medium before it reached the surface -- nothing is recorded, but the lane takes part
     // in the appends of the wave below (their bookkeeping is per wave)
     const int S = sc.n_surf;
     // energy carried from the surface the ray left (S = the source) to the one it lands on
     if (sc.tr_off >= 0 && !volume) atomicAdd(&sc.tally[sc.tr_off + (long long)prev * S + s], e_in);
-    if (volume) {
+    if (volume || tallied) {
     } else if (LDS_TALLY) {
         atomicAdd(&lds_tally[s], e_abs);
         atomicAdd(&lds_tally[S + s], e_in);
@@ -382,21 +386,23 @@ __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, 
     if (capture_enabled && hc) {
         // chunked append (streaming engine): one atomic per 256 captured hits instead of one per wave and iteration --
         // the cursor of the hit buffer is a single word, and a word sustains only ~88 returning atomics per microsecond
-        bool want = !volume && (sc.sflags[s] & TRC_SURF_CAPTURE_HITS) != 0;
+        const int fl = sc.sflags[s];
+        bool want = !volume && (fl & TRC_SURF_CAPTURE_HITS) != 0;
         unsigned long long slot = chunk_append(&sc.counters[0], *hc, want, nullptr, 0);
         if (want) {
             if ((long long)slot < sc.hit_cap) {
                 sc.h_surf[slot] = s;
-                sc.h_eabs[slot] = e_abs; sc.h_ein[slot] = e_in;
+                sc.h_eabs[slot] = e_abs;
                 sc.h_px[slot] = hx; sc.h_py[slot] = hy; sc.h_pz[slot] = hz;
-                sc.h_dx[slot] = dx; sc.h_dy[slot] = dy; sc.h_dz[slot] = dz;
+                if (!(fl & TRC_SURF_CAPTURE_LEAN)) { sc.h_ein[slot] = e_in; sc.h_dx[slot] = dx; sc.h_dy[slot] = dy; sc.h_dz[slot] = dz; }
             } else {
                 atomicAdd(&sc.counters[1], 1ull);
             }
         }
     } else if (capture_enabled) {
         // wave-aggregated append: one atomic per wave per iteration
-        bool want = !volume && (sc.sflags[s] & TRC_SURF_CAPTURE_HITS) != 0;
+        const int fl = sc.sflags[s];
+        bool want = !volume && (fl & TRC_SURF_CAPTURE_HITS) != 0;
         unsigned long long mask = __ballot(want);
         if (mask) {
             int leader = __ffsll((long long)mask) - 1;
@@ -407,9 +413,9 @@ __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, 
                 unsigned long long slot = base + __popcll(mask & ((1ull << lane_id()) - 1ull));
                 if ((long long)slot < sc.hit_cap) {
                     sc.h_surf[slot] = s;
-                    sc.h_eabs[slot] = e_abs; sc.h_ein[slot] = e_in;
+                    sc.h_eabs[slot] = e_abs;
                     sc.h_px[slot] = hx; sc.h_py[slot] = hy; sc.h_pz[slot] = hz;
-                    sc.h_dx[slot] = dx; sc.h_dy[slot] = dy; sc.h_dz[slot] = dz;
+                    if (!(fl & TRC_SURF_CAPTURE_LEAN)) { sc.h_ein[slot] = e_in; sc.h_dx[slot] = dx; sc.h_dy[slot] = dy; sc.h_dz[slot] = dz; }
                 } else {
                     atomicAdd(&sc.counters[1], 1ull);
                 }
@@ -1499,7 +1505,14 @@ static int scene_upload_surfaces(trc_scene *sc) {
     for (int i = 0; i < sc->n_surf; ++i) {
         pack_record(sc->surfs[i], recs.data() + (size_t)i * sc->stride, sc->stride);
         for (int k = 0; k < 8; ++k) opt[(size_t)i * 8 + k] = sc->surfs[i].opt[k];
-        flags[i] = sc->surfs[i].flags;
+        flags[i] = sc->surfs[i].flags & 0xFFFF;
+        // e_out = e (1 - absorptivity) = 0 exactly, and 0 <= min_energy for every min_energy the API accepts
+        const trc_surface_desc &sd = sc->surfs[i];
+        const int ok = sd.optics_kind;
+        const bool plain = ((ok == TRC_OPT_REFLECTIVE || ok == TRC_OPT_ONE_SIDED_REFLECTIVE) && sd.opt[1] == 0.0) ||
+                           ((ok == TRC_OPT_REAL_REFLECTIVE || ok == TRC_OPT_ONE_SIDED_REAL_REFLECTIVE) && sd.opt[3] == 0.0) ||
+                           (ok == TRC_OPT_LAMBERTIAN && sd.opt[2] == 0.0 && sd.opt[4] == 0.0) || ok == TRC_OPT_LAMBERTIAN_SPECULAR;
+        if (plain && sd.opt[0] == 1.0) flags[i] |= TRC_SURF_TERMINAL;
     }
     HIP_TRY(hipMemcpy(sc->d_recs, recs.data(), recs.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(sc->d_opt, opt.data(), opt.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1815,6 +1828,7 @@ struct HitPack {
     int32_t *o_surf;
     double *o_col[8];
     int want[8];
+    const int32_t *sflags;      // TRC_SURF_CAPTURE_LEAN: columns 1 (incident energy) and 5-7 (direction) of the hit were not written
 };
 __global__ __launch_bounds__(256) void k_hits_pack(HitPack H, const uint32_t *offs, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1825,6 +1839,11 @@ __global__ __launch_bounds__(256) void k_hits_pack(HitPack H, const uint32_t *of
     H.o_surf[o] = s;
 #pragma unroll
     for (int k = 0; k < 8; ++k) if (H.want[k]) H.o_col[k][o] = H.col[k][i];
+    if (H.sflags[s] & TRC_SURF_CAPTURE_LEAN) {
+        if (H.want[1]) H.o_col[1][o] = H.col[0][i];
+#pragma unroll
+        for (int k = 5; k < 8; ++k) if (H.want[k]) H.o_col[k][o] = 0.0;
+    }
 }
 
 extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, double *e_abs, double *e_in, double *px,
@@ -1864,6 +1883,7 @@ extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, doub
         *n = cnt;
         if (cnt == 0 || (!surf && !e_abs && !e_in && !px && !py && !pz && !dx && !dy && !dz)) break;
         H.surf = sc->d_h_surf;
+        H.sflags = sc->d_sflags;
         if ((st = dev_alloc(&H.o_surf, (size_t)cnt))) break;
         for (int k = 0; k < 8 && st == TRC_OK; ++k) {
             H.col[k] = sc->d_h[k];

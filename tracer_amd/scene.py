@@ -77,8 +77,12 @@ class CompiledScene(object):
             extra.extend(ex)
             wants_hits = isinstance(opt, OpticsCallable) and len(opt.accountants) > 0
             self.capture.append(wants_hits)
+            sflags = _cabi.SURF_CAPTURE_HITS if wants_hits else 0
+            # "Receiver" classes (absorbed energy + hit points): the device leaves incident energy and direction of their hits out
+            if wants_hits and all(type(a) in (AbsorptionAccountant, LocationAccountant) for a in opt.accountants):
+                sflags |= _cabi.SURF_CAPTURE_LEAN
             fill_desc(self.descs[i], s._temp_frame, gkind, gpar, okind, opar,
-                      flags=_cabi.SURF_CAPTURE_HITS if wants_hits else 0, extra_off=off, extra_len=len(ex))
+                      flags=sflags, extra_off=off, extra_len=len(ex))
             if getattr(nat, '_splits', False):
                 self.splits = True
         self.extra = _cabi.f64(extra)
