@@ -189,6 +189,62 @@ def test_fresh_and_bounce_kernels_on_mixed_scenes_and_sources(ctx):
                 _same(ref, _trace(ctx, cs, bundle, reps=12, accel=False), ('all boxes', flat_only, k))
 
 
+def test_terminal_surfaces_are_finished_by_k_s_absorb(ctx):
+    """
+    Surfaces that end every ray (absorptivity 1: the receivers) among mirrors and partly absorbing walls.  k_s_bounce lists the hits on
+    them apart and k_s_absorb finishes them (no optics sampled, eight waves per SIMD): tallies, flux map and the captured hits equal
+    those of the route without the split (TRC_STREAM_ABSORB=0) and of the megakernel.  Capture: a Receiver (absorbed energy + hit
+    points) is captured lean -- incident energy reads back as the absorbed one, directions as 0; a Detector keeps everything.
+    """
+    from tracer_amd import sources, optics_callables as opt
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM, RoundPlateGM
+    from tracer_amd.spatial_geometry import translate, rotx, roty, rotz
+    from tracer_amd.scene import compile_scene
+    from tracer_amd import _cabi
+    rng = N.random.RandomState(12)
+    kinds = [lambda: opt.Reflective(0.1), lambda: opt.LambertianReceiver(1.0), lambda: opt.RealReflective(0.2, 3e-3),
+             lambda: opt.ReflectiveDetector(1.0), lambda: opt.LambertianReceiver(0.6), lambda: opt.Reflective(0.05)]
+    objs = []
+    for k in range(30):
+        gm = [RectPlateGM(1.8, 1.1), RoundPlateGM(0.9)][k % 2]
+        tr = N.dot(translate(*rng.uniform(-5, 5, 3)), N.dot(rotx(rng.uniform(0, 6.3)), N.dot(roty(rng.uniform(0, 6.3)), rotz(rng.uniform(0, 6.3)))))
+        objs.append(AssembledObject(surfs=[Surface(gm, kinds[k % 6]())], transform=tr))
+    cs = compile_scene(Assembly(objects=objs))
+    flags = N.array([cs.descs[i].flags for i in range(cs.n_surf)])
+    lean = (flags & _cabi.SURF_CAPTURE_LEAN) != 0
+    assert lean.sum() == 10 and ((flags & _cabi.SURF_CAPTURE_HITS) != 0).sum() == 15         # two Receivers lean, the Detector not
+    direction = N.r_[0.25, -0.15, -1.] / N.linalg.norm([0.25, -0.15, -1.])
+    n = 1500000
+    bundle = lambda: sources.buie_sunshape(n, N.c_[-30. * direction], direction, 9., 0.05, flux=1., seed=77)
+    ue = N.linspace(-0.9, 0.9, 21)
+    kw = dict(reps=12, fluxmap=(1, ue, ue), hit_capacity=4 * n)
+    ref = _trace(ctx, cs, bundle, **kw)
+    term = N.array([k % 6 in (1, 3) for k in range(30)])
+    assert ref['h'][term].sum() > 0.01 * n and ref['h'][~term].sum() > 0.05 * n and ref['segments'] > 1.05 * n
+    assert N.isclose(ref['fm'].sum(), ref['a'][1], rtol=1e-9) and ref['a'][1] > 0
+
+    def hits_sorted(c):
+        o = N.lexsort((c['points'][2], c['points'][1], c['points'][0], c['surf']))
+        return dict((k, (v[..., o] if isinstance(v, N.ndarray) else v)) for k, v in c.items())
+    a = hits_sorted(ref['captured'])
+    assert len(a['surf']) == ref['h'][(flags & _cabi.SURF_CAPTURE_HITS) != 0].sum()
+    is_lean = lean[a['surf']]
+    assert is_lean.any() and (~is_lean).any()
+    assert N.array_equal(a['e_in'][is_lean], a['e_abs'][is_lean]) and not a['directions'][:, is_lean].any()
+    assert N.allclose(N.sum(a['directions'][:, ~is_lean] ** 2, axis=0), 1.) and (a['e_in'][~is_lean] >= a['e_abs'][~is_lean]).all()
+    for what, knobs in (('no split', dict(TRC_STREAM_ABSORB=0)), ('megakernel', dict(stream=False)), ('general path', dict(TRC_STREAM_BOUNCE=0)),
+                        ('no pre-assigned chunks', dict(TRC_STREAM_STATIC=0))):
+        other = _trace(ctx, cs, bundle, **dict(kw, **knobs))
+        _same(ref, other, what)
+        b = hits_sorted(other['captured'])
+        assert N.array_equal(a['surf'], b['surf']), what
+        for key in ('e_abs', 'e_in', 'points', 'directions'):
+            assert N.allclose(a[key], b[key], rtol=1e-9, atol=1e-12), (what, key)
+
+
 def test_list_overflows_are_reported_and_leave_no_trace(ctx):
     """
     The lists of the engine (ray table, footprint list, general-path list, walker queue, hit list, active list) are sized for
