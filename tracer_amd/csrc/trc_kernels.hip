@@ -170,6 +170,10 @@ struct trc_scene {
     unsigned long long *d_counters;
     double *d_energy_left;     // = (double *)(d_counters + 5)
     trc_source_desc *d_src_buf; // device copy of the source descriptor of the call in progress (kept between calls)
+    trc_source_desc src_host;   // ... and what it holds (src_host_ok): a Monte-Carlo loop hands over the same descriptor every call
+    bool src_host_ok;
+    unsigned long long cnt_host[8];   // host copy of d_counters as trc_trace_fast left them (cnt_host_ok): the next call does not read
+    bool cnt_host_ok;                 // them back before it starts.  Every other writer of d_counters updates or drops the copy.
     int64_t hit_cap;      // entries allocated: the capacity asked for + TRC_HIT_SLACK
     int64_t hit_cap_user;
     uint32_t hit_epoch;   // bumped whenever the cursor is reset: chunks left open by earlier launches are stale
@@ -1590,6 +1594,9 @@ extern "C" int trc_scene_create(trc_ctx *ctx, int32_t n_surf, const trc_surface_
     trc_scene *sc = new (std::nothrow) trc_scene();
     if (!sc) return trc_fail(TRC_ERR_NOMEM, "out of host memory");
     sc->ctx = ctx;
+    sc->src_host_ok = false;
+    sc->cnt_host_ok = false;
+    memset(sc->cnt_host, 0, sizeof(sc->cnt_host));
     sc->n_surf = n_surf;
     sc->stride = TRC_REC_HDR + max_np;
     if ((sc->stride & 1) == 0) sc->stride += 1;  // odd number of doubles: spreads records over LDS banks
@@ -1754,6 +1761,7 @@ extern "C" int trc_scene_set_hit_capacity(trc_scene *sc, int64_t capacity) {
     sc->hit_cap_user = 0;
     sc->hit_epoch += 1;
     HIP_TRY(hipMemset(sc->d_counters, 0, 2 * sizeof(unsigned long long)));
+    sc->cnt_host[0] = sc->cnt_host[1] = 0ull;
     if (capacity == 0) return TRC_OK;
     // the streaming engine appends in chunks that stay open between launches: room for what they can leave unused
     const int64_t slack = (4 * capacity + 4096 < TRC_HIT_SLACK) ? 4 * capacity + 4096 : TRC_HIT_SLACK;   // small buffers see few waves
@@ -1778,6 +1786,7 @@ extern "C" int trc_scene_clear_hits(trc_scene *sc) {
     HIP_TRY(hipSetDevice(sc->ctx->device));
     HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
     HIP_TRY(hipMemset(sc->d_counters, 0, 2 * sizeof(unsigned long long)));
+    sc->cnt_host[0] = sc->cnt_host[1] = 0ull;
     return scene_reset_hit_buffer(sc);
 }
 
@@ -1788,6 +1797,7 @@ extern "C" int trc_scene_reset_tallies(trc_scene *sc) {
     HIP_TRY(hipMemset(sc->d_tally, 0, (size_t)sc->tally_n * sizeof(double)));
     HIP_TRY(hipMemset(sc->d_counters, 0, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(sc->d_energy_left, 0, sizeof(double)));
+    memset(sc->cnt_host, 0, sizeof(sc->cnt_host));
     return scene_reset_hit_buffer(sc);
 }
 
@@ -2162,8 +2172,13 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
             // the scene keeps a device buffer for the descriptor of the call in progress (hipMalloc / hipFree per call
             // cost more than the upload)
             if (src->kind < TRC_SRC_PILLBOX_DISK || src->kind > TRC_SRC_VF_FRUSTUM) { st = trc_fail(TRC_ERR_UNSUPPORTED, "source kind %d is not in the native table", src->kind); break; }
-            if (!sc->d_src_buf && (st = dev_alloc(&sc->d_src_buf, 1))) break;
-            if (hipMemcpy(sc->d_src_buf, src, sizeof(trc_source_desc), hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "source upload failed"); break; }
+            if (!sc->d_src_buf) { if ((st = dev_alloc(&sc->d_src_buf, 1))) break; sc->src_host_ok = false; }
+            if (!(sc->src_host_ok && memcmp(&sc->src_host, src, sizeof(trc_source_desc)) == 0)) {
+                sc->src_host_ok = false;
+                if (hipMemcpy(sc->d_src_buf, src, sizeof(trc_source_desc), hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "source upload failed"); break; }
+                memcpy(&sc->src_host, src, sizeof(trc_source_desc));
+                sc->src_host_ok = true;
+            }
             d_src = sc->d_src_buf;
         }
         int64_t last_cap = 0;
@@ -2177,14 +2192,18 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         }
         // counters and the energy left live in one 64-byte block: one read before, one after
         unsigned long long blk_before[8];
-        if (hipMemcpy(blk_before, sc->d_counters, sizeof(blk_before), hipMemcpyDeviceToHost) != hipSuccess) {
+        if (sc->cnt_host_ok) memcpy(blk_before, sc->cnt_host, sizeof(blk_before));
+        else if (hipMemcpy(blk_before, sc->d_counters, sizeof(blk_before), hipMemcpyDeviceToHost) != hipSuccess) {
             st = trc_fail(TRC_ERR_DEVICE, "counter readback failed"); break;
         }
+        sc->cnt_host_ok = false;          // (until this call has read them back at its end)
         for (int i = 0; i < 4; ++i) cnt_before[i] = blk_before[i];
         memcpy(&eleft_before, &blk_before[5], sizeof(double));
         // the `last` cursor restarts for every call
-        unsigned long long zero = 0;
-        if (hipMemcpy(sc->d_counters + 2, &zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        if (blk_before[2] != 0ull) {
+            unsigned long long zero = 0;
+            if (hipMemcpy(sc->d_counters + 2, &zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        }
 
         FastParams P;
         memset(&P, 0, sizeof(P));
@@ -2269,6 +2288,7 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
             }
             stream_counts_known = true;
         } else {
+        (void)hipStreamSynchronize(ctx->stream);       // (the sums of an earlier streaming call may still be on their way into the buffer)
         if (hipMemcpy(tally_before, sc->d_tally + 3 * S, sizeof(tally_before), hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "counter readback failed"); break; }
         void (*kern)(FastParams) = nullptr;
         if (m32) kern = threads == 1024 ? k_trace_coop<1024> : (threads == 768 ? k_trace_coop<768> : (threads == 512 ? k_trace_coop<512> : k_trace_coop<256>));
@@ -2308,6 +2328,8 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         }
         for (int i = 0; i < 4; ++i) cnt_after[i] = blk_after[i];
         memcpy(&eleft_after, &blk_after[5], sizeof(double));
+        memcpy(sc->cnt_host, blk_after, sizeof(blk_after));
+        sc->cnt_host_ok = true;
         if (stream_counts_known) {              // the streaming form counted on the host
             s.segments = (int64_t)(stream_seg + 0.5);
             s.hits = (int64_t)(stream_hits + 0.5);
