@@ -262,7 +262,7 @@ def main():
                          'traffic': traffic, 'traffic_fetch_as_counted': traffic_raw,
                          'kernel': 'k_trace_coop<512>' if launches == 1 else
                                    'fast engine, streaming form: k_s_cull + k_s_fresh (+ the general path for the aureole) + k_s_shade, '
-                                   'then k_s_bounce + k_s_shade per bounce (%d launches per step)' % launches,
+                                   'then k_s_bounce + k_s_shade + k_s_absorb (the hits on the receiver) per bounce (%d launches per step)' % launches,
                          'kernel_ms_per_launch': kms / args.steps,
                          'algorithmic_bytes_per_launch': seg / args.steps * B_SEG},
             'check': {'receiver_kW': receiver_kw, 'receiver_hits': int(h[218]), 'heliostat_hits': int(h[:218].sum()),
