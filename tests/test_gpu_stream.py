@@ -245,6 +245,50 @@ def test_terminal_surfaces_are_finished_by_k_s_absorb(ctx):
             assert N.allclose(a[key], b[key], rtol=1e-9, atol=1e-12), (what, key)
 
 
+def test_dish_into_spectral_cavity_at_scale(ctx):
+    """
+    BASELINE configs[4] on one rank, 2e7 rays here (tools/gpu_cavity.py runs the 1.25e8 of a rank's share): a dish with slope error
+    focuses a Buie sun into a cavity whose walls have angle- and wavelength-dependent optics (frustum, cylinder, cone, annulus, a
+    Fresnel conductor, a spectral mirror); every ray carries a wavelength.  Streaming form (two batches in flight) == megakernel:
+    hit counts and segments exactly, energies to 1e-9; the first 3000 rays == the oracle ray for ray; the shares of the 2e7 rays
+    per surface agree with those 3000 within 5 sigma; nothing is created: absorbed + still alive <= sent.
+    """
+    from tracer_amd import scenes
+    from tracer_amd.scene import DeviceScene
+    from tracer_amd.ray_bundle import RayBundle
+    from oracle import engine as oracle_engine
+    ts, src = scenes.dish_cavity()
+    n = 20000000
+    b0 = scenes.dish_source(n, src, seed=9)
+    v, d, e = N.asarray(b0.get_vertices()), N.asarray(b0.get_directions()), N.asarray(b0.get_energy())
+    wl = N.random.RandomState(4).uniform(0.3e-6, 2.5e-6, n)
+    reps, emin, seed = 12, 1e-3 * e[0], 31
+    out = {}
+    for name, stream in (('stream', True), ('mega', False)):
+        dev = DeviceScene(ts, ctx)
+        st, _ = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e, wavelengths=wl), reps, emin, seed, stream=stream)
+        a, r, h = dev.get_tallies()
+        out[name] = dict(a=a, r=r, h=h, segments=st.segments, hits=st.hits, left=st.energy_left, launches=st.launches)
+        dev.close()
+    A, B = out['stream'], out['mega']
+    assert A['launches'] > 10 and B['launches'] == 1
+    assert N.array_equal(A['h'], B['h']) and A['segments'] == B['segments'] and A['hits'] == B['hits']
+    assert N.allclose(A['a'], B['a'], rtol=1e-9) and N.allclose(A['r'], B['r'], rtol=1e-9) and N.isclose(A['left'], B['left'], rtol=1e-9, atol=1e-12)
+    assert (A['h'] > 1000).all() and A['h'][0] > n and A['segments'] > 4 * n       # every surface takes part; rays come back to the dish
+    assert 0.5 * e.sum() < A['a'].sum() + A['left'] <= e.sum() * (1. + 1e-12)
+    m = 3000
+    with N.errstate(all='ignore'):
+        o = oracle_engine.trace_bundle(ts, v[:, :m], d[:, :m], e[:m], reps, emin, seed, wavelengths=wl[:m])
+    dev = DeviceScene(ts, ctx)
+    st, _ = dev.trace_fast(RayBundle(vertices=v[:, :m], directions=d[:, :m], energy=e[:m], wavelengths=wl[:m]), reps, emin, seed, stream=True)
+    a, r, h = dev.get_tallies()
+    dev.close()
+    assert N.array_equal(h, o['hits']) and st.segments == o['segments'] and N.allclose(a, o['absorbed'], rtol=1e-9, atol=1e-12)
+    p_small, p_big = o['hits'] / float(m), A['h'] / float(n)
+    sigma = N.sqrt(N.maximum(p_big, 1e-4) / m) * 2.        # hits per ray are not Bernoulli (a ray hits a wall several times): factor 2
+    assert (N.abs(p_small - p_big) < 5. * sigma).all(), (p_small, p_big, sigma)
+
+
 def test_list_overflows_are_reported_and_leave_no_trace(ctx):
     """
     The lists of the engine (ray table, footprint list, general-path list, walker queue, hit list, active list) are sized for

@@ -634,7 +634,8 @@ template <bool LDS_TALLY, bool SIMPLE = false>
 __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *recs, double *l_tally, double t, int s, double &px,
                                            double &py, double &pz, double &dx, double &dy, double &dz, double &e, double &ref,
                                            double wl, unsigned long long rid, int &bounce, int &prev, WaveChunk *hc = nullptr,
-                                           double *lds_fm = nullptr) {
+                                           double *lds_fm = nullptr, bool tallied = false, bool *was_volume = nullptr) {
+    // tallied: the caller adds the three per-surface sums itself (k_s_shade: per wave), unless *was_volume comes back true
     const DScene &sc = P.sc;
     bounce += 1;
     const double *rec = recs + (size_t)s * sc.stride;
@@ -651,9 +652,10 @@ __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *re
     // a volume event (scattering in the medium): the ray never reached the surface -- it goes on from a point before the hit,
     // the surface records nothing, the surface the ray left stays the one it left
     const bool volume = out[0].back > 0.0;
+    if (was_volume) *was_volume = volume;
     if (volume) { hx -= out[0].back * dx; hy -= out[0].back * dy; hz -= out[0].back * dz; }
     double e_abs = e - out[0].e;
-    record_hit<LDS_TALLY>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0, prev, hc, lds_fm, volume);
+    record_hit<LDS_TALLY>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0, prev, hc, lds_fm, volume, tallied);
     if (!volume) prev = s;
     px = hx; py = hy; pz = hz;
     dx = out[0].dx; dy = out[0].dy; dz = out[0].dz;

@@ -99,3 +99,70 @@ def flat_pair():
 def flat_pair_source(n, src, seed=None, ray_offset=0):
     return sources.rect_bundle(n, src['center'], src['direction'], src['x'], src['y'], src['ang_range'],
                                flux=src['flux'], seed=seed, ray_offset=ray_offset)
+
+
+def cavity_arrays():
+    """
+    A cavity receiver in the manner of the reference's tracer/models/Two_N_parameters_cavity.py:87-152, as scene-table arrays
+    (dict for scene.TableScene): aperture annulus at z = 0 (inner radius 1), frustum 0 < z < 1 (radius 1 -> 1.4), cylinder
+    1 < z < 2.5, cone back (apex at z = 3.5), a metal ring plate and a spectrally selective mirror disc inside -- walls with
+    angle- and wavelength-dependent Lambertian optics, a Fresnel conductor, a spectral mirror: every table-driven optics kind.
+    Rays need a `wavelengths` column.
+    """
+    from . import _cabi as K
+    ths = N.linspace(0., N.pi / 2., 7)
+    abth = N.array([0.9, 0.88, 0.85, 0.8, 0.7, 0.5, 0.1])
+    wls = N.linspace(0.25e-6, 2.6e-6, 5)
+    grid = 0.2 + 0.7 * N.outer(N.cos(ths) ** 0.5, 1. / (1. + (wls * 1e6 - 1.) ** 2))
+    mlam = N.linspace(0.2e-6, 3e-6, 8)
+    mn = N.array([0.1, 0.13, 0.2, 0.4, 0.9, 1.5, 2.4, 3.6])
+    mk = N.array([2.0, 3.5, 5.0, 7.0, 9.5, 13., 18., 24.])
+    slam = N.linspace(0.2e-6, 3e-6, 9)
+    sab = N.array([0.1, 0.2, 0.15, 0.4, 0.9, 0.5, 0.3, 0.2, 0.25])
+    tables = [N.concatenate((ths, abth)), N.concatenate(([len(ths), len(wls)], ths, wls, grid.ravel())),
+              N.concatenate((mlam, mn, mk)), N.concatenate((slam, sab))]
+    offs = N.concatenate(([0], N.cumsum([len(t) for t in tables])))
+    gm_kind = [K.GM_FRUSTUM, K.GM_CYL_FINITE, K.GM_CONE_FINITE, K.GM_ROUND, K.GM_ROUND, K.GM_ROUND]
+    frames = [N.eye(4), translate(0, 0, 1.75), N.dot(translate(0, 0, 3.5), rotx(N.pi)), N.eye(4), translate(0, 0, 2.2), translate(0.2, 0., 1.2)]
+    gm = N.zeros((6, 16))
+    gm[0, :4] = (1.4 - 1.0) / (1.0 - 0.0), (1.4 * 0. - 1.0 * 1.0) / (1.4 - 1.0), 0., 1.
+    gm[1, :4] = 1.4, 0.75, 0., 2. * N.pi
+    gm[2, :3] = 1.4 / 1.0, 0., 1.0
+    gm[3, :2] = 1.6, 1.0
+    gm[4, :2] = 0.6, 0.2
+    gm[5, :2] = 0.3, -1.
+    ok = [K.OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL, K.OPT_LAMBERTIAN_DIRECTIONAL, K.OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL, K.OPT_SEMI_LAMBERTIAN,
+          K.OPT_FRESNEL_CONDUCTOR, K.OPT_REFLECTIVE_SPECTRAL]
+    opt_p = N.zeros((6, 8))
+    opt_p[3, :2] = 0.6, 0.9           # the aperture annulus: mirror beyond 0.9 rad of incidence, Lambertian (into 0.9 rad) below
+    opt_p[4, 0] = 1.0
+    which = [1, 0, 1, -1, 2, 3]
+    return dict(gm_kind=N.array(gm_kind, dtype=N.int32), optics_kind=N.array(ok, dtype=N.int32), frames=N.array(frames), gm=gm, opt=opt_p,
+                extra=N.concatenate(tables), extra_off=N.array([offs[w] if w >= 0 else -1 for w in which]),
+                extra_len=N.array([len(tables[w]) if w >= 0 else 0 for w in which]))
+
+
+def dish_cavity(sigma=2e-3, scale=0.12):
+    """
+    The fifth configuration of BASELINE.json on one rank: the dish of `dish()` (slope error `sigma`) focusing into the cavity of
+    `cavity_arrays()` scaled by `scale` (aperture radius 0.12 m) with its aperture in the focal plane, axis along the dish's.
+    Returns (TableScene, src): rays start on a disc between dish and cavity (the cavity does not shade it) and need wavelengths.
+    """
+    from .scene import TableScene, compile_scene, scene_arrays
+    d = scene_arrays(compile_scene(dish(sigma)[0]))
+    c = cavity_arrays()
+    S = N.diag([scale, scale, scale, 1.])
+    frames = [N.dot(translate(0., 0., 3.), N.dot(S, f)) for f in c['frames']]       # scaled copy: frames carry the scale ...
+    for f in frames:                                                               # ... as lengths, rotations stay orthonormal
+        f[:3, :3] /= scale
+    gm = c['gm'].copy()
+    gm[0, 2:4] *= scale; gm[0, 1] *= scale                  # frustum: z range and apex offset (the slope c is a ratio)
+    gm[1, :2] *= scale                                      # cylinder: radius, half height
+    gm[2, 2] *= scale                                       # cone: height (its slope is a ratio)
+    gm[3, :2] *= scale; gm[4, :2] *= scale; gm[5, 0] *= scale
+    cat = lambda a, b: N.concatenate((a[:1], b))
+    ts = TableScene(cat(d['gm_kind'], c['gm_kind']), cat(d['optics_kind'], c['optics_kind']), [d['frames'][0]] + frames,
+                    N.vstack((d['gm'][:1], gm)), N.vstack((d['opt'][:1], c['opt'])), c['extra'],
+                    N.concatenate(([-1], c['extra_off'])), N.concatenate(([0], c['extra_len'])))
+    src = dict(center=N.c_[[0., 0., 2.9]], direction=N.r_[0., 0., -1.], radius=2.5, CSR=0.05, flux=1000.)
+    return ts, src
