@@ -289,6 +289,61 @@ def test_dish_into_spectral_cavity_at_scale(ctx):
     assert (N.abs(p_small - p_big) < 5. * sigma).all(), (p_small, p_big, sigma)
 
 
+def test_calls_in_sequence_accumulate_like_fresh_scenes(ctx):
+    """
+    What the library keeps between calls (counters shadowed on the host, the source descriptor on the device, private tally copies
+    whose merge is not waited for, open chunks of the hit buffer) must never show: a scene traced several times -- streaming form,
+    megakernel, hits cleared in between, tallies reset in between, another source -- reports per call and in total what fresh
+    scenes report for the same calls.
+    """
+    from tracer_amd import scenes
+    from tracer_amd.scene import compile_scene, DeviceScene
+    plant, field, rec, src = scenes.nsttf_field(n_heliostats=40)
+    cs = compile_scene(plant)
+    n = 1500000
+    ue, ve = scenes.nsttf_fluxmap_edges()
+    S = cs.n_surf
+
+    def fresh(offset, stream, seed=7, radius=None):
+        dev = DeviceScene(cs, ctx)
+        dev.set_fluxmap(S - 1, ue, ve)
+        dev.set_hit_capacity(n)
+        b = scenes.nsttf_source(n, dict(src, radius=radius or src['radius']), seed=seed, ray_offset=offset)
+        st, _ = dev.trace_fast(b, 100, 1e-10, seed, accel=True, stream=stream)
+        a, r, h = dev.get_tallies()
+        out = dict(a=a, r=r, h=h, fm=dev.get_fluxmap(S - 1), seg=st.segments, hits=st.hits, left=st.energy_left, cap=len(dev.get_hits()['surf']))
+        dev.close()
+        return out
+    calls = [(0, True, None), (n, True, None), (2 * n, False, None), (3 * n, True, 0.6 * src['radius']), (4 * n, True, None)]
+    ref = [fresh(off, stream, radius=rad) for off, stream, rad in calls]
+    dev = DeviceScene(cs, ctx)
+    dev.set_fluxmap(S - 1, ue, ve)
+    dev.set_hit_capacity(5 * n)
+    tot = dict(a=0., r=0., h=0, fm=0., cap=0)
+    for k, (off, stream, rad) in enumerate(calls):
+        b = scenes.nsttf_source(n, dict(src, radius=rad or src['radius']), seed=7, ray_offset=off)
+        st, _ = dev.trace_fast(b, 100, 1e-10, 7, accel=True, stream=stream)
+        assert (st.segments, st.hits) == (ref[k]['seg'], ref[k]['hits']), k
+        assert N.isclose(st.energy_left, ref[k]['left'], rtol=1e-9, atol=1e-12), k
+        for key in ('a', 'r', 'h', 'fm', 'cap'):
+            tot[key] = tot[key] + ref[k][key]
+        if k in (0, 2, 3):              # read right after the call: the merge of the private copies must have happened
+            a, r, h = dev.get_tallies()
+            assert N.array_equal(h, tot['h']) and N.allclose(a, tot['a'], rtol=1e-9, atol=1e-12) and N.allclose(r, tot['r'], rtol=1e-9, atol=1e-12), k
+            assert N.allclose(dev.get_fluxmap(S - 1), tot['fm'], rtol=1e-9, atol=1e-12), k
+        if k == 1:
+            assert len(dev.get_hits()['surf']) == tot['cap']
+            dev.lib.trc_scene_clear_hits(dev.handle)
+            tot['cap'] = 0
+        if k == 3:
+            dev.reset_tallies()
+            tot = dict(a=0., r=0., h=0, fm=0., cap=0)
+    a, r, h = dev.get_tallies()
+    assert N.array_equal(h, ref[4]['h']) and N.allclose(a, ref[4]['a'], rtol=1e-9, atol=1e-12)
+    assert len(dev.get_hits()['surf']) == ref[4]['cap'] > 0
+    dev.close()
+
+
 def test_list_overflows_are_reported_and_leave_no_trace(ctx):
     """
     The lists of the engine (ray table, footprint list, general-path list, walker queue, hit list, active list) are sized for
