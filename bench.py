@@ -236,8 +236,9 @@ def main():
             adt = time.time() - t1
             api = {'entry': 'TracerEngine.ray_tracer(bundle, reps=100, min_energy=1e-10, tree=False, accel=%r)' % accel,
                    'steps': args.api_steps, 'ms_per_step': adt / args.api_steps * 1e3, 'value': aseg / adt / 1e6, 'unit': 'Mray-bounces/s',
-                   'includes': 'scene signature check, hit buffer of 2n+1024 entries cleared, trc_trace_fast, %d receiver hits per step '
-                               'copied to the host and fed to the receiver\'s accountants' % int(h[218] / max(args.steps, 1))}
+                   'includes': 'scene signature check, hit buffer of 2n+1024 entries emptied (the part the last trace used), trc_trace_fast, '
+                               '%d receiver hits per step (absorbed energy + hit point: 36 B each) packed on the device, copied to the host '
+                               'and fed to the receiver\'s accountants' % int(h[218] / max(args.steps, 1))}
         total_rays = float(n) * args.steps * world
         e_ray = 1000. * N.pi * src['radius'] ** 2 / n        # energy per ray of ONE step's bundle
         receiver_kw = a[218] / args.steps / world / 1e3       # mean over the independent batches

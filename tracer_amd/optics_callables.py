@@ -616,7 +616,7 @@ class AbsorptionAccountant(Accountant):
         self._data.append(rays.get_energy(selector) - new_bundle.get_energy())
 
     def feed(self, hit):
-        self._data.append(hit['e_in'] - hit['e_out'])
+        self._data.append(hit['e_abs'] if 'e_abs' in hit else hit['e_in'] - hit['e_out'])
 
 
 class AttenuationAccountant(Accountant):

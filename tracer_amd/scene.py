@@ -250,17 +250,23 @@ class DeviceScene(object):
         return a, r, h
 
     def get_hits(self):
-        """dict of the captured hits, device arrival order."""
+        """dict of the captured hits, device arrival order.  When every capturing surface is captured lean (Receiver accountants:
+        absorbed energy + hit point) the columns the device did not write are not fetched either: `e_in` is the absorbed energy,
+        `directions` is None."""
         n = C.c_int64(0)
         nul = C.POINTER(C.c_double)()
         _cabi.check(self.lib.trc_scene_get_hits(self.handle, C.byref(n), None, nul, nul, nul, nul, nul, nul, nul, nul))
         k = n.value
+        fl = [self.compiled.descs[i].flags for i in range(self.n_surf)]
+        lean = all((f & _cabi.SURF_CAPTURE_LEAN) for f in fl if (f & _cabi.SURF_CAPTURE_HITS)) and any(f & _cabi.SURF_CAPTURE_HITS for f in fl)
         surf = N.empty(k, dtype=N.int32)
-        e_abs, e_in, points, directions = N.empty(k), N.empty(k), N.empty((3, k)), N.empty((3, k))
-        cols = [e_abs, e_in, points[0], points[1], points[2], directions[0], directions[1], directions[2]]   # rows: no copy afterwards
+        e_abs, points = N.empty(k), N.empty((3, k))
+        e_in = e_abs if lean else N.empty(k)
+        directions = None if lean else N.empty((3, k))
+        cols = [e_abs, None if lean else e_in, points[0], points[1], points[2]] + ([None] * 3 if lean else [directions[0], directions[1], directions[2]])   # rows: no copy afterwards
         if k:
             _cabi.check(self.lib.trc_scene_get_hits(self.handle, C.byref(n), surf.ctypes.data_as(C.POINTER(C.c_int32)),
-                                                    *[_cabi.ptr(c) for c in cols]))
+                                                    *[(_cabi.ptr(c) if c is not None else nul) for c in cols]))
         return dict(surf=surf, e_abs=e_abs, e_in=e_in, points=points, directions=directions)
 
     def bin_hits(self, surf_lo, surf_hi, ranges, mode):
@@ -431,7 +437,7 @@ class OrderedResult(object):
         return out
 
 
-def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavelengths=None, spectra=None):
+def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavelengths=None, spectra=None, e_abs=None):
     """
     Hand per-hit data to the accountants of each surface's optics (fused engines).  Inside one call
     the hits of a surface are kept in the order given.
@@ -454,7 +460,7 @@ def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavele
         idx = slice(None) if order is None else order[a:b]
         surf = surfaces[s]
         pts = points[:, idx]
-        dirs = directions[:, idx]
+        dirs = None if directions is None else directions[:, idx]
 
         def normals(surf=surf, pts=pts, dirs=dirs):
             gm = surf.get_geometry_manager()
@@ -467,8 +473,10 @@ def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavele
                                                    _cabi.ptr(h[2]), _cabi.ptr(d[0]), _cabi.ptr(d[1]), _cabi.ptr(d[2]),
                                                    _cabi.ptr(out[0]), _cabi.ptr(out[1]), _cabi.ptr(out[2])))
             return out
-        hit = dict(e_in=e_in[idx], e_out=e_out[idx], points=pts, directions=dirs, normals=normals,
+        hit = dict(e_in=e_in[idx], e_out=None if e_out is None else e_out[idx], points=pts, directions=dirs, normals=normals,
                    wavelengths=None if wavelengths is None else wavelengths[idx])
+        if e_abs is not None:       # (given instead of e_out by the fast engine's lean capture: no array of differences is made)
+            hit['e_abs'] = e_abs[idx]
         if spectra is not None:     # polychromatic bundles: (spectra of the incident rays, of the outgoing ones, their wavelength grids)
             hit['spectra_in'], hit['spectra_out'], hit['wavelengths'] = spectra[0][:, idx], spectra[1][:, idx], spectra[2][:, idx]
         for acc in opt.accountants:

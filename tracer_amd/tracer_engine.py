@@ -218,8 +218,10 @@ class TracerEngine(object):
                                % (stats.hits_dropped, dev.hit_capacity))
         if capture and feed:
             h = dev.get_hits()
-            feed_accountants(dev.compiled.surfaces, h['surf'], h['e_in'], h['e_in'] - h['e_abs'], h['points'],
-                             h['directions'])
+            if h['directions'] is None:         # Receiver accountants only: absorbed energy and hit points
+                feed_accountants(dev.compiled.surfaces, h['surf'], h['e_in'], None, h['points'], None, e_abs=h['e_abs'])
+            else:
+                feed_accountants(dev.compiled.surfaces, h['surf'], h['e_in'], h['e_in'] - h['e_abs'], h['points'], h['directions'])
         self._warn_left(stats.rays_left, stats.energy_left, bundle)
         vertices, directions = N.vstack(last[0:3]), N.vstack(last[3:6])
         # "otherwise only register the last bundle" (tracer_engine.py:288-291): scripts read engine.tree[-1] after tree=False
