@@ -102,6 +102,18 @@ int hc_shade_x(const trc_surface_desc *s, const double *extra, long n, const dou
     return 0;
 }
 
+// sizes of the C-ABI structs as the compiler lays them out (tests/test_abi.py compares the ctypes mirrors)
+long hc_sizeof(int which) {
+    switch (which) {
+    case 0: return (long)sizeof(trc_surface_desc);
+    case 1: return (long)sizeof(trc_rays);
+    case 2: return (long)sizeof(trc_source_desc);
+    case 3: return (long)sizeof(trc_kdtree_desc);
+    case 4: return (long)sizeof(trc_trace_stats);
+    default: return -1;
+    }
+}
+
 int hc_shade(const trc_surface_desc *s, const double *extra, long n, const double *dx, const double *dy, const double *dz,
              const double *e, const double *ref, const double *wl, const double *nx, const double *ny, const double *nz,
              const uint64_t *rid, uint64_t seed, int event, double *odx, double *ody, double *odz, double *oe, double *oref,

@@ -58,6 +58,19 @@ def test_enum_values_match_header():
     assert ctypes.sizeof(_cabi.TraceStats) == 56
 
 
+def test_struct_sizes_match_the_compiler():
+    """the ctypes mirrors of the C-ABI structs have the sizes the header gives them under a C++ compiler (trc_rays grew this round:
+    complex indices, material rows, spectra)"""
+    from tracer_amd import _cabi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(['make', '-s', '-C', root, 'hostcheck'])
+    hc = ctypes.CDLL(os.path.join(root, 'tests', 'hostcheck', 'libtrc_hostcheck.so'))
+    hc.hc_sizeof.restype = ctypes.c_long
+    for which, cls in enumerate((_cabi.SurfaceDesc, _cabi.Rays, _cabi.SourceDesc, _cabi.KdTreeDesc, _cabi.TraceStats)):
+        assert hc.hc_sizeof(which) == ctypes.sizeof(cls), cls.__name__
+    assert ctypes.sizeof(_cabi.Rays) == 16 + 11 * 8 + 3 * 8 + 2 * 8
+
+
 def test_no_gpu_means_loud_failure(lib_path):
     """the product has no CPU path: on a machine without a GPU creating a context raises"""
     import torch
