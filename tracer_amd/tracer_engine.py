@@ -27,6 +27,7 @@ from . import rng
 from .accel_tree import KdTree
 from .ray_bundle import RayBundle, concatenate_rays
 from .scene import compile_scene, DeviceScene, NotNativeError, feed_accountants
+from .optics_callables import OpticsCallable
 from .trace_tree import RayTree
 
 
@@ -247,20 +248,30 @@ class TracerEngine(object):
             prev = None
             prev_surf = None
             last = None
+            acc_table = None
             for lv in range(1, nlev):
                 L = res.level(lv, with_ref_index=True, with_wavelength=has_wl, complex_index=cplx, n_spec=n_spec)
                 if prev is None:
                     prev = dict(energy=N.asarray(bundle.get_energy()), directions=N.asarray(bundle.get_directions()),
                                 wavelengths=bundle.get_wavelengths() if has_wl else None,
                                 spectra=N.asarray(bundle.get_spectra()) if n_spec else None)
-                # accountants: hits of a surface in the order the reference selects them (ascending parent)
+                # accountants: hits of a surface in the order the reference selects them (ascending parent).  Only the hits on
+                # surfaces that have accountants are touched, and they are only sorted when the device's order -- (culled, surface,
+                # block) with ascending parents inside -- is not that order already (no culled rays, one block: the usual case)
                 par = L['parents']
-                order = N.lexsort((par, L['surf']))
-                po = par[order]
-                feed_accountants(dev.compiled.surfaces, L['surf'][order], prev['energy'][po], L['energy'][order],
-                                 L['vertices'][:, order], prev['directions'][:, po],
-                                 None if prev['wavelengths'] is None else prev['wavelengths'][po],
-                                 spectra=None if not n_spec else (prev['spectra'][:, po], L['spectra'][:, order], L['wavelengths'][:, order]))
+                if acc_table is None:
+                    acc_table = N.array([isinstance(sf.get_optics_manager(), OpticsCallable) and len(sf.get_optics_manager().accountants) > 0
+                                         for sf in dev.compiled.surfaces]) if dev.compiled.surfaces is not None else N.zeros(dev.n_surf, dtype=bool)
+                order = N.nonzero(acc_table[L['surf']])[0] if acc_table.any() else N.zeros(0, dtype=int)
+                if len(order):
+                    key = L['surf'][order].astype(N.int64) * (1 << 40) + par[order]
+                    if not (key[1:] >= key[:-1]).all():
+                        order = order[N.argsort(key, kind='stable')]
+                    po = par[order]
+                    feed_accountants(dev.compiled.surfaces, L['surf'][order], prev['energy'][po], L['energy'][order],
+                                     L['vertices'][:, order], prev['directions'][:, po],
+                                     None if prev['wavelengths'] is None else prev['wavelengths'][po],
+                                     spectra=None if not n_spec else (prev['spectra'][:, po], L['spectra'][:, order], L['wavelengths'][:, order]))
                 if self._transfer:
                     ns = dev.n_surf
                     left = N.full(len(prev['energy']), ns) if prev_surf is None else prev_surf
