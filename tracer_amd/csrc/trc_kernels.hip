@@ -1110,6 +1110,13 @@ struct OrdParams {
     PayLayout lay;
 };
 
+struct LocalStack32 {          // pending far children of the single-precision Kd walk (trc_nearest_accel32)
+    uint32_t na[64];
+    float tmax[64];
+    __device__ __forceinline__ void push(int sp, uint32_t n, float t) { na[sp] = n; tmax[sp] = t; }
+    __device__ __forceinline__ void pop(int sp, uint32_t *n, float *t) { *n = na[sp]; *t = tmax[sp]; }
+};
+
 #define ORD_EMPTY 0xFFFFFFFFu
 #define ORD_CULLED_BIT (1u << 30)
 
@@ -1123,7 +1130,16 @@ __global__ __launch_bounds__(256) void k_ord_bounce(OrdParams P) {
     unsigned long long rid = P.rid[i];
     double t;
     int s;
-    if (sc.has_kd && (P.flags & TRC_TRACE_ACCEL)) {
+    const bool use_kd = sc.has_kd && (P.flags & TRC_TRACE_ACCEL);
+    if (sc.a_ok && sc.n_surf <= 65535 && (!use_kd || (sc.a_kd_ok && sc.a_kd_depth <= 64))) {
+        // the conservative single-precision search of the fast engines (boxes of the geometry, packed Kd nodes) in front of the
+        // exact float64 tests: the same nearest hit, the same tie rule (trc_nearest_accel32; tests/hostcheck pins it against
+        // brute force), a fifth of the time of the float64 walk below
+        const trc_accel_view A = stream_accel_global(sc, use_kd ? 1 : 0);
+        LocalStack32 stk;
+        trc_nearest_accel32(A, stk, sc.recs, sc.stride, sc.extra, px, py, pz, dx, dy, dz, use_kd, &t, &s);
+        if (s < 0) t = 0.0;
+    } else if (use_kd) {
         trc_kd_view kd = make_kd_view(sc, sc.kd_a, sc.kd_b, sc.kd_split, sc.kd_leaf, sc.kd_always);
         LocalKdStack stk;
         trc_nearest_kd(kd, stk, sc.recs, sc.stride, sc.extra, px, py, pz, dx, dy, dz, &t, &s);
