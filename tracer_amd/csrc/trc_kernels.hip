@@ -1110,33 +1110,41 @@ struct OrdParams {
     PayLayout lay;
 };
 
-struct LocalStack32 {          // pending far children of the single-precision Kd walk (trc_nearest_accel32)
-    uint32_t na[64];
-    float tmax[64];
-    __device__ __forceinline__ void push(int sp, uint32_t n, float t) { na[sp] = n; tmax[sp] = t; }
-    __device__ __forceinline__ void pop(int sp, uint32_t *n, float *t) { *n = na[sp]; *t = tmax[sp]; }
+// pending far children of the single-precision Kd walk (trc_nearest_accel32), in LDS: entry sp of thread t at [sp * 256 + t].
+// (In private memory the two stacks of this kernel were 576 bytes of scratch per lane -- 300 MB per dispatch, more than the
+// runtime keeps, so every launch allocated and freed it: 7.4 ms per bounce, whatever the number of rays.)
+#define ORD_STACK_DEPTH 24
+struct LdsStack32 {
+    uint32_t *na;
+    float *tmax;
+    __device__ __forceinline__ void push(int sp, uint32_t n, float t) { na[sp * 256] = n; tmax[sp * 256] = t; }
+    __device__ __forceinline__ void pop(int sp, uint32_t *n, float *t) { *n = na[sp * 256]; *t = tmax[sp * 256]; }
 };
 
 #define ORD_EMPTY 0xFFFFFFFFu
 #define ORD_CULLED_BIT (1u << 30)
 
+// FAST: the conservative single-precision search of the fast engines (boxes of the geometry, packed Kd nodes) in front of the exact
+// float64 tests -- the same nearest hit, the same tie rule (trc_nearest_accel32; tests/hostcheck pins it against brute force) --
+// with its stack in LDS; otherwise the float64 walk of the caller's tree / brute force, with a stack in private memory.
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_ord_bounce(OrdParams P) {
+    __shared__ uint32_t s_na[FAST ? ORD_STACK_DEPTH * 256 : 1];
+    __shared__ float s_tm[FAST ? ORD_STACK_DEPTH * 256 : 1];
     const DScene &sc = P.sc;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    // global atomics for tallies here: this engine favours order over speed
-    if (i >= P.n) return;
+    const bool live = i < P.n;              // (no lane leaves early: the tallies below are summed per wave)
+    if (!live) i = 0;
     double px = P.x[i], py = P.y[i], pz = P.z[i], dx = P.dx[i], dy = P.dy[i], dz = P.dz[i], e = P.e[i];
     double ref = P.ref[i], wl = P.wl[i];
     unsigned long long rid = P.rid[i];
     double t;
     int s;
     const bool use_kd = sc.has_kd && (P.flags & TRC_TRACE_ACCEL);
-    if (sc.a_ok && sc.n_surf <= 65535 && (!use_kd || (sc.a_kd_ok && sc.a_kd_depth <= 64))) {
-        // the conservative single-precision search of the fast engines (boxes of the geometry, packed Kd nodes) in front of the
-        // exact float64 tests: the same nearest hit, the same tie rule (trc_nearest_accel32; tests/hostcheck pins it against
-        // brute force), a fifth of the time of the float64 walk below
+    if (FAST) {
         const trc_accel_view A = stream_accel_global(sc, use_kd ? 1 : 0);
-        LocalStack32 stk;
+        LdsStack32 stk;
+        stk.na = s_na + threadIdx.x; stk.tmax = s_tm + threadIdx.x;
         trc_nearest_accel32(A, stk, sc.recs, sc.stride, sc.extra, px, py, pz, dx, dy, dz, use_kd, &t, &s);
         if (s < 0) t = 0.0;
     } else if (use_kd) {
@@ -1146,6 +1154,9 @@ __global__ __launch_bounds__(256) void k_ord_bounce(OrdParams P) {
     } else {
         trc_nearest_brute(sc.recs, sc.stride, sc.n_surf, sc.extra, px, py, pz, dx, dy, dz, &t, &s);
     }
+    if (!live) s = -1;
+    int ts = -1;                // the surface this lane's hit is tallied on, with absorbed and incident energy
+    double tea = 0.0, tei = 0.0;
     uint32_t k0 = ORD_EMPTY, k1 = ORD_EMPTY;
     if (s >= 0) {
         const double *rec = sc.recs + (size_t)s * sc.stride;
@@ -1169,13 +1180,7 @@ __global__ __launch_bounds__(256) void k_ord_bounce(OrdParams P) {
         double e_out = out[0].e + (n_out > 1 ? out[1].e : 0.0);
         const bool volume = out[0].back > 0.0;      // scattered in the medium before the surface: nothing recorded there
         if (volume) { hx -= out[0].back * dx; hy -= out[0].back * dy; hz -= out[0].back * dz; }
-        // tallies (no wave-aggregated capture here: lanes may have exited)
-        const int S = sc.n_surf;
-        if (!volume) {
-            atomicAdd(&sc.tally[s], e - e_out);
-            atomicAdd(&sc.tally[S + s], e);
-            atomicAdd(&sc.tally[2 * S + s], 1.0);
-        }
+        if (!volume) { ts = s; tea = e - e_out; tei = e; }         // (the three sums of the surface: below, per wave)
         int fm = (!volume && sc.fm_of_surf) ? sc.fm_of_surf[s] : -1;
         if (fm >= 0) {
             const FluxMapDev &m = sc.fms[fm];
@@ -1208,8 +1213,28 @@ __global__ __launch_bounds__(256) void k_ord_bounce(OrdParams P) {
             if (c == 0) k0 = k; else k1 = k;
         }
     }
-    P.key[i] = k0;
-    P.key[P.n + i] = k1;
+    {
+        // The three sums per surface: global float64 atomics on one word are served one after the other, and a bounce whose rays
+        // all land on the receiver of a field put 640 000 x 3 of them on three words -- 7.8 ms for a bounce of 6e5 rays.  The
+        // lanes of a wave that share the surface of the first lane still to be served are summed in registers and added once.
+        const int S = sc.n_surf;
+        unsigned long long todo = __ballot(ts >= 0);
+        for (int round = 0; round < 8 && todo; ++round) {
+            const int s0 = __shfl(ts, __ffsll((long long)todo) - 1, 64);
+            const bool in = ts == s0;
+            const unsigned long long m = __ballot(in);
+            if (__popcll(m) < 4) break;
+            const double a = wave_sum(in ? tea : 0.0), b = wave_sum(in ? tei : 0.0);
+            if (lane_id() == 0) { atomicAdd(&sc.tally[s0], a); atomicAdd(&sc.tally[S + s0], b); atomicAdd(&sc.tally[2 * S + s0], (double)__popcll(m)); }
+            if (in) ts = -1;
+            todo &= ~m;
+        }
+        if (ts >= 0) { atomicAdd(&sc.tally[ts], tea); atomicAdd(&sc.tally[S + ts], tei); atomicAdd(&sc.tally[2 * S + ts], 1.0); }
+    }
+    if (live) {
+        P.key[i] = k0;
+        P.key[P.n + i] = k1;
+    }
 }
 
 // ---- order-preserving compaction of the occupied slots: ballot + prefix sum ----
@@ -2623,7 +2648,12 @@ extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_so
             P.pay = cur.pay; P.pay_stride = cur.n_total; P.opay = sx.opay; P.lay = lay;
 
             (void)hipEventRecord(ctx->ev0, ctx->stream);
-            hipLaunchKernelGGL(k_ord_bounce, dim3((unsigned)((n_cur + 255) / 256)), dim3(256), 0, ctx->stream, P);
+            {
+                const bool use_kd = sc->has_kd && (flags & TRC_TRACE_ACCEL);
+                const bool fast = sc->accel_ok && sc->n_surf <= 65535 && (!use_kd || (sc->accel_kd_ok && sc->accel.kd_depth + 2 <= ORD_STACK_DEPTH));
+                if (fast) hipLaunchKernelGGL(k_ord_bounce<true>, dim3((unsigned)((n_cur + 255) / 256)), dim3(256), 0, ctx->stream, P);
+                else hipLaunchKernelGGL(k_ord_bounce<false>, dim3((unsigned)((n_cur + 255) / 256)), dim3(256), 0, ctx->stream, P);
+            }
             hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, sx.key, (long long)slots,
                                sx.blk_cnt, sx.blk_cul);
             hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, ctx->stream, sx.blk_cnt, sx.blk_cul, nblk, sx.blk_off,
