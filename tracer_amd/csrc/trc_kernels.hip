@@ -174,6 +174,8 @@ struct trc_scene {
     bool src_host_ok;
     unsigned long long cnt_host[8];   // host copy of d_counters as trc_trace_fast left them (cnt_host_ok): the next call does not read
     bool cnt_host_ok;                 // them back before it starts.  Every other writer of d_counters updates or drops the copy.
+    double *d_last[7];                // device side of trc_trace_fast's `last` bundle, kept between calls (seven hipMalloc / hipFree per
+    int64_t d_last_cap;               // call were a millisecond of a Monte-Carlo loop's 1e6-ray calls)
     int64_t hit_dirty_to;             // entries [0, hit_dirty_to) of the hit buffer may have been written since it was last emptied: emptying
                                       // 2e8 entries for the 6e6 a trace used was 0.9 GB of memset, twice per call of the public entry point
     int64_t hit_cap;      // entries allocated: the capacity asked for + TRC_HIT_SLACK
@@ -1642,6 +1644,8 @@ extern "C" int trc_scene_create(trc_ctx *ctx, int32_t n_surf, const trc_surface_
     sc->src_host_ok = false;
     sc->cnt_host_ok = false;
     sc->hit_dirty_to = 0;
+    for (int i = 0; i < 7; ++i) sc->d_last[i] = nullptr;
+    sc->d_last_cap = 0;
     memset(sc->cnt_host, 0, sizeof(sc->cnt_host));
     sc->n_surf = n_surf;
     sc->stride = TRC_REC_HDR + max_np;
@@ -1688,6 +1692,7 @@ extern "C" int trc_scene_destroy(trc_scene *sc) {
     dev_free(sc->d_kd_split); dev_free(sc->d_tally); dev_free(sc->d_fm_of_surf); dev_free(sc->d_fms);
     dev_free(sc->d_fm_edges); dev_free(sc->d_counters); dev_free(sc->d_src_buf); dev_free(sc->d_h_surf);
     for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
+    for (int i = 0; i < 7; ++i) dev_free(sc->d_last[i]);
     delete sc;
     return TRC_OK;
 }
@@ -2236,8 +2241,14 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
                 st = trc_fail(TRC_ERR_INVALID, "TRC_TRACE_KEEP_LAST needs a host `last` bundle with x..e"); break;
             }
             last_cap = last->n;
-            for (int i = 0; i < 7 && st == TRC_OK; ++i) st = dev_alloc(&d_last[i], (size_t)last_cap);
-            if (st) break;
+            if (sc->d_last_cap < last_cap) {
+                for (int i = 0; i < 7; ++i) dev_free(sc->d_last[i]);
+                sc->d_last_cap = 0;
+                for (int i = 0; i < 7 && st == TRC_OK; ++i) st = dev_alloc(&sc->d_last[i], (size_t)last_cap);
+                if (st) { for (int i = 0; i < 7; ++i) dev_free(sc->d_last[i]); break; }
+                sc->d_last_cap = last_cap;
+            }
+            for (int i = 0; i < 7; ++i) d_last[i] = sc->d_last[i];
         }
         // counters and the energy left live in one 64-byte block: one read before, one after
         unsigned long long blk_before[8];
@@ -2410,7 +2421,6 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         }
     } while (0);
     dr.release();
-    for (int i = 0; i < 7; ++i) dev_free(d_last[i]);
     if (stats) *stats = s;
     return st;
 }
