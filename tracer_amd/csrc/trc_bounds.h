@@ -127,8 +127,9 @@ struct trc_accel_host {
     std::vector<int32_t> grid_apart;   // bounded surfaces kept out of the grid: their boxes are tested for every ray
     float grid_root[6];                // box of the surfaces in the grid, relative, rounded outwards
     // the same kind of grid without the limits of LDS, for scenes the one above cannot hold (trc_accel_build_grid32):
-    // 32-bit offsets and lists in global memory, every bounded surface in it (none set apart)
+    // 32-bit offsets and lists in global memory; big_apart: the few surfaces kept out of it (as grid_apart)
     bool big_ok;
+    std::vector<int32_t> big_apart;
     int32_t big_dim[3];
     float big_lo[3], big_cs[3], big_inv[3], big_root[6];
     std::vector<uint32_t> big_off, big_list;
@@ -325,14 +326,53 @@ static inline void trc_accel_build_grid(trc_accel_host &A, int n_surf) {
 
 // The grid for scenes that do not fit the one above: same construction (cells of about equal sides, TRC_GRID_DENSITY cells per
 // surface, a surface listed in every cell its box inflated by 2*delta overlaps), at most 2^24 cells and 2^28 list entries, all
-// bounded surfaces (none set apart), 32-bit offsets and lists.  Call after trc_accel_build_surfaces.
+// bounded surfaces but the few set apart (big_apart), 32-bit offsets and lists.  Call after trc_accel_build_surfaces.
 static inline void trc_accel_build_grid32(const trc_surface_desc *, int n_surf, trc_accel_host &A) {
     A.big_ok = false;
-    A.big_off.clear(); A.big_list.clear();
+    A.big_off.clear(); A.big_list.clear(); A.big_apart.clear();
     std::vector<uint32_t> members;
     for (int i = 0; i < n_surf; ++i) {
         const float *b = &A.sbox[6 * (size_t)i];
         if (!(b[3] == INFINITY && b[0] == -INFINITY)) members.push_back((uint32_t)i);
+    }
+    // Surfaces that stand far from the rest -- the lid 50 m above a mesh of 1e5 faces -- would stretch the grid over empty space
+    // and leave hundreds of faces in every cell of the mesh (the 105 800-triangle relief: 280 -> ms per 2e7 rays).  As in
+    // trc_accel_build_grid up to 8 of them are set apart while leaving one out shrinks the box of the others by more than 30 %;
+    // here in linear time: only a surface that holds an extreme of the box on some axis can shrink it, and the box without it
+    // follows from the two smallest lower and two largest upper bounds per axis.
+    while (A.big_apart.size() < 8 && members.size() > 16) {
+        double lo1[3], lo2[3], hi1[3], hi2[3];
+        long ilo[3], ihi[3];
+        for (int k = 0; k < 3; ++k) { lo1[k] = lo2[k] = INFINITY; hi1[k] = hi2[k] = -INFINITY; ilo[k] = ihi[k] = -1; }
+        for (size_t j = 0; j < members.size(); ++j) {
+            const float *b = &A.sbox[6 * (size_t)members[j]];
+            for (int k = 0; k < 3; ++k) {
+                const double l = (double)b[k], h = (double)b[3 + k];
+                if (l < lo1[k]) { lo2[k] = lo1[k]; lo1[k] = l; ilo[k] = (long)j; } else if (l < lo2[k]) lo2[k] = l;
+                if (h > hi1[k]) { hi2[k] = hi1[k]; hi1[k] = h; ihi[k] = (long)j; } else if (h > hi2[k]) hi2[k] = h;
+            }
+        }
+        auto volume = [](const double *blo, const double *bhi) {
+            double e[3], emax = 0.0;
+            for (int k = 0; k < 3; ++k) { e[k] = bhi[k] - blo[k]; emax = std::fmax(emax, e[k]); }
+            double v = 1.0;
+            for (int k = 0; k < 3; ++k) v *= std::fmax(e[k], 1e-3 * emax);
+            return v;
+        };
+        const double v_all = volume(lo1, hi1);
+        long best = -1;
+        double v_best = v_all;
+        for (int c = 0; c < 6; ++c) {
+            const long j = c < 3 ? ilo[c] : ihi[c - 3];
+            if (j < 0) continue;
+            double l2[3], h2[3];
+            for (int k = 0; k < 3; ++k) { l2[k] = (ilo[k] == j) ? lo2[k] : lo1[k]; h2[k] = (ihi[k] == j) ? hi2[k] : hi1[k]; }
+            const double v = volume(l2, h2);
+            if (v < v_best) { v_best = v; best = j; }
+        }
+        if (best < 0 || !(v_best < 0.7 * v_all)) break;
+        A.big_apart.push_back((int32_t)members[(size_t)best]);
+        members.erase(members.begin() + best);
     }
     const size_t nb = members.size();
     if (nb == 0) return;

@@ -111,6 +111,8 @@ struct DScene {
     float a_glo[3], a_gcs[3], a_ginv[3], a_groot[6];
     // the grid of scenes too large for LDS (trc_accel_build_grid32): 32-bit offsets and lists in global memory
     const uint32_t *a_bg_off, *a_bg_list;
+    const int32_t *a_bg_apart;  // bounded surfaces kept out of that grid (box-tested for every ray)
+    int32_t a_bg_napart, a_bg_pad;
     int32_t a_bg_ok, a_bg_dim[3];
     float a_bg_lo[3], a_bg_cs[3], a_bg_inv[3], a_bg_root[6];
     // tallies: [absorbed S | received S | count S | segments, hits | flux bins ... | transfer (S+1) x S]
@@ -155,6 +157,7 @@ struct trc_scene {
     uint16_t *d_a_bleaf;
     uint16_t *d_a_goff, *d_a_glist;
     uint32_t *d_a_bg_off, *d_a_bg_list;
+    int32_t *d_a_bg_apart;
     int32_t *d_a_gapart;
     struct StreamEngine *stream_eng;   // slots of the streaming fast engine (trc_stream.inc), allocated on first use
     double *d_tally;
@@ -1594,8 +1597,8 @@ static int scene_upload_surfaces(trc_scene *sc) {
         HIP_TRY(hipMemcpy(sc->d_a_goff, sc->accel.grid_off.data(), sc->accel.grid_off.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(sc->d_a_glist, sc->accel.grid_list.data(), sc->accel.grid_list.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
-    dev_free(sc->d_a_bg_off); dev_free(sc->d_a_bg_list);
-    sc->d_a_bg_off = nullptr; sc->d_a_bg_list = nullptr;
+    dev_free(sc->d_a_bg_off); dev_free(sc->d_a_bg_list); dev_free(sc->d_a_bg_apart);
+    sc->d_a_bg_off = nullptr; sc->d_a_bg_list = nullptr; sc->d_a_bg_apart = nullptr;
     if (!sc->accel.grid_ok) {      // a scene the LDS-sized grid cannot hold: the 32-bit grid in global memory
         trc_accel_build_grid32(sc->surfs.data(), sc->n_surf, sc->accel);
         if (sc->accel.big_ok) {
@@ -1603,6 +1606,9 @@ static int scene_upload_surfaces(trc_scene *sc) {
             TRC_TRY(dev_alloc(&sc->d_a_bg_list, sc->accel.big_list.size()));
             HIP_TRY(hipMemcpy(sc->d_a_bg_off, sc->accel.big_off.data(), sc->accel.big_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(sc->d_a_bg_list, sc->accel.big_list.data(), sc->accel.big_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            TRC_TRY(dev_alloc(&sc->d_a_bg_apart, sc->accel.big_apart.size() + 1));
+            if (!sc->accel.big_apart.empty())
+                HIP_TRY(hipMemcpy(sc->d_a_bg_apart, sc->accel.big_apart.data(), sc->accel.big_apart.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
     }
     sc->accel_ok = true;
@@ -1688,7 +1694,7 @@ extern "C" int trc_scene_destroy(trc_scene *sc) {
     dev_free(sc->d_recs); dev_free(sc->d_opt); dev_free(sc->d_extra); dev_free(sc->d_sflags);
     dev_free(sc->d_kd_a); dev_free(sc->d_kd_b); dev_free(sc->d_kd_leaf); dev_free(sc->d_kd_always);
     dev_free(sc->d_a_sbox); dev_free(sc->d_a_obb); dev_free(sc->d_a_nodes); dev_free(sc->d_a_leaf); dev_free(sc->d_a_unbounded); dev_free(sc->d_a_bleaf);
-    dev_free(sc->d_a_goff); dev_free(sc->d_a_glist); dev_free(sc->d_a_gapart); dev_free(sc->d_a_bg_off); dev_free(sc->d_a_bg_list);
+    dev_free(sc->d_a_goff); dev_free(sc->d_a_glist); dev_free(sc->d_a_gapart); dev_free(sc->d_a_bg_off); dev_free(sc->d_a_bg_list); dev_free(sc->d_a_bg_apart);
     dev_free(sc->d_kd_split); dev_free(sc->d_tally); dev_free(sc->d_fm_of_surf); dev_free(sc->d_fms);
     dev_free(sc->d_fm_edges); dev_free(sc->d_counters); dev_free(sc->d_src_buf); dev_free(sc->d_h_surf);
     for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
@@ -2112,6 +2118,7 @@ static DScene make_dscene(trc_scene *sc) {
     d.a_delta = sc->accel.delta;
     d.a_goff = sc->d_a_goff; d.a_glist = sc->d_a_glist; d.a_gapart = sc->d_a_gapart;
     d.a_bg_off = sc->d_a_bg_off; d.a_bg_list = sc->d_a_bg_list; d.a_bg_ok = sc->accel.big_ok ? 1 : 0;
+    d.a_bg_apart = sc->d_a_bg_apart; d.a_bg_napart = sc->accel.big_ok ? (int32_t)sc->accel.big_apart.size() : 0;
     for (int i = 0; i < 3; ++i) {
         d.a_bg_dim[i] = sc->accel.big_ok ? sc->accel.big_dim[i] : 1;
         d.a_bg_lo[i] = sc->accel.big_lo[i]; d.a_bg_cs[i] = sc->accel.big_cs[i]; d.a_bg_inv[i] = sc->accel.big_inv[i];
