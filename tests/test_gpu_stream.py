@@ -546,6 +546,8 @@ def test_mesh_of_1e5_triangles(ctx, tmp_path):
     bundle = lambda: sources.buie_sunshape(n, center, direction, 12., 0.05, flux=1., seed=21)
     ref = _trace(ctx, cs, bundle, reps=6)
     assert ref['hits'] > 0.5 * n and ref['h'][nf] > 0.15 * n and ref['segments'] > 1.8 * n
+    # (a mesh that fills the source's view gets no footprint map by default -- it would cull nothing: asking for a resolution forces it)
+    _same(ref, _trace(ctx, cs, bundle, reps=6, TRC_STREAM_FP_CELLS=512), 'footprint map, lists in global memory')
     _same(ref, _trace(ctx, cs, bundle, reps=6, TRC_STREAM_FRESH=0), 'fresh rays through k_s_bounce<FRESH> / the general path')
     _same(ref, _trace(ctx, cs, bundle, reps=6, TRC_STREAM_FIRST=1), 'aureole through k_s_bounce<FRESH>')
     _same(ref, _trace(ctx, cs, bundle, reps=6, TRC_STREAM_FRESH=0, TRC_STREAM_FIRST=1), 'all fresh rays through k_s_bounce<FRESH>')
@@ -565,7 +567,7 @@ def test_mesh_of_1e5_triangles(ctx, tmp_path):
     eng = TracerEngine(asm)
     n = 2000000
     out = {}
-    for key, knobs in (('map', {}), ('per ray', dict(TRC_STREAM_FRESH=0))):
+    for key, knobs in (('map', dict(TRC_STREAM_FP_CELLS=1024)), ('per ray', {})):
         with env(**knobs):
             eng.reset_tallies(); asm.reset_all_optics()
             eng.ray_tracer(sources.buie_sunshape(n, center, direction, 12., 0.05, flux=1., seed=23), reps=6, min_energy=1e-10, tree=False, accel=True, seed=23)
