@@ -46,6 +46,23 @@ class TracerEngine(object):
         self._auto_kd = None
         self.stats = {}
 
+    # -- the Kd-tree of the last accelerated call (tracer_engine.py:171-185) -------------------------------
+    @property
+    def Kd_Tree(self):
+        lazy = getattr(self, '_kd_lazy', None)
+        if lazy is not None:
+            key, max_depth, fast, kw = lazy
+            if self._auto_kd is None or self._auto_kd[0] != key:
+                self._auto_kd = (key, KdTree(self._asm, max_depth, loglevel=self.loglevel, fast=fast, **kw))
+            self._Kd_Tree = self._auto_kd[1]
+            self._kd_lazy = None
+        return getattr(self, '_Kd_Tree', None)
+
+    @Kd_Tree.setter
+    def Kd_Tree(self, value):
+        self._Kd_Tree = value
+        self._kd_lazy = None
+
     # -- device scene management ------------------------------------------------------------------
     def _device_scene(self, unchanged=False):
         if unchanged and self._dev is not None:      # the caller vouches for it (ray_tracer(scene_unchanged=True)): no re-compilation
@@ -168,11 +185,24 @@ class TracerEngine(object):
             logging.log(self.loglevel, 'protocol engine: %s' % err)
             return self._trace_protocol(bundle, reps, min_energy, tree)
 
-        if accel and Kd_Tree is None and dev.n_surf > self.KD_BUILD_MAX and engine in ('auto', 'fast') and not (tree or dev.compiled.splits):
-            # A mesh of 1e5 faces: the reference's SAH build (accel_tree.py:42-204, Python) would take minutes and the fast
-            # engine does not walk it anyway -- it searches its own uniform grid over the same geometry boxes
-            # (csrc/trc_bounds.h).  engine.Kd_Tree stays None.
-            self.Kd_Tree = None
+        if engine == 'auto':
+            # complex refractive indices and spectra travel with the rays of the ordered engine only
+            carries = dev.compiled.carries or (not _pending(bundle) and (bundle.is_polychromatic() or bundle.has_complex_index()))
+            engine = 'ordered' if (tree or dev.compiled.splits or carries) else 'fast'
+        if accel and Kd_Tree is None and engine == 'fast':
+            # The fast engine does not walk the reference's Kd-tree: large calls search the library's own uniform grid over the same
+            # geometry boxes (csrc/trc_bounds.h), small ones test the boxes themselves.  Building the tree -- the reference's SAH
+            # build, Python: 38 ms for the 219 surfaces of the NSTTF field, minutes for a mesh of 1e5 faces -- before every trace
+            # of a scene that moves (a day of sun positions) cost more than the traces.  engine.Kd_Tree builds it when it is read.
+            num_surfs = dev.n_surf
+            kw = dict(kwargs)
+            kw.setdefault('min_leaf', 1)
+            self._Kd_Tree = None
+            self._kd_lazy = None if num_surfs > self.KD_BUILD_MAX else \
+                ((self._dev_sig, accel == 'fast', tuple(sorted(kw.items()))), 8 + 1.3 * N.log(num_surfs), accel == 'fast', kw)
+            if self._kd_on_device is not None:
+                dev.set_kdtree(None)
+                self._kd_on_device = None
         elif accel:
             if Kd_Tree is None:
                 num_surfs = dev.n_surf
@@ -191,10 +221,6 @@ class TracerEngine(object):
                 dev.set_kdtree(self.Kd_Tree)
                 self._kd_on_device = self.Kd_Tree
 
-        if engine == 'auto':
-            # complex refractive indices and spectra travel with the rays of the ordered engine only
-            carries = dev.compiled.carries or (not _pending(bundle) and (bundle.is_polychromatic() or bundle.has_complex_index()))
-            engine = 'ordered' if (tree or dev.compiled.splits or carries) else 'fast'
         if engine == 'fast':
             return self._trace_fast(dev, bundle, reps, min_energy, seed, bool(accel), hit_capacity, fast_kernel, feed, last_capacity)
         if engine == 'ordered':
