@@ -24,14 +24,17 @@ class BoundaryBox(BoundaryShape):
         self._AABB = N.array(aabb)
 
     def update_AABB(self):
-        lo, hi = self._aabb
-        corners = N.ones((4, 8))
-        for k in range(8):
-            corners[0, k] = hi[0] if (k & 1) else lo[0]
-            corners[1, k] = hi[1] if (k & 2) else lo[1]
-            corners[2, k] = hi[2] if (k & 4) else lo[2]
-        glob = N.dot(self._temp_frame, corners)[:3]
-        self._minpoint, self._maxpoint = N.array(AABB(glob))
+        corners = getattr(self, '_corners', None)
+        if corners is None or self._corners_of is not self._aabb:       # the eight corners of the local box, homogeneous: made once
+            lo, hi = self._aabb
+            k = N.arange(8)
+            corners = N.ones((4, 8))
+            corners[0] = N.where(k & 1, hi[0], lo[0])
+            corners[1] = N.where(k & 2, hi[1], lo[1])
+            corners[2] = N.where(k & 4, hi[2], lo[2])
+            self._corners, self._corners_of = corners, self._aabb
+        glob = N.dot(self._temp_frame[:3], corners)
+        self._minpoint, self._maxpoint = glob.min(axis=1), glob.max(axis=1)
         self._AABB = N.array([self._minpoint, self._maxpoint])
 
     def in_bounds(self, bund_vertices):
