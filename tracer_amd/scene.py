@@ -20,6 +20,10 @@ from .optics_callables import OpticsCallable, native_optics_of, LocationAccounta
     AbsorptionAccountant, ReceptionAccountant, ScatteringAccountant, NormalAccountant
 
 
+_DESC_DTYPE = N.dtype([('ints', N.int32, 6), ('frame', N.float64, 12), ('gm', N.float64, 16), ('opt', N.float64, 8)])
+assert _DESC_DTYPE.itemsize == C.sizeof(_cabi.SurfaceDesc)
+
+
 def material_rows(materials, wavelengths):
     """trc_rays.mat: (2K, n), rows 2k, 2k+1 = Re, Im of materials[k].m(wavelengths)"""
     wl = N.asarray(wavelengths, dtype=float)
@@ -42,6 +46,9 @@ class CompiledScene(object):
         if n == 0:
             raise ValueError("the assembly has no surfaces")
         self.descs = (_cabi.SurfaceDesc * n)()
+        # the table is filled row by row into one array laid out like trc_surface_desc (6 int32, then frame 12, gm 16, opt 8 doubles)
+        # and copied over the ctypes array at the end: this runs once per call of ray_tracer, to see whether the scene changed
+        rows = N.zeros(n, dtype=_DESC_DTYPE)
         extra = []
         self.splits = False
         self.carries = False        # optics that read what only rays of the ordered engine carry (complex indices, spectra)
@@ -81,10 +88,16 @@ class CompiledScene(object):
             # "Receiver" classes (absorbed energy + hit points): the device leaves incident energy and direction of their hits out
             if wants_hits and all(type(a) in (AbsorptionAccountant, LocationAccountant) for a in opt.accountants):
                 sflags |= _cabi.SURF_CAPTURE_LEAN
-            fill_desc(self.descs[i], s._temp_frame, gkind, gpar, okind, opar,
-                      flags=sflags, extra_off=off, extra_len=len(ex))
+            row = rows[i]
+            row['ints'] = (gkind, okind, sflags, off, len(ex), 0)
+            row['frame'] = N.asarray(s._temp_frame, dtype=float)[:3].ravel()
+            if len(gpar):
+                row['gm'][:len(gpar)] = gpar
+            if len(opar):
+                row['opt'][:len(opar)] = opar
             if getattr(nat, '_splits', False):
                 self.splits = True
+        C.memmove(self.descs, rows.ctypes.data, n * C.sizeof(_cabi.SurfaceDesc))
         self.extra = _cabi.f64(extra)
         self.n_surf = n
 
