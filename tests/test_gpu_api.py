@@ -19,7 +19,7 @@ from tracer_amd.triangular_face import TriangularFace
 from tracer_amd.paraboloid import Paraboloid, ParabolicDishGM
 from tracer_amd.sphere_surface import HemisphereGM, SphericalGM
 from tracer_amd.cylinder import InfiniteCylinder, FiniteCylinder
-from tracer_amd.spatial_geometry import generate_transform, rotx, translate, general_axis_rotation
+from tracer_amd.spatial_geometry import generate_transform, rotx, roty, translate, general_axis_rotation
 from tracer_amd.tracer_engine import TracerEngine
 from tracer_amd import optics_callables as opt
 from tracer_amd import optics, sources
@@ -264,6 +264,73 @@ def test_homogenizer_first_hits():
     assert N.allclose(d, N.c_[[-1, 0, -1], [1, 0, -1], [0, -1, -1], [0, 1, -1]] / N.sqrt(2))
     assert N.allclose(v, N.c_[[2.5, 0, 8.5], [-2.5, 0, 8.5], [0, 1.5, 9.5], [0, -1.5, 9.5]])
     assert N.allclose(eng.tree[1].get_energy(), 3.6)
+
+
+def test_minidish_upright_and_rotated():
+    """tests/models/test_minidish.py::test_upright/test_rotated: five rays down onto a 90 % dish with a 90 % homogenizer; the
+    two inner rays reach the plate directly (90), the two outer ones off one duct wall (81), the axial ray is taken whole by the
+    plate's back (the upstream test predates that entry: energies and abscissae below are the reference's, run on this scene)"""
+    from tracer_amd.models.tau_minidish import MiniDish
+    pos = N.zeros((3, 5))
+    pos[0] = N.r_[-2:2:5j]
+    pos[2] = 6.
+    dirs = N.zeros((3, 5))
+    dirs[2] = -1.
+    for turn in (N.eye(4), roty(N.pi / 4)):
+        md = MiniDish(5, 5, 0.9, 5.7, .4, 0.7, 0.9)
+        md.set_transform(turn)
+        eng = TracerEngine(md)
+        bund = RayBundle(N.dot(turn[:3, :3], pos), N.dot(turn[:3, :3], dirs), energy=N.ones(5) * 100, ref_index=N.ones(5))
+        eng.ray_tracer(bund, 1776, 0.05)
+        plate = md.get_receiver_surf().get_surfaces()[0]
+        energy, pts = plate.get_optics_manager().get_all_hits()
+        x, y = plate.global_to_local(pts)[:2]
+        assert N.allclose(y, 0)
+        order = N.argsort(energy)
+        assert N.allclose(energy[order], [81., 81., 90., 90., 100.], rtol=0, atol=1e-12)
+        assert N.allclose(N.abs(x[order]), [13 / 120., 13 / 120., 14 / 99., 14 / 99., 0.], rtol=0, atol=1e-9)
+        H, xe, ye = md.histogram_hits(bins=4)
+        assert H.shape == (4, 4) and abs(H.sum() - 442.) < 1e-9 and N.allclose(xe, N.r_[-.2:.2:5j])
+
+
+def test_sg4_zones_and_petal_under_a_parallel_beam():
+    """models/SG4.py:14-61 (two nested zones, the inner one met first) and models/PETAL_dish.py:12-50 (hexagonal aperture)
+    under 2e5 axial rays: which zone a ray meets, the absorbed share, the perfect focus of the zone without slope error"""
+    from tracer_amd.models.SG4 import SG4
+    from tracer_amd.models.PETAL_dish import PETAL
+    n = 200000
+    g = N.random.default_rng(11)
+    r, th = 12.5 * N.sqrt(g.random(n)), 2 * N.pi * g.random(n)
+    pos = N.vstack((r * N.cos(th), r * N.sin(th), N.full(n, 20.)))
+    dish = SG4(25., 13.4, 0.05, 0., dishDiameter_in=20., sigma_in=0.)
+    eng = TracerEngine(dish)
+    v, d = eng.ray_tracer(RayBundle(pos, N.tile(N.c_[[0., 0., -1.]], (1, n)), energy=N.ones(n), ref_index=N.ones(n)), 1, 1e-9,
+                          seed=3)
+    hits, absorbed = dish.get_all_hits()
+    assert hits.shape == (3, n) and abs(dish.total_abs - n * dish.absDish) < 1e-6 * n
+    outer, inner = [s.get_optics_manager().get_all_hits()[1] for s in dish.get_surfaces()]
+    assert outer.shape[1] == (r > 10.).sum() and inner.shape[1] == (r <= 10.).sum()
+    assert N.all(N.hypot(outer[0], outer[1]) > 10.) and N.all(N.hypot(inner[0], inner[1]) <= 10.)
+    assert N.allclose(inner[2], (inner[0] ** 2 + inner[1] ** 2) / (4 * 13.4) + 0.0001)
+    # no slope error: every reflected ray goes through the focus of its zone (the inner one is 0.1 mm higher)
+    t = -(v[0] * d[0] + v[1] * d[1]) / N.maximum(d[0] ** 2 + d[1] ** 2, 1e-300)          # closest approach to the axis
+    z_axis = v[2] + t * d[2]
+    off_axis = N.hypot(v[0], v[1]) > 0.5
+    lifted = N.hypot(v[0], v[1]) <= 10.
+    assert N.allclose(z_axis[off_axis & ~lifted], 13.4, atol=1e-9) and N.allclose(z_axis[off_axis & lifted], 13.4001, atol=1e-9)
+
+    petal = PETAL(5., 5., 0.9, 5.7, .4, 0.7, 0.9)
+    m = 50000
+    p2 = N.vstack((g.uniform(-2.5, 2.5, m), g.uniform(-2.5, 2.5, m), N.full(m, 6.)))
+    eng = TracerEngine(petal)
+    eng.ray_tracer(RayBundle(p2, N.tile(N.c_[[0., 0., -1.]], (1, m)), energy=N.ones(m), ref_index=N.ones(m)), 1, 1e-9, tree=True)
+    on_dish = eng.tree[1].get_parents()[eng.tree[1].get_energy() == 0.9]
+    # a regular hexagon of circumradius 2.5 with two vertices on the y axis (paraboloid.py:213-216)
+    x, y = N.abs(p2[0, on_dish]), N.abs(p2[1, on_dish])
+    assert N.all(x <= 2.5 * N.sqrt(3) / 2 + 1e-12) and N.all(y <= 2.5 - x / N.sqrt(3) + 1e-9)
+    shadow = (N.abs(p2[0]) <= .2) & (N.abs(p2[1]) <= .2)                                    # the receiver's back is met first
+    inside = (N.abs(p2[0]) <= 2.5 * N.sqrt(3) / 2) & (N.abs(p2[1]) <= 2.5 - N.abs(p2[0]) / N.sqrt(3))
+    assert abs(on_dish.size - (inside & ~shadow).sum()) <= 0.002 * m                        # duct walls shade a sliver more
 
 
 def test_spherical_lens_imaging():

@@ -160,6 +160,42 @@ def test_radial_stagger_positions():
     assert N.allclose(N.sqrt(N.sum(pos ** 2, axis=1)), N.r_[5, 5, 7, 7, 9, 9, 6, 8])
 
 
+def test_homogenized_receiver_dishes_layout():
+    """models/homogenized_local_receiver.py:14-46, tau_minidish.py:22-103, PETAL_dish.py:12-50, SG4.py:14-43: what the
+    constructors build (values taken from the reference's own instances of the same arguments)"""
+    from tracer_amd import _cabi
+    from tracer_amd.models.tau_minidish import MiniDish, standard_minidish, standard_minidish_measures
+    from tracer_amd.models.PETAL_dish import PETAL
+    from tracer_amd.models.SG4 import SG4
+    md = MiniDish(5, 5, 0.9, 5.7, .4, 0.7, 0.9, 1.5)
+    surfs = md.get_surfaces()
+    kinds = [s.get_geometry_manager()._native()[0] for s in surfs]
+    assert kinds == [_cabi.GM_RECT] * 5 + [_cabi.GM_PARAB_DISH]            # four duct walls, the receiver plate, the dish
+    assert [type(s.get_optics_manager()).__name__ for s in surfs] == \
+        ['OneSidedRealReflectiveDetector'] * 4 + ['OneSidedReflectiveReceiver', 'Reflective']
+    rec = md.get_receiver_surf().get_surfaces()[0]
+    assert rec is surfs[4] and md.get_main_reflector() is surfs[5] and len(md.get_homogenizer().get_surfaces()) == 4
+    assert N.allclose(rec._temp_frame, [[1, 0, 0, 0], [0, -1, 0, 0], [0, 0, -1, 5.7], [0, 0, 0, 1]])       # looking down the axis
+    # the duct stands on the plate and opens towards the dish: walls centred 0.35 below the plate, at x = +-0.2 and y = -+0.3
+    centres = N.array([s._temp_frame[:3, 3] for s in surfs[:4]])
+    assert N.allclose(centres, [[0.2, 0, 5.35], [-0.2, 0, 5.35], [0, -0.3, 5.35], [0, 0.3, 5.35]])
+    inward = N.array([s._temp_frame[:3, 2] for s in surfs[:4]])                  # each wall's mirrored side faces the axis
+    assert N.allclose(inward, [[-1, 0, 0], [1, 0, 0], [0, 1, 0], [0, -1, 0]])
+    assert md.get_external_dimensions() == (5, 5.7)
+    md.set_transform(roty(N.pi / 4))                                            # the whole collector turns as one
+    assert N.allclose(rec._temp_frame[:3, 3], 5.7 * N.r_[N.sin(N.pi / 4), 0, N.cos(N.pi / 4)])
+    assert N.allclose(standard_minidish_measures(1., 500., 1), (0.6035533905932736, 0.03963327297606011, 0.05196030660088499))
+    dish, f, W, H = standard_minidish(1., 500., 1)
+    assert dish.get_external_dimensions() == (1., f + H)
+    petal = PETAL(5, 5, 0.9, 5.7, .4, 0.7, 0.9, 2.)
+    assert petal.get_surfaces()[5].get_geometry_manager()._native()[0] == _cabi.GM_PARAB_HEX
+    sg4 = SG4(25., 13.4, 0.05, 2e-3)
+    assert abs(sg4.absDish - 0.05362651118924833) < 1e-15
+    zones = sg4.get_surfaces()
+    assert len(zones) == 2 and zones[0]._temp_frame[2, 3] == 0. and zones[1]._temp_frame[2, 3] == 0.0001
+    assert [type(s.get_optics_manager()).__name__ for s in zones] == ['RealReflectiveReceiver'] * 2
+
+
 def test_spherical_lens_focal_lengths_and_layout():
     """tests/models/test_spherical_lens.py::*::test_focal_length (lensmaker equation, exact) + the surfaces created"""
     from tracer_amd.models.spherical_lens import SphericalLens

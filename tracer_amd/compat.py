@@ -12,7 +12,8 @@ _MODULES = ['assembly', 'object', 'surface', 'has_frame', 'geometry_manager', 'f
             'optics', 'optics_callables', 'ray_bundle', 'trace_tree', 'tracer_engine', 'sources',
             'spatial_geometry', 'boundary_shape', 'accel_tree', 'polygon', 'tracer_engine_mp', 'models',
             'models.one_sided_mirror', 'models.heliostat_field', 'models.homogenizer', 'models.spherical_lens',
-            'models.triangulated_surface']
+            'models.triangulated_surface', 'models.homogenized_local_receiver', 'models.tau_minidish', 'models.PETAL_dish',
+            'models.SG4']
 
 
 def install(force=False):

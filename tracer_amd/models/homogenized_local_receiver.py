@@ -1,0 +1,58 @@
+"""
+A concentrator with a rectangular homogenizer duct in front of a flat receiver.  The plate sits on the optical axis
+(+z of the main reflector) at `receiver_pos`, turned over to look back at the reflector; the duct stands on it and opens
+towards the reflector.  Class, arguments and accessors are those of the reference's
+tracer/models/homogenized_local_receiver.py:14-83, which tau_minidish.MiniDish and PETAL_dish.PETAL derive from.
+"""
+import numpy as N
+
+from ..assembly import Assembly
+from ..object import AssembledObject
+from ..spatial_geometry import generate_transform
+from .homogenizer import rect_homogenizer
+from .one_sided_mirror import one_sided_receiver
+
+
+def _as_pair(dims):
+    return tuple(dims) if isinstance(dims, tuple) else (dims, dims)
+
+
+class HomogenizedLocalReceiver(Assembly):
+    def __init__(self, main_reflector, receiver_pos, receiver_dims, homogenizer_depth, homog_opt_eff):
+        """
+        main_reflector: the Surface concentrating light towards the receiver.  receiver_pos: axial distance from the
+        reflector's vertex to the plate.  receiver_dims: side of a square plate, or the tuple (x side, y side).
+        homogenizer_depth, homog_opt_eff: length of the duct and reflectivity of its four walls.
+        """
+        lx, ly = self._sides = _as_pair(receiver_dims)
+        self._rec_pos = receiver_pos
+        self._mr = main_reflector
+        # half a turn about x, then up the axis: both parts are modelled looking up (+z) and mounted looking down
+        mount = generate_transform(N.r_[1., 0., 0.], N.pi, N.c_[[0., 0., receiver_pos]])
+        self._rec = one_sided_receiver(lx, ly)
+        self._hom = rect_homogenizer(lx, ly, homogenizer_depth, homog_opt_eff)
+        for part in (self._rec, self._hom):
+            part.set_transform(mount)
+        Assembly.__init__(self, objects=[self._rec, AssembledObject(surfs=[main_reflector])], subassemblies=[self._hom])
+
+    def get_receiver_surf(self):
+        """the receiver (an object of one surface, which holds the hits)"""
+        return self._rec
+
+    def get_homogenizer(self):
+        """the duct: an assembly of four one-sided mirrors"""
+        return self._hom
+
+    def get_main_reflector(self):
+        return self._mr
+
+    def histogram_hits(self, bins=50):
+        """
+        Energy absorbed on the plate during the traces run so far, binned over the plate: (H, x edges, y edges) in the
+        convention of numpy.histogram2d, x along the first axis of H, `bins` cells each way.
+        """
+        plate, = self._rec.get_surfaces()
+        absorbed, where = plate.get_optics_manager().get_all_hits()[:2]
+        local = plate.global_to_local(where)
+        extent = [(-side / 2., side / 2.) for side in self._sides]
+        return N.histogram2d(local[0], local[1], bins, range=extent, weights=absorbed)
