@@ -234,6 +234,61 @@ def test_models_and_compat_script():
     assert N.allclose(det[0], [0.1, 1.]) and det[1].shape == (3, 2) and det[2].shape == (3, 2)
 
 
+def test_accel_example_scene_through_tracer_names():
+    """examples/accel_tree_example.py:20-98 restated call for call on the aliased `tracer.*` names: 1000 Lambertian plates in ten
+    layers over two slabs, every object with a BoundaryBox given before it is moved, the Coin3D star import, a single Surface
+    passed positionally, `engine._asm`, `reset_all_optics`, and the three spellings of the acceleration keyword -- which give
+    the same absorbed power surface by surface from one seed"""
+    import logging
+    import tracer_amd.compat as compat
+    compat.install(force=True)
+    from tracer.assembly import Assembly as TAssembly
+    from tracer.object import AssembledObject as TObject
+    from tracer.surface import Surface as TSurface
+    from tracer.flat_surface import RectPlateGM as TRect
+    from tracer.boundary_shape import BoundaryBox
+    from tracer.optics_callables import LambertianReceiver
+    from tracer.CoIn_rendering.rendering import Renderer                      # scripts import it; only instantiating it raises
+    from tracer.tracer_engine import TracerEngine as TEngine
+    from tracer.sources import oblique_solar_rect_bundle
+    n = 10
+    side = n + 1.
+    objects = []
+    for z in (-1., None):
+        slab = TObject(TSurface(geometry=TRect(side, side), optics=LambertianReceiver(0.6)),
+                       bounds=BoundaryBox([[-side / 2., -side / 2., 0.], [side / 2., side / 2., 0.]]))
+        if z is not None:
+            slab.set_location(N.array([0., 0., z]))
+        objects.append(slab)
+    for k in range(n):
+        for i in range(n):
+            for j in range(n):
+                plate = TObject(TSurface(geometry=TRect(.8, .8), optics=LambertianReceiver(0.9)),
+                                bounds=BoundaryBox([[-.4, -.4, 0.], [.4, .4, 0.]]))
+                plate.set_location(N.array([i + 0.5 - n / 2., j + 0.5 - n / 2., k + 1.]))
+                objects.append(plate)
+    assembly = TAssembly(objects=objects)
+    engine = TEngine(assembly, loglevel=logging.INFO)
+    assert len(engine._asm.get_surfaces()) == 1002
+    per_surface = {}
+    for accel in ('lightweight', True, None):
+        assembly.reset_all_optics()
+        source = oblique_solar_rect_bundle(num_rays=200000, center=N.vstack([0, 0, n + 1]), source_direction=N.hstack([0, 0, -1]),
+                                           rays_direction=N.hstack([0, 0, -1]), x=side, y=side, ang_range=4.65e-3, flux=1000., seed=7)
+        if accel is None:
+            engine.ray_tracer(source, seed=7)
+        else:
+            engine.ray_tracer(source, accel=accel, seed=7)
+        per_surface[accel] = N.array([N.sum(s.get_optics_manager().get_all_hits()[0]) for s in engine._asm.get_surfaces()])
+    total = per_surface[None].sum()
+    assert 0.85 * 121000. < total < 0.89 * 121000.                           # the rest leaves between the plates and over the rim
+    top = per_surface[None][2 + 900:]                                          # the layer the sun sees first takes 0.9 x 0.64 of it
+    assert abs(top.sum() - 0.9 * 0.64 * 100 * 1000.) < 0.02 * 57600. + 0.1 * (total - 57600.)
+    assert N.array_equal(per_surface['lightweight'], per_surface[None]) and N.array_equal(per_surface[True], per_surface[None])
+    with pytest.raises(NotImplementedError):
+        Renderer(engine)
+
+
 def test_cut_sphere_gm():
     """tests/test_cut_sphere.py: a sphere of radius 2 trimmed to its bottom part by a bounding sphere"""
     from tracer_amd.sphere_surface import CutSphereGM

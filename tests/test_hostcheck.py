@@ -266,6 +266,75 @@ def test_core_kd_traversal_equals_brute_force(hc):
     assert N.array_equal(front, sb[:20000])
 
 
+def test_kd32_walk_with_origins_on_split_planes(hc):
+    """
+    The single-precision Kd walk when a ray starts within delta of a split plane (both children are then walked with the full
+    interval): rays leaving a stack of plates from points on the lines where plates end -- the planes the tree splits at --
+    find the brute-force (t, surface).  The scene is the one of examples/accel_tree_example.py:20-53; an early version of the walk
+    stopped at the first pending child behind the best hit and lost the other child of such a node (3 rays in 4e5 on this scene).
+    """
+    from tracer_amd import _cabi
+    from tracer_amd.accel_tree import KdTree
+    from tracer_amd.scene import compile_scene
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM
+    from tracer_amd.boundary_shape import BoundaryBox
+    from tracer_amd.optics_callables import LambertianReceiver
+    n = 10
+    side = n + 1.
+    objects = []
+    for z in (-1., 0.):
+        slab = AssembledObject(Surface(geometry=RectPlateGM(side, side), optics=LambertianReceiver(0.6)),
+                               bounds=BoundaryBox([[-side / 2., -side / 2., 0.], [side / 2., side / 2., 0.]]))
+        slab.set_location(N.array([0., 0., z]))
+        objects.append(slab)
+    for k in range(n):
+        for i in range(n):
+            for j in range(n):
+                plate = AssembledObject(Surface(geometry=RectPlateGM(.8, .8), optics=LambertianReceiver(0.9)),
+                                        bounds=BoundaryBox([[-.4, -.4, 0.], [.4, .4, 0.]]))
+                plate.set_location(N.array([i + 0.5 - n / 2., j + 0.5 - n / 2., k + 1.]))
+                objects.append(plate)
+    asm = Assembly(objects=objects)
+    cs = compile_scene(asm)
+    f = KdTree(asm, 8 + 1.3 * N.log(cs.n_surf), min_leaf=1).flat()
+    d = _cabi.KdTreeDesc()
+    d.n_nodes, d.n_leaf_surfs, d.n_always = len(f['flag']), len(f['leaf_surfs']), len(f['always_relevant'])
+    i32 = C.POINTER(C.c_int32)
+    d.flag, d.child, d.leaf_off, d.leaf_cnt = [f[k].ctypes.data_as(i32) for k in ('flag', 'child', 'leaf_off', 'leaf_cnt')]
+    d.leaf_surfs, d.always_relevant = f['leaf_surfs'].ctypes.data_as(i32), f['always_relevant'].ctypes.data_as(i32)
+    d.split = _p(f['split'])
+    for k in range(6):
+        d.bounds[k] = f['bounds'][k]
+    rng = N.random.RandomState(4)
+    m = 300000
+    # one coordinate within 1.5e-3 of a plate edge (delta is 1e-3 here), the start on a plate layer, cosine-law directions up or down
+    edge = rng.randint(-5, 5, m) + rng.choice([0.1, 0.9], m) + rng.uniform(-1.5e-3, 1.5e-3, m)
+    other = rng.uniform(-5.5, 5.5, m)
+    on_x = rng.uniform(size=m) < 0.5
+    v = N.ascontiguousarray(N.vstack((N.where(on_x, edge, other), N.where(on_x, other, edge), rng.randint(0, 11, m).astype(float))))
+    th, ph = N.arcsin(N.sqrt(rng.uniform(0, 1, m))), rng.uniform(0, 2 * N.pi, m)
+    dr = N.ascontiguousarray(N.vstack((N.sin(th) * N.cos(ph), N.sin(th) * N.sin(ph), rng.choice([-1., 1.], m) * N.cos(th))))
+    tb, tk = N.empty(m), N.empty(m)
+    sb, sk = N.empty(m, dtype=N.int32), N.empty(m, dtype=N.int32)
+    extra = N.zeros(1)
+    hc.hc_nearest(cs.n_surf, cs.descs, _p(extra), C.byref(d), C.c_long(m), _p(v[0]), _p(v[1]), _p(v[2]), _p(dr[0]), _p(dr[1]), _p(dr[2]),
+                  _p(tb), _p(sb, C.c_int32), _p(tk), _p(sk, C.c_int32))
+    assert (sb >= 0).sum() > m // 2 and N.array_equal(sb, sk) and N.array_equal(tb, tk)
+    for use_kd in (True, False):
+        t32, s32 = N.empty(m), N.empty(m, dtype=N.int32)
+        rc = hc.hc_nearest32(cs.n_surf, cs.descs, _p(extra), C.byref(d) if use_kd else None, C.c_long(m), _p(v[0]), _p(v[1]), _p(v[2]),
+                             _p(dr[0]), _p(dr[1]), _p(dr[2]), _p(t32), _p(s32, C.c_int32))
+        assert rc == 0
+        assert N.array_equal(s32, sb) and N.array_equal(t32, tb), use_kd
+    t32, s32, st = N.empty(m), N.empty(m, dtype=N.int32), N.zeros(8)
+    rc = hc.hc_nearest_grid(cs.n_surf, cs.descs, _p(extra), C.c_long(m), _p(v[0]), _p(v[1]), _p(v[2]), _p(dr[0]), _p(dr[1]), _p(dr[2]),
+                            _p(t32), _p(s32, C.c_int32), _p(st))
+    assert rc == 0 and N.array_equal(s32, sb) and N.array_equal(t32, tb)
+
+
 def _fp(hc, cs, desc, n, M=512, seed=77, offset=0):
     out = N.zeros(10)
     why = C.create_string_buffer(128)

@@ -910,18 +910,27 @@ TRC_HD void trc_nearest_accel32(const trc_accel_view &A, Stack &stk, const doubl
                             int s = A.leaf_surfs[off + k];
                             if (trc_box_hit32(A.sbox + 6 * (size_t)s, r)) TRC_TEST_EXACT(s);
                         }
-                        if (sp == 0) break;
-                        --sp;
-                        uint32_t na;
-                        float tmax_far;
-                        stk.pop(sp, &na, &tmax_far);
-                        node = na >> 2;
-                        tmin = trc_kd32_pop_tmin(na & 3u, r, A.delta, tmax);
-                        tmax = tmax_far;
-                        if (sb >= 0) {
-                            float tbr = (float)(tb - t0);
-                            if (tbr < tmin - (1e-3f + 1e-5f * fabsf(tbr))) break;   // everything left starts behind the best hit
+                        // Next pending child.  One whose interval starts behind the best hit is passed over, not taken as the
+                        // end of the walk: below it on the stack there may be the other child of a node whose plane lies within
+                        // delta of the origin (code 3), and that one starts at the origin.  Passing over keeps the chain of
+                        // interval ends that the next pop starts from.
+                        bool pending = false;
+                        while (sp > 0) {
+                            --sp;
+                            uint32_t na;
+                            float tmax_far;
+                            stk.pop(sp, &na, &tmax_far);
+                            node = na >> 2;
+                            tmin = trc_kd32_pop_tmin(na & 3u, r, A.delta, tmax);
+                            tmax = tmax_far;
+                            if (sb >= 0) {
+                                float tbr = (float)(tb - t0);
+                                if (tbr < tmin - (1e-3f + 1e-5f * fabsf(tbr))) continue;
+                            }
+                            pending = true;
+                            break;
                         }
+                        if (!pending) break;
                     }
                 }
             }
