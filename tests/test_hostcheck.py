@@ -335,6 +335,108 @@ def test_kd32_walk_with_origins_on_split_planes(hc):
     assert rc == 0 and N.array_equal(s32, sb) and N.array_equal(t32, tb)
 
 
+def _kd_desc(asm, n_surf):
+    from tracer_amd import _cabi
+    from tracer_amd.accel_tree import KdTree
+    f = KdTree(asm, 8 + 1.3 * N.log(n_surf), min_leaf=1).flat()
+    d = _cabi.KdTreeDesc()
+    d.n_nodes, d.n_leaf_surfs, d.n_always = len(f['flag']), len(f['leaf_surfs']), len(f['always_relevant'])
+    i32 = C.POINTER(C.c_int32)
+    d.flag, d.child, d.leaf_off, d.leaf_cnt = [f[k].ctypes.data_as(i32) for k in ('flag', 'child', 'leaf_off', 'leaf_cnt')]
+    d.leaf_surfs, d.always_relevant = f['leaf_surfs'].ctypes.data_as(i32), f['always_relevant'].ctypes.data_as(i32)
+    d.split = _p(f['split'])
+    for k in range(6):
+        d.bounds[k] = f['bounds'][k]
+    return d, f                   # f keeps the arrays alive
+
+
+def test_nearest_hit_searches_on_random_scenes(hc):
+    """
+    Every candidate search of the engines -- the float64 Kd walk, the single-precision walk with and without the tree, the uniform
+    grid with its DDA -- against brute force on scenes of 120 plates, discs, spheres, hemispheres, cylinders and dishes thrown
+    into a cube: once turned at random, once on integer positions with quarter turns (coincident planes, faces in cell and split
+    planes), with axis-parallel rays and rays that start on those planes; then again for rays that leave the points just hit.
+    """
+    from tracer_amd.scene import compile_scene
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM, RoundPlateGM
+    from tracer_amd.sphere_surface import SphericalGM, HemisphereGM
+    from tracer_amd.cylinder import FiniteCylinder
+    from tracer_amd.paraboloid import ParabolicDishGM
+    from tracer_amd.boundary_shape import BoundaryBox
+    from tracer_amd.optics_callables import Reflective
+    from tracer_amd.spatial_geometry import generate_transform
+
+    def scene(rng, aligned):
+        objs = []
+        for _ in range(120):
+            kind, s = rng.randint(0, 6), rng.uniform(0.2, 1.5)
+            if kind == 0:
+                gm, lo, hi = RectPlateGM(2 * s, s), [-s, -s / 2, 0], [s, s / 2, 0]
+            elif kind == 1:
+                gm, lo, hi = RoundPlateGM(s), [-s, -s, 0], [s, s, 0]
+            elif kind == 2:
+                gm, lo, hi = SphericalGM(s), [-s, -s, -s], [s, s, s]
+            elif kind == 3:
+                gm, lo, hi = HemisphereGM(s), [-s, -s, -s], [s, s, 0]
+            elif kind == 4:
+                gm, lo, hi = FiniteCylinder(2 * s, 3 * s), [-s, -s, -1.5 * s], [s, s, 1.5 * s]
+            else:
+                f = rng.uniform(0.5, 2.)
+                gm, lo, hi = ParabolicDishGM(2 * s, f), [-s, -s, 0], [s, s, s * s / (4 * f)]
+            o = AssembledObject(Surface(gm, Reflective(0.1)), bounds=BoundaryBox([lo, hi]))
+            loc = rng.uniform(-6., 6., 3)
+            if aligned:
+                o.set_transform(generate_transform(N.r_[1., 0, 0], rng.choice([0., N.pi / 2, N.pi]), N.round(loc)[:, None]))
+            else:
+                ax = rng.normal(size=3)
+                o.set_transform(generate_transform(ax / N.linalg.norm(ax), rng.uniform(0, 2 * N.pi), loc[:, None]))
+            objs.append(o)
+        return Assembly(objects=objs)
+
+    def searches(cs, d, v, dr):
+        m = v.shape[1]
+        extra = N.ascontiguousarray(cs.extra if len(cs.extra) else N.zeros(1))
+        rays = (C.c_long(m), _p(v[0]), _p(v[1]), _p(v[2]), _p(dr[0]), _p(dr[1]), _p(dr[2]))
+        tb, tk, sb, sk = N.empty(m), N.empty(m), N.empty(m, dtype=N.int32), N.empty(m, dtype=N.int32)
+        assert hc.hc_nearest(cs.n_surf, cs.descs, _p(extra), C.byref(d), *rays, _p(tb), _p(sb, C.c_int32), _p(tk), _p(sk, C.c_int32)) == 0
+        got = {'float64 Kd walk': (sk, tk)}
+        for use_kd in (True, False):
+            t32, s32 = N.empty(m), N.empty(m, dtype=N.int32)
+            assert hc.hc_nearest32(cs.n_surf, cs.descs, _p(extra), C.byref(d) if use_kd else None, *rays, _p(t32), _p(s32, C.c_int32)) == 0
+            got['float32 walk, tree %s' % use_kd] = (s32, t32)
+        t32, s32, st = N.empty(m), N.empty(m, dtype=N.int32), N.zeros(8)
+        assert hc.hc_nearest_grid(cs.n_surf, cs.descs, _p(extra), *rays, _p(t32), _p(s32, C.c_int32), _p(st)) == 0
+        got['grid'] = (s32, t32)
+        for name, (s_, t_) in got.items():
+            assert N.array_equal(s_, sb), name
+            assert N.array_equal(t_[sb >= 0], tb[sb >= 0]), name
+        return sb, tb
+
+    for aligned in (False, True):
+        rng = N.random.RandomState(31 + aligned)
+        asm = scene(rng, aligned)
+        cs = compile_scene(asm)
+        d, keep = _kd_desc(asm, cs.n_surf)
+        m = 40000
+        v = N.ascontiguousarray(rng.uniform(-8, 8, (3, m)))
+        dr = rng.normal(size=(3, m))
+        dr /= N.sqrt((dr ** 2).sum(axis=0))
+        if aligned:
+            dr[:, :m // 10] = N.eye(3)[:, rng.randint(0, 3, m // 10)] * rng.choice([-1., 1.], m // 10)
+            v[:, m // 10: m // 5] = N.round(v[:, m // 10: m // 5])
+        dr = N.ascontiguousarray(dr)
+        sb, tb = searches(cs, d, v, dr)
+        hit = sb >= 0
+        assert hit.sum() > m // 5
+        v2 = N.ascontiguousarray(v[:, hit] + tb[hit] * dr[:, hit])
+        d2 = rng.normal(size=v2.shape)
+        sb2, _ = searches(cs, d, v2, N.ascontiguousarray(d2 / N.sqrt((d2 ** 2).sum(axis=0))))
+        assert (sb2 >= 0).sum() > hit.sum() // 3
+
+
 def _fp(hc, cs, desc, n, M=512, seed=77, offset=0):
     out = N.zeros(10)
     why = C.create_string_buffer(128)
