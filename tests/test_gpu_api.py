@@ -287,6 +287,22 @@ def test_accel_example_scene_through_tracer_names():
     assert N.array_equal(per_surface['lightweight'], per_surface[None]) and N.array_equal(per_surface[True], per_surface[None])
     with pytest.raises(NotImplementedError):
         Renderer(engine)
+    # the same scene without a recorded tree (fast engine): both of its forms, with and without the Kd-tree, end every ray alike
+    tallies = {}
+    for form in ('megakernel', 'stream'):
+        for accel in (False, True):
+            assembly.reset_all_optics()
+            engine.reset_tallies()
+            source = oblique_solar_rect_bundle(num_rays=200000, center=N.vstack([0, 0, n + 1]), source_direction=N.hstack([0, 0, -1]),
+                                               rays_direction=N.hstack([0, 0, -1]), x=side, y=side, ang_range=4.65e-3, flux=1000., seed=7)
+            engine.ray_tracer(source, accel=accel, seed=7, tree=False, fast_kernel=form)
+            assert engine.stats['engine'] == 'fast'
+            tallies[form, accel] = engine.get_tallies()
+    a0, r0, h0 = tallies['megakernel', False]
+    assert h0.sum() > 250000 and abs(a0.sum() - total) < 0.01 * total
+    for key, (a1, r1, h1) in tallies.items():
+        assert N.array_equal(h1, h0), key
+        assert N.allclose(a1, a0, rtol=1e-9, atol=1e-9), key
 
 
 def test_cut_sphere_gm():
