@@ -24,6 +24,10 @@
 #include <string>
 #include <vector>
 #include <new>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <utility>
 
 #include "trc_core.h"
 #include "trc_bounds.h"
@@ -205,6 +209,7 @@ struct Level {
     int64_t *parent;
     int32_t *surf;
     double *pay;
+    char *slab;       // the one allocation the columns above are carved from
 };
 
 struct trc_result {
@@ -213,18 +218,110 @@ struct trc_result {
     PayLayout lay;
 };
 
+// Device memory.  A freed block is kept for the next request of its size class instead of going back to the driver: scripts build an
+// engine per run, and an ordered trace of 1e5 rays spent 3 of its 10 ms in hipMalloc / hipFree (a block of a few MB costs ~0.3 ms to
+// map and as much to release).  Size classes are an eighth of an octave apart (at most 12.5 % over the request); at most POOL_KEEP
+// bytes wait idle, blocks beyond POOL_BLOCK_MAX (the hit buffers of 1e8-ray runs) are never kept, and a failed hipMalloc empties the
+// pool and tries again.  Keeping a block waits for the device as hipFree would have.  TRC_DEV_POOL=0 turns the pool off.
+struct DevPool {
+    std::mutex mu;
+    std::unordered_map<void *, std::pair<size_t, int>> live;      // block handed out -> (bytes allocated, device)
+    std::multimap<std::pair<int, size_t>, void *> idle;           // (device, bytes) -> block waiting
+    size_t idle_bytes = 0;
+    int enabled = -1;
+};
+static DevPool g_pool;
+static const size_t POOL_KEEP = (size_t)4 << 30;
+static const size_t POOL_BLOCK_MAX = (size_t)2 << 30;
+
+static bool pool_enabled() {
+    if (g_pool.enabled < 0) {
+        const char *e = getenv("TRC_DEV_POOL");
+        g_pool.enabled = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_pool.enabled == 1;
+}
+
+static size_t pool_class(size_t bytes) {
+    if (bytes <= 256) return 256;
+    const int k = 63 - __builtin_clzll((unsigned long long)bytes);      // 2^k <= bytes
+    const size_t step = (size_t)1 << (k - 3);
+    return (bytes + step - 1) & ~(step - 1);
+}
+
+static void pool_trim() {
+    std::vector<void *> gone;
+    {
+        std::lock_guard<std::mutex> g(g_pool.mu);
+        for (auto &kv : g_pool.idle) gone.push_back(kv.second);
+        g_pool.idle.clear();
+        g_pool.idle_bytes = 0;
+    }
+    for (void *p : gone) (void)hipFree(p);
+}
+
+static hipError_t pool_alloc(void **out, size_t bytes) {
+    *out = nullptr;
+    if (!pool_enabled()) return hipMalloc(out, bytes);
+    const size_t cls = pool_class(bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> g(g_pool.mu);
+        auto it = g_pool.idle.find(std::make_pair(dev, cls));
+        if (it != g_pool.idle.end()) {
+            *out = it->second;
+            g_pool.idle.erase(it);
+            g_pool.idle_bytes -= cls;
+            g_pool.live[*out] = std::make_pair(cls, dev);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, cls);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        pool_trim();
+        e = hipMalloc(out, cls);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> g(g_pool.mu);
+    g_pool.live[*out] = std::make_pair(cls, dev);
+    return hipSuccess;
+}
+
+static void pool_free(void *p) {
+    size_t cls = 0;
+    int dev = 0;
+    bool keep = false;
+    {
+        std::lock_guard<std::mutex> g(g_pool.mu);
+        auto it = g_pool.live.find(p);
+        if (it != g_pool.live.end()) {
+            cls = it->second.first;
+            dev = it->second.second;
+            g_pool.live.erase(it);
+            keep = pool_enabled() && cls <= POOL_BLOCK_MAX && g_pool.idle_bytes + cls <= POOL_KEEP;
+        }
+    }
+    if (!keep) { (void)hipFree(p); return; }
+    (void)hipDeviceSynchronize();        // nothing in flight may still use the block when the next owner gets it
+    std::lock_guard<std::mutex> g(g_pool.mu);
+    g_pool.idle.insert(std::make_pair(std::make_pair(dev, cls), p));
+    g_pool.idle_bytes += cls;
+}
+
 template <class T>
 static int dev_alloc(T **p, size_t n) {
     *p = nullptr;
     if (n == 0) n = 1;
-    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    hipError_t e = pool_alloc((void **)p, n * sizeof(T));
     if (e != hipSuccess)
         return trc_fail(TRC_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
     return TRC_OK;
 }
 template <class T>
 static void dev_free(T *&p) {
-    if (p) (void)hipFree((void *)p);
+    if (p) pool_free((void *)p);
     p = nullptr;
 }
 
@@ -1479,6 +1576,7 @@ extern "C" int trc_ctx_destroy(trc_ctx *ctx) {
     (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    pool_trim();          // blocks kept for reuse go back to the driver with the context
     return TRC_OK;
 }
 
@@ -2155,8 +2253,8 @@ struct DevRays {
     bool owned[10] = {false, false, false, false, false, false, false, false, false, false};
     void release() {
         double **p[9] = {&x, &y, &z, &dx, &dy, &dz, &e, &ref, &wl};
-        for (int i = 0; i < 9; ++i) { if (owned[i] && *p[i]) (void)hipFree(*p[i]); *p[i] = nullptr; }
-        if (owned[9] && rid) (void)hipFree(rid);
+        for (int i = 0; i < 9; ++i) { if (owned[i] && *p[i]) pool_free(*p[i]); *p[i] = nullptr; }
+        if (owned[9] && rid) pool_free(rid);
         rid = nullptr;
     }
 };
@@ -2505,22 +2603,30 @@ extern "C" int trc_source_generate(trc_ctx *ctx, const trc_source_desc *src, int
 // C-ABI: ordered engine
 // ================================================================================================
 static void level_free(Level &L) {
-    dev_free(L.x); dev_free(L.y); dev_free(L.z); dev_free(L.dx); dev_free(L.dy); dev_free(L.dz); dev_free(L.e);
-    dev_free(L.ref); dev_free(L.wl); dev_free(L.rid); dev_free(L.parent); dev_free(L.surf); dev_free(L.pay);
+    dev_free(L.slab);
+    L.x = L.y = L.z = L.dx = L.dy = L.dz = L.e = L.ref = L.wl = L.pay = nullptr;
+    L.rid = nullptr; L.parent = nullptr; L.surf = nullptr;
 }
 
+// One allocation per level (a trace of five levels used to cost 65 hipMalloc / hipFree pairs, 2 ms of a 1e5-ray call): eleven
+// 8-byte columns and the surface column, each starting on a 256-byte boundary, then the carried rows (n apart, as the kernels index them).
 static int level_alloc(Level &L, int64_t n, int n_pay) {
     memset(&L, 0, sizeof(L));
-    if (n_pay > 0) TRC_TRY(dev_alloc(&L.pay, (size_t)n * n_pay));
     L.n_total = n; L.n_live = n;
+    const size_t m = ((size_t)(n > 0 ? n : 1) + 31) & ~(size_t)31;
+    const size_t bytes = m * (11 * 8 + 4) + (n_pay > 0 ? (size_t)n * n_pay * 8 : 0);
+    TRC_TRY(dev_alloc(&L.slab, bytes));
     double **p[9] = {&L.x, &L.y, &L.z, &L.dx, &L.dy, &L.dz, &L.e, &L.ref, &L.wl};
-    for (int i = 0; i < 9; ++i) TRC_TRY(dev_alloc(p[i], (size_t)n));
-    TRC_TRY(dev_alloc(&L.rid, (size_t)n));
-    TRC_TRY(dev_alloc(&L.parent, (size_t)n));
-    TRC_TRY(dev_alloc(&L.surf, (size_t)n));
+    for (int i = 0; i < 9; ++i) *p[i] = (double *)(L.slab + (size_t)i * m * 8);
+    L.rid = (uint64_t *)(L.slab + 9 * m * 8);
+    L.parent = (int64_t *)(L.slab + 10 * m * 8);
+    L.surf = (int32_t *)(L.slab + 11 * m * 8);
+    if (n_pay > 0) L.pay = (double *)(L.slab + 11 * m * 8 + m * 4);
     return TRC_OK;
 }
 
+// Scratch of the bounce loop: allocated for the first (usually the largest) bounce and kept; a bounce that needs more -- refractive
+// surfaces can double a level -- gets a new set.
 struct OrdScratch {
     double *o[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint64_t *orid = nullptr;
@@ -2529,6 +2635,7 @@ struct OrdScratch {
     unsigned *blk_cnt = nullptr, *blk_cul = nullptr;
     unsigned long long *blk_off = nullptr, *totals = nullptr;
     void *sort_tmp = nullptr;
+    size_t cap_slots = 0, sort_bytes = 0;
     void release() {
         for (int i = 0; i < 9; ++i) dev_free(o[i]);
         dev_free(opay);
@@ -2536,6 +2643,30 @@ struct OrdScratch {
         dev_free(blk_cnt); dev_free(blk_cul); dev_free(blk_off); dev_free(totals);
         if (sort_tmp) (void)hipFree(sort_tmp);
         sort_tmp = nullptr;
+        cap_slots = 0; sort_bytes = 0;
+    }
+    int ensure(size_t slots, int n_pay) {
+        if (slots <= cap_slots) return TRC_OK;
+        release();
+        for (int i = 0; i < 9; ++i) TRC_TRY(dev_alloc(&o[i], slots));
+        TRC_TRY(dev_alloc(&orid, slots));
+        if (n_pay > 0) TRC_TRY(dev_alloc(&opay, slots * (size_t)n_pay));
+        TRC_TRY(dev_alloc(&key, slots));
+        TRC_TRY(dev_alloc(&ckey, slots)); TRC_TRY(dev_alloc(&cslot, slots));      // the occupied slots: at most all of them
+        TRC_TRY(dev_alloc(&skey, slots)); TRC_TRY(dev_alloc(&sslot, slots));
+        const size_t nblk = (slots + 255) / 256;
+        TRC_TRY(dev_alloc(&blk_cnt, nblk)); TRC_TRY(dev_alloc(&blk_cul, nblk)); TRC_TRY(dev_alloc(&blk_off, nblk));
+        TRC_TRY(dev_alloc(&totals, 2));
+        cap_slots = slots;
+        return TRC_OK;
+    }
+    int ensure_sort(size_t bytes) {
+        if (bytes <= sort_bytes && sort_tmp) return TRC_OK;
+        if (sort_tmp) (void)hipFree(sort_tmp);
+        sort_tmp = nullptr; sort_bytes = 0;
+        if (hipMalloc(&sort_tmp, bytes ? bytes : 1) != hipSuccess) return trc_fail(TRC_ERR_NOMEM, "sort scratch allocation failed");
+        sort_bytes = bytes;
+        return TRC_OK;
     }
 };
 
@@ -2642,17 +2773,8 @@ extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_so
         for (int it = 0; it < reps && n_cur > 0; ++it) {
             const Level cur = res->levels.back();
             const int64_t slots = 2 * n_cur;
-            sx.release();
-            for (int i = 0; i < 9 && st == TRC_OK; ++i) st = dev_alloc(&sx.o[i], (size_t)slots);
-            if (st == TRC_OK) st = dev_alloc(&sx.orid, (size_t)slots);
-            if (st == TRC_OK && n_pay > 0) st = dev_alloc(&sx.opay, (size_t)slots * n_pay);
-            if (st == TRC_OK) st = dev_alloc(&sx.key, (size_t)slots);
+            if ((st = sx.ensure((size_t)slots, n_pay))) break;
             const long long nblk = (slots + 255) / 256;
-            if (st == TRC_OK) st = dev_alloc(&sx.blk_cnt, (size_t)nblk);
-            if (st == TRC_OK) st = dev_alloc(&sx.blk_cul, (size_t)nblk);
-            if (st == TRC_OK) st = dev_alloc(&sx.blk_off, (size_t)nblk);
-            if (st == TRC_OK) st = dev_alloc(&sx.totals, 2);
-            if (st) break;
 
             OrdParams P;
             memset(&P, 0, sizeof(P));
@@ -2687,15 +2809,13 @@ extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_so
             const int64_t m = (int64_t)totals[0], n_culled = (int64_t)totals[1];
             // hits = rays that produced at least one child: count child-0 slots == slots < n_cur occupied; cheap bound: m minus second children
             if (m == 0) { n_cur = 0; break; }   // "Ray bundle depleted": nothing recorded (tracer_engine.py:271, :277)
-            if ((st = dev_alloc(&sx.ckey, (size_t)m)) || (st = dev_alloc(&sx.cslot, (size_t)m)) ||
-                (st = dev_alloc(&sx.skey, (size_t)m)) || (st = dev_alloc(&sx.sslot, (size_t)m))) break;
             hipLaunchKernelGGL(k_compact_scatter, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, sx.key, (long long)slots,
                                sx.blk_off, sx.ckey, sx.cslot);
             // stable sort by (culled, surface, block); slot order (= parent order) is kept inside a key
             size_t tmp_bytes = 0;
             hipError_t re = rocprim::radix_sort_pairs(nullptr, tmp_bytes, sx.ckey, sx.skey, sx.cslot, sx.sslot, (size_t)m, 0, 31, ctx->stream);
             if (re != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "radix_sort_pairs(size query) failed: %s", hipGetErrorString(re)); break; }
-            if (hipMalloc(&sx.sort_tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { st = trc_fail(TRC_ERR_NOMEM, "sort scratch allocation failed"); break; }
+            if ((st = sx.ensure_sort(tmp_bytes))) break;
             re = rocprim::radix_sort_pairs(sx.sort_tmp, tmp_bytes, sx.ckey, sx.skey, sx.cslot, sx.sslot, (size_t)m, 0, 31, ctx->stream);
             if (re != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "radix_sort_pairs failed: %s", hipGetErrorString(re)); break; }
             Level Ln;
