@@ -364,6 +364,32 @@ def test_minidish_upright_and_rotated():
         assert H.shape == (4, 4) and abs(H.sum() - 442.) < 1e-9 and N.allclose(xe, N.r_[-.2:.2:5j])
 
 
+def test_engines_built_in_a_loop_leave_device_memory_bounded():
+    """scripts build an assembly and an engine per run: freed device blocks wait in the library's pool for the next request of
+    their size class (DevPool, at most 4 GiB idle).  Thirty runs of growing size -- 60 GB of levels, scratch and hit buffers
+    allocated and released in all -- end with no more than that held back, and every run gives the same physics."""
+    import torch
+    from tracer_amd.models.tau_minidish import MiniDish
+    from tracer_amd.sources import solar_disk_bundle
+    x = -1 / math.sqrt(2)
+    share = []
+    free_before = None
+    for i in range(30):
+        n = 1000000 + 130003 * i
+        dish = MiniDish(5., 6.25, 0.9, 6.95, 0.4, 0.7, 0.9)
+        dish.set_transform(rotx(-N.pi / 4))
+        sun = solar_disk_bundle(n, N.c_[[0, 7., 7.]], N.array([0, x, x]), 3., 0.005, flux=1000., seed=i)
+        eng = TracerEngine(dish)
+        eng.ray_tracer(sun, 100, 1e-6, tree=(i % 2 == 0))
+        share.append(dish.histogram_hits(bins=10)[0].sum() / (1000. * math.pi * 9.))
+        del eng, dish, sun
+        if i == 0:
+            free_before = torch.cuda.mem_get_info()[0]          # after the first run: context, library and torch itself are up
+    held = free_before - torch.cuda.mem_get_info()[0]
+    assert held < 4.5 * 2 ** 30, held
+    assert max(share) - min(share) < 0.004 and abs(N.mean(share) - 0.6012) < 0.001
+
+
 def test_sg4_zones_and_petal_under_a_parallel_beam():
     """models/SG4.py:14-61 (two nested zones, the inner one met first) and models/PETAL_dish.py:12-50 (hexagonal aperture)
     under 2e5 axial rays: which zone a ray meets, the absorbed share, the perfect focus of the zone without slope error"""
