@@ -368,9 +368,15 @@ def test_engines_built_in_a_loop_leave_device_memory_bounded():
     """scripts build an assembly and an engine per run: freed device blocks wait in the library's pool for the next request of
     their size class (DevPool, at most 4 GiB idle).  Thirty runs of growing size -- 60 GB of levels, scratch and hit buffers
     allocated and released in all -- end with no more than that held back, and every run gives the same physics."""
-    import torch
+    import ctypes
     from tracer_amd.models.tau_minidish import MiniDish
     from tracer_amd.sources import solar_disk_bundle
+    hip = ctypes.CDLL('libamdhip64.so')
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
     x = -1 / math.sqrt(2)
     share = []
     free_before = None
@@ -384,8 +390,8 @@ def test_engines_built_in_a_loop_leave_device_memory_bounded():
         share.append(dish.histogram_hits(bins=10)[0].sum() / (1000. * math.pi * 9.))
         del eng, dish, sun
         if i == 0:
-            free_before = torch.cuda.mem_get_info()[0]          # after the first run: context, library and torch itself are up
-    held = free_before - torch.cuda.mem_get_info()[0]
+            free_before = free_bytes()                          # after the first run: context and library are up
+    held = free_before - free_bytes()
     assert held < 4.5 * 2 ** 30, held
     assert max(share) - min(share) < 0.004 and abs(N.mean(share) - 0.6012) < 0.001
 

@@ -461,6 +461,12 @@ def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavele
     if surf_ids[0] == surf_ids[-1] and (surf_ids == surf_ids[0]).all():
         # one capturing surface (the receiver of a field): no sorting, no gathering of 1e7 hits
         order, uniq, start, stop = None, [int(surf_ids[0])], [0], [len(surf_ids)]
+    elif (surf_ids[1:] >= surf_ids[:-1]).all():
+        # surface by surface already (the ordered engine's levels): runs are slices, nothing is gathered
+        order = None
+        start = N.r_[0, N.nonzero(surf_ids[1:] != surf_ids[:-1])[0] + 1]
+        uniq = surf_ids[start]
+        stop = list(start[1:]) + [len(surf_ids)]
     else:
         order = N.argsort(surf_ids, kind='stable')
         sorted_ids = surf_ids[order]
@@ -470,7 +476,7 @@ def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavele
         opt = surfaces[s].get_optics_manager()
         if not isinstance(opt, OpticsCallable) or not opt.accountants:
             continue
-        idx = slice(None) if order is None else order[a:b]
+        idx = slice(int(a), int(b)) if order is None else order[a:b]
         surf = surfaces[s]
         pts = points[:, idx]
         dirs = None if directions is None else directions[:, idx]

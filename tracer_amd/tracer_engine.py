@@ -296,14 +296,19 @@ class TracerEngine(object):
                                          for sf in dev.compiled.surfaces]) if dev.compiled.surfaces is not None else N.zeros(dev.n_surf, dtype=bool)
                 order = N.nonzero(acc_table[L['surf']])[0] if acc_table.any() else N.zeros(0, dtype=int)
                 if len(order):
-                    key = L['surf'][order].astype(N.int64) * (1 << 40) + par[order]
+                    whole = len(order) == len(par)           # every ray of the level ended on a surface with accountants: no gathering
+                    so, po = (L['surf'], par) if whole else (L['surf'][order], par[order])
+                    key = so.astype(N.int64) * (1 << 40) + po
                     if not (key[1:] >= key[:-1]).all():
                         order = order[N.argsort(key, kind='stable')]
-                    po = par[order]
-                    feed_accountants(dev.compiled.surfaces, L['surf'][order], prev['energy'][po], L['energy'][order],
-                                     L['vertices'][:, order], prev['directions'][:, po],
+                        whole = False
+                        so, po = L['surf'][order], par[order]
+                    sel = slice(None) if whole else order
+                    # (copies, not views, of what the recorded bundle of the tree holds: a script may edit engine.tree in place)
+                    feed_accountants(dev.compiled.surfaces, so, prev['energy'][po], L['energy'].copy() if whole else L['energy'][order],
+                                     L['vertices'].copy() if whole else L['vertices'][:, order], prev['directions'][:, po],
                                      None if prev['wavelengths'] is None else prev['wavelengths'][po],
-                                     spectra=None if not n_spec else (prev['spectra'][:, po], L['spectra'][:, order], L['wavelengths'][:, order]))
+                                     spectra=None if not n_spec else (prev['spectra'][:, po], L['spectra'][:, sel], L['wavelengths'][:, sel]))
                 if self._transfer:
                     ns = dev.n_surf
                     left = N.full(len(prev['energy']), ns) if prev_surf is None else prev_surf
