@@ -3,6 +3,7 @@ GPU tests of the Python plugin API (run with -m gpu): the reference's own unit t
 classes -- same inputs, same expected values (file:line of the reference test in each docstring).  They exercise
 the per-surface protocol kernels, the three engines through TracerEngine, the accountants and the compat aliases.
 """
+import os
 import math
 
 import numpy as N
@@ -394,6 +395,29 @@ def test_engines_built_in_a_loop_leave_device_memory_bounded():
     held = free_before - free_bytes()
     assert held < 4.5 * 2 ** 30, held
     assert max(share) - min(share) < 0.004 and abs(N.mean(share) - 0.6012) < 0.001
+
+
+def test_without_the_device_pool():
+    """TRC_DEV_POOL=0 (every freed block straight back to the driver) in a process of its own: the minidish known answers"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as N\n"
+        "from tracer_amd.models.tau_minidish import MiniDish\n"
+        "from tracer_amd.tracer_engine import TracerEngine\n"
+        "from tracer_amd.ray_bundle import RayBundle\n"
+        "pos = N.zeros((3, 5)); pos[0] = N.r_[-2:2:5j]; pos[2] = 6.\n"
+        "d = N.zeros((3, 5)); d[2] = -1.\n"
+        "for k in range(3):\n"
+        "    md = MiniDish(5, 5, 0.9, 5.7, .4, 0.7, 0.9)\n"
+        "    TracerEngine(md).ray_tracer(RayBundle(pos, d, energy=N.ones(5) * 100, ref_index=N.ones(5)), 1776, 0.05, tree=bool(k % 2))\n"
+        "    e = md.get_receiver_surf().get_surfaces()[0].get_optics_manager().get_all_hits()[0]\n"
+        "    assert N.allclose(N.sort(e), [81., 81., 90., 90., 100.]), e\n"
+        "print('ok')\n")
+    env = dict(os.environ, TRC_DEV_POOL='0', PYTHONPATH=root)
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
 
 
 def test_sg4_zones_and_petal_under_a_parallel_beam():
