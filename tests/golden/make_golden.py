@@ -868,6 +868,44 @@ def make_mc(ref):
     N.savez_compressed(os.path.join(HERE, 'mc_reference.npz'), **out)
 
 
+def make_mc_minidish(ref):
+    """
+    The scene of examples/test_case.py:29-52 (models/tau_minidish.py on homogenized_local_receiver.py: tilted dish, homogenizer
+    duct, one-sided receiver) traced by the reference itself, 10 seeds x 1e5 rays of `disk_bundle` (the example's
+    `solar_disk_bundle` under its current name): power on the receiver plate and absorbed by each duct wall and by the dish,
+    the 20 x 20 map of examples/test_case.py:60, the size of every level of the ray tree.  -> mc_minidish.npz
+    """
+    import math
+    import time
+    md = importlib.import_module('tracer.models.tau_minidish')
+    focus, h_depth, side, n = 6.25, 0.7, 0.4, 100000
+    x = -1 / math.sqrt(2)
+    P, W, H, L = [], [], [], []
+    t0 = time.time()
+    for k in range(10):
+        N.random.seed(4000 + k)
+        dish = md.MiniDish(5., focus, 0.9, focus + h_depth, side, h_depth, 0.9)
+        dish.set_transform(ref.spatial_geometry.rotx(-N.pi / 4))
+        sun = ref.sources.disk_bundle(n, N.c_[[0, 7., 7.]], N.array([0, x, x]), 3., 0.005, flux=1000.)
+        eng = ref.tracer_engine.TracerEngine(dish)
+        eng.ray_tracer(sun, 100, 1e-6)
+        hist = dish.histogram_hits(bins=20)[0]
+        plate = dish.get_receiver_surf().get_surfaces()[0]
+        P.append(plate.get_optics_manager().get_all_hits()[0].sum())
+        W.append([s_.get_optics_manager().get_all_hits()[0].sum() for s_ in dish.get_homogenizer().get_surfaces()])
+        H.append(hist)
+        sizes = [eng.tree[i].get_num_rays() for i in range(len(eng.tree._bunds))]
+        L.append(sizes[:5] + [0] * (5 - len(sizes[:5])))
+    out = dict(rays_per_run=N.int64(n), source_power=1000. * N.pi * 9.,
+               receiver_runs=N.array(P), receiver_mean=N.mean(P), receiver_se=N.std(P, ddof=1) / N.sqrt(len(P)),
+               walls_mean=N.mean(W, axis=0), walls_se=N.std(W, axis=0, ddof=1) / N.sqrt(len(W)),
+               map_mean=N.mean(H, axis=0), map_se=N.std(H, axis=0, ddof=1) / N.sqrt(len(H)),
+               levels_mean=N.mean(L, axis=0), levels_se=N.std(L, axis=0, ddof=1) / N.sqrt(len(L)))
+    print('  minidish mc: %.1f s, receiver %.1f +- %.1f W of %.1f, walls %s, levels %s' %
+          (time.time() - t0, out['receiver_mean'], out['receiver_se'], out['source_power'], N.round(out['walls_mean'], 1), out['levels_mean']))
+    N.savez_compressed(os.path.join(HERE, 'mc_minidish.npz'), **out)
+
+
 def make_emissive(out):
     """
     emissive_losses.  radiosity_RTVF is called as it is (emissive_losses.py imports under Python 3).
@@ -995,6 +1033,9 @@ def main():
     import_reference()
     if '--mc' in sys.argv:
         make_mc(NS('tracer'))
+        return
+    if '--mc-minidish' in sys.argv:
+        make_mc_minidish(NS('tracer'))
         return
     ref = NS('tracer')
     amd = NS('tracer_amd')

@@ -634,6 +634,60 @@ def _cavity_scene():
     return TableScene(gm_kind, ok, frames, gm, opt, extra, eoff, elen)
 
 
+def test_minidish_example_vs_reference_runs(ctx):
+    """
+    The scene of examples/test_case.py (models/tau_minidish.py: tilted dish, homogenizer duct, one-sided receiver) against ten
+    runs of the reference itself on it (tests/golden/mc_minidish.npz, made by make_golden.py --mc-minidish): power on the plate,
+    power absorbed by each duct wall, the 20 x 20 flux map bin by bin, the size of every level of the ray tree.
+    """
+    import math
+    from tracer_amd.models.tau_minidish import MiniDish
+    from tracer_amd.sources import solar_disk_bundle
+    from tracer_amd.spatial_geometry import rotx
+    from tracer_amd.tracer_engine import TracerEngine
+    mc = load('mc_minidish.npz')
+    x = -1 / math.sqrt(2)
+
+    def scene():
+        dish = MiniDish(5., 6.25, 0.9, 6.95, 0.4, 0.7, 0.9)
+        dish.set_transform(rotx(-N.pi / 4))
+        return dish, dish.get_receiver_surf().get_surfaces()[0]
+
+    # fast engine, 2e7 rays, flux map binned on the device: its own Monte-Carlo error is a seventh of the reference's
+    n = 20000000
+    dish, plate = scene()
+    eng = TracerEngine(dish)
+    edges = N.linspace(-0.2, 0.2, 21)
+    eng.set_fluxmap(plate, edges, edges)
+    eng.ray_tracer(solar_disk_bundle(n, N.c_[[0, 7., 7.]], N.array([0, x, x]), 3., 0.005, flux=1000., seed=41), 100, 1e-6,
+                   tree=False, feed=False, seed=41)
+    a, r, h = eng.get_tallies()
+    surfs = dish.get_surfaces()
+    ip = surfs.index(plate)
+    shrink = math.sqrt(10 * float(mc['rays_per_run']) / n)
+    se = float(mc['receiver_se']) * math.sqrt(1. + shrink ** 2)
+    assert abs(a[ip] - float(mc['receiver_mean'])) <= 4. * se, (a[ip], float(mc['receiver_mean']), se)
+    walls = [surfs.index(w) for w in dish.get_homogenizer().get_surfaces()]
+    assert N.all(N.abs(a[walls] - mc['walls_mean']) <= 4. * mc['walls_se'] * math.sqrt(1. + shrink ** 2)), (a[walls], mc['walls_mean'])
+    # the map: bins the sun reaches, each against the reference's mean with the reference's standard error (9 degrees of freedom)
+    got = eng.get_fluxmap(plate)
+    assert abs(got.sum() - a[ip]) < 1e-6 * a[ip]
+    lit = mc['map_se'] > 0
+    z = (got[lit] - mc['map_mean'][lit]) / (mc['map_se'][lit] * math.sqrt(1. + shrink ** 2))
+    assert lit.sum() > 300 and abs(z.mean()) < 0.3 and N.mean(z ** 2) < 2.2 and N.abs(z).max() < 8., (z.mean(), N.mean(z ** 2), N.abs(z).max())
+    # ordered engine, the call of the script word for word: level sizes of the ray tree, and the same power through histogram_hits
+    n = 1000000
+    dish, plate = scene()
+    eng = TracerEngine(dish)
+    eng.ray_tracer(solar_disk_bundle(n, N.c_[[0, 7., 7.]], N.array([0, x, x]), 3., 0.005, flux=1000., seed=42), 100, 1e-6, seed=42)
+    sizes = N.array([b.get_num_rays() for b in eng.tree._bunds][:5], dtype=float)
+    frac, frac_ref = sizes / n, mc['levels_mean'] / float(mc['rays_per_run'])
+    frac_se = N.sqrt((mc['levels_se'] / float(mc['rays_per_run'])) ** 2 + frac * (1 - frac) / n)
+    assert N.all(N.abs(frac - frac_ref) <= 4. * frac_se + 1e-12), (frac, frac_ref)
+    hist = dish.histogram_hits(bins=20)[0]
+    assert abs(hist.sum() - float(mc['receiver_mean'])) <= 4. * float(mc['receiver_se']) * math.sqrt(2.), hist.sum()
+
+
 def test_cavity_spectral_engines_vs_oracle(ctx):
     """cavity scene (frustum / cylinder / cone / plates, table-driven spectral and directional optics, per-ray wavelengths):
     ordered and fast engines against the oracle, ray by ray, on identical Philox streams"""

@@ -380,3 +380,38 @@ def test_scattering_maps_vs_reference():
     scat, lengths = optics.scattering(g['sc_sigma'], g['sc_paths'], g['sc_R'])
     assert N.array_equal(scat, g['sc_scattered']) and 500 < scat.sum() < 3000
     assert N.allclose(lengths, g['sc_lengths'], rtol=1e-14, atol=0.)
+
+
+def test_minidish_example_scene_vs_reference_runs():
+    """
+    The oracle on the scene of examples/test_case.py (tilted dish of models/tau_minidish.py, homogenizer duct, one-sided receiver),
+    2e5 rays, against ten runs of the reference itself (mc_minidish.npz, make_golden.py --mc-minidish): power on the plate and on
+    each duct wall, the size of every level of the ray tree.
+    """
+    import math
+    from tracer_amd.models.tau_minidish import MiniDish
+    from tracer_amd.sources import solar_disk_bundle
+    from tracer_amd.spatial_geometry import rotx
+    from tracer_amd.scene import compile_scene
+    from oracle import engine
+    mc = load('mc_minidish.npz')
+    n = 200000
+    x = -1 / math.sqrt(2)
+    dish = MiniDish(5., 6.25, 0.9, 6.95, 0.4, 0.7, 0.9)
+    dish.set_transform(rotx(-N.pi / 4))
+    cs = compile_scene(dish)
+    sun = solar_disk_bundle(n, N.c_[[0, 7., 7.]], N.array([0, x, x]), 3., 0.005, flux=1000., seed=43)
+    with N.errstate(all='ignore'):
+        out = engine.trace_from_compiled(cs, sun.source_args(), 100, 1e-6)
+    surfs = dish.get_surfaces()
+    plate = surfs.index(dish.get_receiver_surf().get_surfaces()[0])
+    walls = [surfs.index(w) for w in dish.get_homogenizer().get_surfaces()]
+    grow = math.sqrt(1. + 10 * float(mc['rays_per_run']) / n)            # this run's own Monte-Carlo error on top of the reference's
+    got = out['absorbed']
+    assert abs(got[plate] - float(mc['receiver_mean'])) <= 4. * float(mc['receiver_se']) * grow, (got[plate], float(mc['receiver_mean']))
+    assert N.all(N.abs(got[walls] - mc['walls_mean']) <= 4. * mc['walls_se'] * grow), (got[walls], mc['walls_mean'])
+    sizes = N.array([lv['energy'].shape[0] for lv in out['levels']][:5], dtype=float)          # levels[0] is the source bundle
+    frac, frac_ref = sizes / n, mc['levels_mean'] / float(mc['rays_per_run'])
+    frac_se = N.sqrt((mc['levels_se'] / float(mc['rays_per_run'])) ** 2 + frac * (1 - frac) / n)
+    assert N.all(N.abs(frac - frac_ref) <= 4. * frac_se + 1e-12), (frac, frac_ref)
+
