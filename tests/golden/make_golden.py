@@ -906,6 +906,57 @@ def make_mc_minidish(ref):
     N.savez_compressed(os.path.join(HERE, 'mc_minidish.npz'), **out)
 
 
+def plates_scene(T):
+    """the scene of examples/accel_tree_example.py:20-53 from the modules of T (the reference or tracer_amd): two slabs, ten layers
+    of 10 x 10 Lambertian plates, every object with its BoundaryBox"""
+    n = 10
+    side = n + 1.
+    objects = []
+    for z in (-1., None):
+        slab = T.object.AssembledObject(T.surface.Surface(geometry=T.flat_surface.RectPlateGM(side, side), optics=T.optics_callables.LambertianReceiver(0.6)),
+                                        bounds=T.boundary_shape.BoundaryBox([[-side / 2., -side / 2., 0.], [side / 2., side / 2., 0.]]))
+        if z is not None:
+            slab.set_location(N.array([0., 0., z]))
+        objects.append(slab)
+    for k in range(n):
+        for i in range(n):
+            for j in range(n):
+                plate = T.object.AssembledObject(T.surface.Surface(geometry=T.flat_surface.RectPlateGM(.8, .8), optics=T.optics_callables.LambertianReceiver(0.9)),
+                                                 bounds=T.boundary_shape.BoundaryBox([[-.4, -.4, 0.], [.4, .4, 0.]]))
+                plate.set_location(N.array([i + 0.5 - n / 2., j + 0.5 - n / 2., k + 1.]))
+                objects.append(plate)
+    return T.assembly.Assembly(objects=objects), n, side
+
+
+def make_mc_plates(ref):
+    """
+    examples/accel_tree_example.py traced by the reference itself (brute force: its Kd-tree build stops on this scene, where no
+    object is without bounds -- N.hstack of an empty list, accel_tree.py:73): 8 seeds x 2e4 rays of the example's source, default
+    reps and min_energy as in the example.  Power absorbed by the slab the sun can reach, by each of the ten layers, in total.
+    -> mc_plates.npz
+    """
+    import time
+    asm, n, side = plates_scene(ref)
+    eng = ref.tracer_engine.TracerEngine(asm)
+    rays = 20000
+    rows = []
+    t0 = time.time()
+    for k in range(8):
+        N.random.seed(5000 + k)
+        asm.reset_all_optics()
+        src = ref.sources.oblique_solar_rect_bundle(num_rays=rays, center=N.vstack([0, 0, n + 1]), source_direction=N.hstack([0, 0, -1]),
+                                                    rays_direction=N.hstack([0, 0, -1]), x=side, y=side, ang_range=4.65e-3, flux=1000.)
+        eng.ray_tracer(src)
+        per = N.array([N.sum(s_.get_optics_manager().get_all_hits()[0]) for s_ in asm.get_surfaces()])
+        rows.append(N.r_[per.sum(), per[1], per[2:].reshape(10, 100).sum(axis=1)])
+    rows = N.array(rows)
+    out = dict(rays_per_run=N.int64(rays), source_power=1000. * side * side, runs=rows, mean=rows.mean(axis=0),
+               se=rows.std(axis=0, ddof=1) / N.sqrt(len(rows)))
+    print('  plates mc: %.1f s, total %.0f +- %.0f W of %.0f; slab %.0f +- %.0f; layers %s' %
+          (time.time() - t0, out['mean'][0], out['se'][0], out['source_power'], out['mean'][1], out['se'][1], N.round(out['mean'][2:])))
+    N.savez_compressed(os.path.join(HERE, 'mc_plates.npz'), **out)
+
+
 def make_emissive(out):
     """
     emissive_losses.  radiosity_RTVF is called as it is (emissive_losses.py imports under Python 3).
@@ -1036,6 +1087,9 @@ def main():
         return
     if '--mc-minidish' in sys.argv:
         make_mc_minidish(NS('tracer'))
+        return
+    if '--mc-plates' in sys.argv:
+        make_mc_plates(NS('tracer'))
         return
     ref = NS('tracer')
     amd = NS('tracer_amd')

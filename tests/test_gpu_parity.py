@@ -688,6 +688,43 @@ def test_minidish_example_vs_reference_runs(ctx):
     assert abs(hist.sum() - float(mc['receiver_mean'])) <= 4. * float(mc['receiver_se']) * math.sqrt(2.), hist.sum()
 
 
+def test_plates_example_vs_reference_runs(ctx):
+    """
+    examples/accel_tree_example.py (a thousand Lambertian plates in ten layers over a slab; up to a dozen diffuse bounces per ray)
+    against eight runs of the reference itself (tests/golden/mc_plates.npz, make_golden.py --mc-plates): power absorbed in total,
+    by the slab, by each layer -- the ordered engine with the example's own call, the fast engine in both forms.
+    """
+    import math
+    from helpers import plates_scene, plates_source
+    from tracer_amd.tracer_engine import TracerEngine
+    mc = load('mc_plates.npz')
+    asm, layers, side = plates_scene()
+    eng = TracerEngine(asm)
+
+    def rows(per):
+        return N.r_[per.sum(), per[1], per[2:].reshape(10, 100).sum(axis=1)]
+
+    def check(got, n, what):
+        grow = math.sqrt(1. + 8 * float(mc['rays_per_run']) / n)
+        z = (got - mc['mean']) / (mc['se'] * grow)
+        assert N.abs(z).max() < 4.5, (what, z)
+
+    # min_energy is an energy per ray: the example's default of 0.05 W on 2e4 rays of 6.05 W each is kept in proportion
+    n = 400000
+    asm.reset_all_optics()
+    eng.ray_tracer(plates_source(n, layers, side, 51), 1000, 0.05 * float(mc['rays_per_run']) / n, accel=True, seed=51)
+    assert eng.stats['engine'] == 'ordered'
+    check(rows(N.array([N.sum(s.get_optics_manager().get_all_hits()[0]) for s in asm.get_surfaces()])), n, 'ordered')
+    n = 4000000
+    for form in ('megakernel', 'stream'):
+        asm.reset_all_optics()
+        eng.reset_tallies()
+        eng.ray_tracer(plates_source(n, layers, side, 52), 1000, 0.05 * float(mc['rays_per_run']) / n, accel=True, seed=52, tree=False,
+                       fast_kernel=form, feed=False)
+        a, r, h = eng.get_tallies()
+        check(rows(a), n, form)
+
+
 def test_cavity_spectral_engines_vs_oracle(ctx):
     """cavity scene (frustum / cylinder / cone / plates, table-driven spectral and directional optics, per-ray wavelengths):
     ordered and fast engines against the oracle, ray by ray, on identical Philox streams"""

@@ -415,3 +415,25 @@ def test_minidish_example_scene_vs_reference_runs():
     frac_se = N.sqrt((mc['levels_se'] / float(mc['rays_per_run'])) ** 2 + frac * (1 - frac) / n)
     assert N.all(N.abs(frac - frac_ref) <= 4. * frac_se + 1e-12), (frac, frac_ref)
 
+
+def test_plates_example_scene_vs_reference_runs():
+    """
+    The oracle on the scene of examples/accel_tree_example.py (1002 Lambertian surfaces, a dozen diffuse bounces), 3e4 rays, against
+    eight runs of the reference itself (mc_plates.npz, make_golden.py --mc-plates): power absorbed in total, by the slab, by each layer.
+    """
+    import math
+    from helpers import plates_scene, plates_source
+    from tracer_amd.scene import compile_scene
+    from oracle import engine
+    mc = load('mc_plates.npz')
+    asm, layers, side = plates_scene()
+    n = 30000
+    with N.errstate(all='ignore'):
+        # (min_energy is an energy per ray: the example's 0.05 W on 2e4 rays, kept in proportion)
+        out = engine.trace_from_compiled(compile_scene(asm), plates_source(n, layers, side, 53).source_args(), 1000,
+                                         0.05 * float(mc['rays_per_run']) / n)
+    per = out['absorbed']
+    got = N.r_[per.sum(), per[1], per[2:].reshape(10, 100).sum(axis=1)]
+    z = (got - mc['mean']) / (mc['se'] * math.sqrt(1. + 8 * float(mc['rays_per_run']) / n))
+    assert N.abs(z).max() < 4.5, z
+
