@@ -6,8 +6,10 @@ tracer/models/homogenized_local_receiver.py:14-83, which tau_minidish.MiniDish a
 """
 import numpy as N
 
+from .. import optics_callables as opt
 from ..assembly import Assembly
 from ..object import AssembledObject
+from ..surface import Surface
 from ..spatial_geometry import generate_transform
 from .homogenizer import rect_homogenizer
 from .one_sided_mirror import one_sided_receiver
@@ -56,3 +58,24 @@ class HomogenizedLocalReceiver(Assembly):
         local = plate.global_to_local(where)
         extent = [(-side / 2., side / 2.) for side in self._sides]
         return N.histogram2d(local[0], local[1], bins, range=extent, weights=absorbed)
+
+
+class DishOnHomogenizedReceiver(HomogenizedLocalReceiver):
+    """
+    What the dish collectors of this package share (tau_minidish.MiniDish, PETAL_dish.PETAL): a paraboloidal mirror of the
+    aperture shape `aperture` (a geometry manager taking diameter and focal length) as main reflector, and a receiver plate of
+    receiver_side (x) by receiver_side * receiver_aspect (y).
+    """
+    aperture = None
+
+    def __init__(self, diameter, focal_length, dish_opt_eff, receiver_pos, receiver_side, homogenizer_depth, homog_opt_eff,
+                 receiver_aspect=1., **surface_options):
+        mirror = Surface(self.aperture(diameter, focal_length), opt.Reflective(1 - dish_opt_eff), **surface_options)
+        HomogenizedLocalReceiver.__init__(self, mirror, receiver_pos, (receiver_side, receiver_side * receiver_aspect),
+                                          homogenizer_depth, homog_opt_eff)
+        self._ext_dims = (diameter, receiver_pos)
+
+    def get_external_dimensions(self):
+        """(diameter of the dish, height from its vertex to the receiver plate): the cylinder the collector fits in"""
+        return self._ext_dims
+

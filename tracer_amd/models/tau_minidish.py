@@ -4,28 +4,20 @@ Same names and arguments as the reference's tracer/models/tau_minidish.py:22-103
 """
 from math import sqrt, pi
 
-from .. import optics_callables as opt
-from ..surface import Surface
 from ..paraboloid import ParabolicDishGM
-from .homogenized_local_receiver import HomogenizedLocalReceiver
+from .homogenized_local_receiver import DishOnHomogenizedReceiver
 
 
-class MiniDish(HomogenizedLocalReceiver):
-    def __init__(self, diameter, focal_length, dish_opt_eff, receiver_pos, receiver_side, homogenizer_depth,
-                 homog_opt_eff, receiver_aspect=1.):
-        """
-        diameter, focal_length, dish_opt_eff - the dish and its reflectivity; receiver_pos - axial distance from the dish
-        vertex to the receiver plate; receiver_side (x) and receiver_side * receiver_aspect (y) - the plate;
-        homogenizer_depth, homog_opt_eff - the duct in front of it.
-        """
-        dish = Surface(ParabolicDishGM(diameter, focal_length), opt.Reflective(1 - dish_opt_eff), fixed_color=(1., 0., 0.))
-        HomogenizedLocalReceiver.__init__(self, dish, receiver_pos, (receiver_side, receiver_side * receiver_aspect),
-                                          homogenizer_depth, homog_opt_eff)
-        self._ext_dims = (diameter, receiver_pos)
+class MiniDish(DishOnHomogenizedReceiver):
+    """
+    MiniDish(diameter, focal_length, dish_opt_eff, receiver_pos, receiver_side, homogenizer_depth, homog_opt_eff,
+    receiver_aspect=1.): the dish and its reflectivity; the axial distance from the dish vertex to the receiver plate; the
+    plate (receiver_side along x, receiver_side * receiver_aspect along y); depth and wall reflectivity of the duct before it.
+    """
+    aperture = ParabolicDishGM
 
-    def get_external_dimensions(self):
-        """(dish diameter, height from the dish vertex to the receiver plate): the bounding cylinder"""
-        return self._ext_dims
+    def __init__(self, *args, **kwargs):
+        DishOnHomogenizedReceiver.__init__(self, *args, fixed_color=(1., 0., 0.), **kwargs)
 
 
 def standard_minidish_measures(diameter, concentration, virt_sources):
