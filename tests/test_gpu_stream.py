@@ -509,6 +509,54 @@ def test_forms_of_the_fast_engine_end_every_ray_alike(ctx):
         assert N.allclose(a1, a0, rtol=1e-9, atol=1e-12), aligned
 
 
+def test_auto_form_settles_on_the_faster_one_for_a_dense_scene(ctx):
+    """
+    fast_kernel='auto' on a scene where the streaming form is slow (200 overlapping curved shapes, every segment a hit): the first
+    large call streams, the second tries the megakernel, the following ones keep whichever was faster -- and every call ends its
+    rays alike.  A heliostat field never leaves the streaming form.
+    """
+    from tracer_amd import scenes
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM, RoundPlateGM
+    from tracer_amd.sphere_surface import SphericalGM, HemisphereGM
+    from tracer_amd.cylinder import FiniteCylinder
+    from tracer_amd.paraboloid import ParabolicDishGM
+    from tracer_amd.optics_callables import Reflective
+    from tracer_amd.tracer_engine import TracerEngine
+    from tracer_amd.sources import disk_bundle
+    from tracer_amd.spatial_geometry import generate_transform
+    rng = N.random.RandomState(8)
+    objs = []
+    for _ in range(200):
+        kind, s = rng.randint(0, 6), rng.uniform(0.2, 1.5)
+        gm = (RectPlateGM(2 * s, s), RoundPlateGM(s), SphericalGM(s), HemisphereGM(s), FiniteCylinder(2 * s, 3 * s),
+              ParabolicDishGM(2 * s, rng.uniform(0.5, 2.)))[kind]
+        o = AssembledObject(surfs=[Surface(gm, Reflective(0.2))])
+        ax = rng.normal(size=3)
+        o.set_transform(generate_transform(ax / N.linalg.norm(ax), rng.uniform(0, 2 * N.pi), rng.uniform(-6., 6., 3)[:, None]))
+        objs.append(o)
+    eng = TracerEngine(Assembly(objects=objs))
+    sun = N.r_[0.2, -0.1, -1.] / N.linalg.norm([0.2, -0.1, -1.])
+    n = 4000000
+    forms, counts, rates = [], [], []
+    for call in range(4):
+        eng.reset_tallies()
+        eng.ray_tracer(disk_bundle(n, N.c_[-12. * sun], sun, 9., 4.65e-3, flux=1., seed=2), 50, 1e-8, seed=2, tree=False)
+        forms.append(eng.stats['form'])
+        rates.append(eng.stats['segments'] / eng.stats['kernel_ms'])
+        counts.append(eng.get_tallies()[2].copy())
+    assert forms[:2] == ['stream', 'megakernel'] and forms[2] == forms[3]
+    assert forms[2] == ('megakernel' if rates[1] > rates[0] else 'stream')
+    assert all(N.array_equal(c, counts[0]) for c in counts[1:]) and counts[0].sum() > n
+    plant, field, rec, src = scenes.nsttf_field(n_heliostats=40)
+    eng = TracerEngine(plant)
+    for call in range(3):
+        eng.ray_tracer(scenes.nsttf_source(n, src, seed=3), reps=100, min_energy=1e-10, tree=False, accel=True, seed=3)
+        assert eng.stats['form'] == 'stream'
+
+
 def test_accel_keyword_forms_through_ray_tracer(ctx):
     """
     ray_tracer(accel=...) as the reference spells it (tracer_engine.py:171-185): False, True, 'fast' (KdTree with at most 12

@@ -178,6 +178,7 @@ class DeviceScene(object):
         self.n_surf = compiled.n_surf
         self.fluxmaps = {}
         self.hit_capacity = 0
+        self.form_rate = {}         # segments per ms of kernel time seen from each form of the fast engine on this scene (TracerEngine)
         self._kd_keep = None
 
     def close(self):

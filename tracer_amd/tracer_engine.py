@@ -148,6 +148,9 @@ class TracerEngine(object):
 
     # -- the entry point ------------------------------------------------------------------------------
     KD_BUILD_MAX = 8192      # surfaces beyond which accel=True does not build the reference's Kd-tree for the fast engine
+    TUNE_MIN_RAYS = 1 << 21  # calls from which the two forms of the fast engine are compared on a scene (fast_kernel='auto')
+    TUNE_MAX_SURFACES = 512  # ... and the scene size up to which the megakernel is worth a try
+    SLOW_STREAM = 1.5e6      # segments per ms of kernel time below which the streaming form counts as slow
 
     def ray_tracer(self, bundle, reps=100, min_energy=1e-10, tree=True, accel=False, Kd_Tree=None, **kwargs):
         """
@@ -238,6 +241,15 @@ class TracerEngine(object):
         stream = {'auto': None, 'stream': True, 'megakernel': False}[fast_kernel]
         if stream is None and accel and dev.n_surf > self.KD_BUILD_MAX:
             stream = True       # the streaming form has the grid for large scenes; the megakernel would test every box
+        # Large calls go to the streaming form.  On a scene where it turns out slow -- every segment a hit on overlapping curved
+        # shapes, several bounces deep: below SLOW_STREAM segments per ms, a fortieth of its rate on a heliostat field -- the next
+        # large call tries the megakernel, whose rays stay in registers, and the faster of the two serves the scene from then on.
+        # Both forms end every ray alike (test_forms_of_the_fast_engine_end_every_ray_alike).
+        tuned = stream is None and n >= self.TUNE_MIN_RAYS and dev.n_surf <= self.TUNE_MAX_SURFACES
+        if tuned:
+            rate = dev.form_rate
+            if 'stream' in rate and rate['stream'] < self.SLOW_STREAM:
+                stream = False if ('megakernel' not in rate or rate['megakernel'] > rate['stream']) else True
         # Rays still alive after `reps` interactions come back as the call's result (tracer_engine.py:293-295).  Bundles beyond
         # 2^24 rays get room for 2^22 of them unless the caller says otherwise (last_capacity=...): 1e8 rays would cost 5.6 GB
         # of host arrays per call for a result that is empty in most scenes.  More rays left than room is an error of the
@@ -246,6 +258,9 @@ class TracerEngine(object):
         stats, last = dev.trace_fast(bundle, reps, min_energy, seed, accel=accel, keep_last=True, stream=stream, last_capacity=cap)
         wall = time.time() - t0
         self._set_stats(stats, wall, 'fast')
+        self.stats['form'] = 'megakernel' if (stream is False or (stream is None and n < (1 << 20))) else 'stream'
+        if tuned and stats.kernel_ms > 0:
+            dev.form_rate[self.stats['form']] = stats.segments / stats.kernel_ms
         if stats.hits_dropped:
             raise RuntimeError("%d hits were not captured: the hit buffer holds %d; pass hit_capacity=..."
                                % (stats.hits_dropped, dev.hit_capacity))
