@@ -286,7 +286,8 @@ int trc_scene_reset_tallies(trc_scene *scene);
    received = sum E_in (ReceptionAccountant :1699-1701), hits = count. Any pointer may be NULL. */
 int trc_scene_get_tallies(trc_scene *scene, double *absorbed, double *received, int64_t *hits);
 int trc_scene_get_fluxmap(trc_scene *scene, int32_t surf, double *out /* nu*nv, row-major u */);
-/* captured hits, in device arrival order. Query n first with all arrays NULL. */
+/* captured hits: in device arrival order when one surface captures; when several do, surface by surface (ascending index),
+   arrival order inside a surface. Query n first with all arrays NULL. */
 int trc_scene_get_hits(trc_scene *scene, int64_t *n, int32_t *surf, double *e_abs, double *e_in,
                        double *px, double *py, double *pz, double *dx, double *dy, double *dz);
 /* View-factor allocation (emissive_losses/view_factors_3D.py:239-356 and :598-674, `alloc_VF`): the absorbed energy of

@@ -509,6 +509,43 @@ def test_forms_of_the_fast_engine_end_every_ray_alike(ctx):
         assert N.allclose(a1, a0, rtol=1e-9, atol=1e-12), aligned
 
 
+def test_hits_of_several_capturing_surfaces_come_grouped(ctx):
+    """
+    trc_scene_get_hits with more than one capturing surface (the duct walls and the plate of the minidish): the hits come surface
+    by surface, so that the accountants are fed slices; counts and absorbed energy per surface are those of the tallies, in both
+    forms of the fast engine, and the accountants see what the ordered engine's accountants see.
+    """
+    import math
+    from tracer_amd.models.tau_minidish import MiniDish
+    from tracer_amd.sources import solar_disk_bundle
+    from tracer_amd.spatial_geometry import rotx
+    from tracer_amd.tracer_engine import TracerEngine
+    x = -1 / math.sqrt(2)
+    n = 600000
+    per_form = {}
+    for form in ('megakernel', 'stream', 'ordered'):
+        dish = MiniDish(5., 6.25, 0.9, 6.95, 0.4, 0.7, 0.9)
+        dish.set_transform(rotx(-N.pi / 4))
+        eng = TracerEngine(dish)
+        sun = solar_disk_bundle(n, N.c_[[0, 7., 7.]], N.array([0, x, x]), 3., 0.005, flux=1000., seed=6)
+        if form == 'ordered':
+            eng.ray_tracer(sun, 100, 1e-6, seed=6)
+        else:
+            eng.ray_tracer(sun, 100, 1e-6, seed=6, tree=False, fast_kernel=form)
+            h = eng._dev.get_hits()
+            a, r, cnt = eng.get_tallies()
+            assert (N.diff(h['surf']) >= 0).all() and len(N.unique(h['surf'])) == 5
+            assert N.array_equal(N.bincount(h['surf'], minlength=len(cnt))[:5], cnt[:5])          # every surface but the dish captures
+            assert N.allclose(N.bincount(h['surf'], weights=h['e_abs'], minlength=len(a))[:5], a[:5], rtol=1e-9)
+        per_form[form] = [s.get_optics_manager().get_all_hits() for s in dish.get_surfaces()[:5]]
+    for k in range(5):
+        e0, p0 = per_form['ordered'][k][:2]
+        for form in ('megakernel', 'stream'):
+            e1, p1 = per_form[form][k][:2]
+            assert len(e1) == len(e0) and abs(e1.sum() - e0.sum()) < 1e-9 * e0.sum()
+            assert N.allclose(N.sort(p1[0]), N.sort(p0[0]), atol=1e-9)          # the same hit points, in another order
+
+
 def test_auto_form_settles_on_the_faster_one_for_a_dense_scene(ctx):
     """
     fast_kernel='auto' on a scene where the streaming form is slow (200 overlapping curved shapes, every segment a hit): the first

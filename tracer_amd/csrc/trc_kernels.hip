@@ -218,11 +218,13 @@ struct trc_result {
     PayLayout lay;
 };
 
-// Device memory.  A freed block is kept for the next request of its size class instead of going back to the driver: scripts build an
-// engine per run, and an ordered trace of 1e5 rays spent 3 of its 10 ms in hipMalloc / hipFree (a block of a few MB costs ~0.3 ms to
-// map and as much to release).  Size classes are an eighth of an octave apart (at most 12.5 % over the request); at most POOL_KEEP
-// bytes wait idle, blocks beyond POOL_BLOCK_MAX (the hit buffers of 1e8-ray runs) are never kept, and a failed hipMalloc empties the
-// pool and tries again.  Keeping a block waits for the device as hipFree would have.  TRC_DEV_POOL=0 turns the pool off.
+// Device memory.  A freed block of up to POOL_BLOCK_MAX bytes is kept for the next request of its size class instead of going back
+// to the driver: scripts build an engine per run, and an ordered trace of 1e5 rays spent 3 of its 10 ms in hipMalloc / hipFree (a
+// block of a few MB costs ~0.3 ms to map and as much to release).  Size classes are an eighth of an octave apart (at most 12.5 %
+// over the request); at most POOL_KEEP bytes wait idle, and a failed hipMalloc empties the pool and tries again.  Larger requests
+// (the hit buffers and ray tables of 1e7-ray runs and beyond) go to hipMalloc as they are and come straight back: their cost is
+// nothing next to the run, and hipMalloc of a *rounded* large size was seen to stall for 1.2 s.  Keeping a block waits for the
+// device as hipFree would have.  TRC_DEV_POOL=0 turns the pool off.
 struct DevPool {
     std::mutex mu;
     std::unordered_map<void *, std::pair<size_t, int>> live;      // block handed out -> (bytes allocated, device)
@@ -231,8 +233,8 @@ struct DevPool {
     int enabled = -1;
 };
 static DevPool g_pool;
-static const size_t POOL_KEEP = (size_t)4 << 30;
-static const size_t POOL_BLOCK_MAX = (size_t)2 << 30;
+static const size_t POOL_KEEP = (size_t)2 << 30;
+static const size_t POOL_BLOCK_MAX = (size_t)128 << 20;
 
 static bool pool_enabled() {
     if (g_pool.enabled < 0) {
@@ -262,7 +264,9 @@ static void pool_trim() {
 
 static hipError_t pool_alloc(void **out, size_t bytes) {
     *out = nullptr;
-    if (!pool_enabled()) return hipMalloc(out, bytes);
+    // large requests are neither rounded nor kept: hipMalloc of a rounded size (2 GiB, 4 GiB, 7 x 256 MiB ...) was seen to take
+    // 1.2 s where the exact size takes a millisecond
+    if (!pool_enabled() || bytes > POOL_BLOCK_MAX) return hipMalloc(out, bytes);
     const size_t cls = pool_class(bytes);
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -2014,6 +2018,29 @@ __global__ __launch_bounds__(256) void k_hits_pack(HitPack H, const uint32_t *of
     }
 }
 
+// The same, surface by surface: entry src[o] of the buffer goes to place o (src = the entries sorted by surface, stably).
+__global__ __launch_bounds__(256) void k_hits_keys(const int32_t *surf, long long n, uint32_t none, uint32_t *key, uint32_t *entry) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t s = surf[i];
+    key[i] = s < 0 ? none : (uint32_t)s;          // unwritten entries of open chunks sort behind every surface
+    entry[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void k_hits_gather(HitPack H, const uint32_t *src, long long cnt) {
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= cnt) return;
+    const uint32_t i = src[o];
+    const int32_t s = H.surf[i];
+    H.o_surf[o] = s;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (H.want[k]) H.o_col[k][o] = H.col[k][i];
+    if (H.sflags[s] & TRC_SURF_CAPTURE_LEAN) {
+        if (H.want[1]) H.o_col[1][o] = H.col[0][i];
+#pragma unroll
+        for (int k = 5; k < 8; ++k) if (H.want[k]) H.o_col[k][o] = 0.0;
+    }
+}
+
 extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, double *e_abs, double *e_in, double *px,
                                   double *py, double *pz, double *dx, double *dy, double *dz) {
     if (!sc || !n) return trc_fail(TRC_ERR_INVALID, "bad arguments");
@@ -2027,10 +2054,11 @@ extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, doub
     if (reserved == 0) return TRC_OK;
     if (reserved >= (1ll << 32)) return trc_fail(TRC_ERR_CAPACITY, "more than 2^32 entries in the hit buffer");
     // The reserved range holds unwritten entries (surface -1) where the streaming engine's chunks are still open: the caller
-    // gets the written ones, in buffer order.  They are packed on the device (copying the whole range and picking on the
+    // gets the written ones, in buffer order (one capturing surface) or surface by surface (several).  They are packed on the device (copying the whole range and picking on the
     // host was 0.11 s for the 6.5e6 receiver hits of an NSTTF step).
     double *dst[8] = {e_abs, e_in, px, py, pz, dx, dy, dz};
     uint32_t *d_flag = nullptr, *d_off = nullptr;
+    uint32_t *d_key[2] = {nullptr, nullptr}, *d_ent[2] = {nullptr, nullptr};
     void *d_tmp = nullptr;
     HitPack H;
     memset(&H, 0, sizeof(H));
@@ -2059,13 +2087,35 @@ extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, doub
             if (dst[k]) st = dev_alloc(&H.o_col[k], (size_t)cnt);
         }
         if (st) break;
-        hipLaunchKernelGGL(k_hits_pack, dim3(nblk), dim3(256), 0, sc->ctx->stream, H, (const uint32_t *)d_off, (long long)reserved);
+        int n_capture = 0;
+        for (int i = 0; i < sc->n_surf; ++i) if (sc->surfs[i].flags & TRC_SURF_CAPTURE_HITS) ++n_capture;
+        if (n_capture <= 1) {
+            hipLaunchKernelGGL(k_hits_pack, dim3(nblk), dim3(256), 0, sc->ctx->stream, H, (const uint32_t *)d_off, (long long)reserved);
+        } else {
+            // Several capturing surfaces: the caller wants each one's hits together (accountants), and regrouping eight columns
+            // on the host cost 60 ms per 1e6 hits.  A stable radix sort of (surface, entry) pairs over the bits a surface index
+            // needs, then one gather: surface by surface, buffer order inside a surface, unwritten entries behind all of them.
+            if ((st = dev_alloc(&d_key[0], (size_t)reserved)) || (st = dev_alloc(&d_key[1], (size_t)reserved)) ||
+                (st = dev_alloc(&d_ent[0], (size_t)reserved)) || (st = dev_alloc(&d_ent[1], (size_t)reserved))) break;
+            hipLaunchKernelGGL(k_hits_keys, dim3(nblk), dim3(256), 0, sc->ctx->stream, sc->d_h_surf, (long long)reserved, (uint32_t)sc->n_surf,
+                               d_key[0], d_ent[0]);
+            unsigned bits = 1;
+            while ((1u << bits) <= (unsigned)sc->n_surf) ++bits;
+            size_t sort_bytes = 0;
+            if (rocprim::radix_sort_pairs(nullptr, sort_bytes, d_key[0], d_key[1], d_ent[0], d_ent[1], (size_t)reserved, 0, bits, sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "radix_sort_pairs (size query) failed"); break; }
+            if (d_tmp) (void)hipFree(d_tmp);
+            d_tmp = nullptr;
+            if (hipMalloc(&d_tmp, sort_bytes ? sort_bytes : 1) != hipSuccess) { st = trc_fail(TRC_ERR_NOMEM, "hipMalloc failed"); break; }
+            if (rocprim::radix_sort_pairs(d_tmp, sort_bytes, d_key[0], d_key[1], d_ent[0], d_ent[1], (size_t)reserved, 0, bits, sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "radix_sort_pairs failed"); break; }
+            hipLaunchKernelGGL(k_hits_gather, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, sc->ctx->stream, H, (const uint32_t *)d_ent[1], (long long)cnt);
+        }
         if (hipStreamSynchronize(sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "k_hits_pack failed"); break; }
         if (surf && hipMemcpy(surf, H.o_surf, (size_t)cnt * 4, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
         for (int k = 0; k < 8; ++k)
             if (dst[k] && hipMemcpy(dst[k], H.o_col[k], (size_t)cnt * 8, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
     } while (0);
     dev_free(d_flag); dev_free(d_off);
+    dev_free(d_key[0]); dev_free(d_key[1]); dev_free(d_ent[0]); dev_free(d_ent[1]);
     if (d_tmp) (void)hipFree(d_tmp);
     dev_free(H.o_surf);
     for (int k = 0; k < 8; ++k) dev_free(H.o_col[k]);

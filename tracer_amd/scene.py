@@ -264,7 +264,7 @@ class DeviceScene(object):
         return a, r, h
 
     def get_hits(self):
-        """dict of the captured hits, device arrival order.  When every capturing surface is captured lean (Receiver accountants:
+        """dict of the captured hits: device arrival order for one capturing surface, surface by surface (arrival order inside) for several.  When every capturing surface is captured lean (Receiver accountants:
         absorbed energy + hit point) the columns the device did not write are not fetched either: `e_in` is the absorbed energy,
         `directions` is None."""
         n = C.c_int64(0)
@@ -469,15 +469,23 @@ def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavele
         uniq = surf_ids[start]
         stop = list(start[1:]) + [len(surf_ids)]
     else:
-        order = N.argsort(surf_ids, kind='stable')
-        sorted_ids = surf_ids[order]
-        uniq, start = N.unique(sorted_ids, return_index=True)
-        stop = list(start[1:]) + [len(order)]
+        # device arrival order (fast engine)
+        counts = N.bincount(surf_ids)
+        present = N.nonzero(counts)[0]
+        if len(present) <= 32:
+            # a few capturing surfaces: one linear pass each finds a surface's hits, in order (a sort of 1e6 keys costs ten of them)
+            order, uniq, start, stop = present, present, [None] * len(present), [None] * len(present)
+        else:
+            order = N.argsort(surf_ids, kind='stable')
+            sorted_ids = surf_ids[order]
+            start = N.r_[0, N.nonzero(sorted_ids[1:] != sorted_ids[:-1])[0] + 1]
+            uniq = sorted_ids[start]
+            stop = list(start[1:]) + [len(order)]
     for s, a, b in zip(uniq, start, stop):
         opt = surfaces[s].get_optics_manager()
         if not isinstance(opt, OpticsCallable) or not opt.accountants:
             continue
-        idx = slice(int(a), int(b)) if order is None else order[a:b]
+        idx = slice(int(a), int(b)) if order is None else (N.nonzero(surf_ids == s)[0] if a is None else order[a:b])
         surf = surfaces[s]
         pts = points[:, idx]
         dirs = None if directions is None else directions[:, idx]
