@@ -148,6 +148,7 @@ class TracerEngine(object):
 
     # -- the entry point ------------------------------------------------------------------------------
     KD_BUILD_MAX = 8192      # surfaces beyond which accel=True does not build the reference's Kd-tree for the fast engine
+    KD_WORTH_IT = 2e9        # rays x surfaces from which the ordered engine gets the reference's Kd-tree built for accel=True
     TUNE_MIN_RAYS = 1 << 21  # calls from which the two forms of the fast engine are compared on a scene (fast_kernel='auto')
     TUNE_MAX_SURFACES = 512  # ... and the scene size up to which the megakernel is worth a try
     SLOW_STREAM = 1.5e6      # segments per ms of kernel time below which the streaming form counts as slow
@@ -192,11 +193,14 @@ class TracerEngine(object):
             # complex refractive indices and spectra travel with the rays of the ordered engine only
             carries = dev.compiled.carries or (not _pending(bundle) and (bundle.is_polychromatic() or bundle.has_complex_index()))
             engine = 'ordered' if (tree or dev.compiled.splits or carries) else 'fast'
-        if accel and Kd_Tree is None and engine == 'fast':
+        if accel and Kd_Tree is None and (engine == 'fast' or (engine == 'ordered' and dev.n_surf <= 65535 and
+                                                                bundle.get_num_rays() * dev.n_surf <= self.KD_WORTH_IT)):
             # The fast engine does not walk the reference's Kd-tree: large calls search the library's own uniform grid over the same
             # geometry boxes (csrc/trc_bounds.h), small ones test the boxes themselves.  Building the tree -- the reference's SAH
             # build, Python: 38 ms for the 219 surfaces of the NSTTF field, minutes for a mesh of 1e5 faces -- before every trace
             # of a scene that moves (a day of sun positions) cost more than the traces.  engine.Kd_Tree builds it when it is read.
+            # The ordered engine walks it, but below KD_WORTH_IT box tests per bounce (rays x surfaces: a millisecond of the GPU)
+            # testing every surface's box costs less than the build: 1e5 rays on the NSTTF field took 30 ms with the tree, 3 without.
             num_surfs = dev.n_surf
             kw = dict(kwargs)
             kw.setdefault('min_leaf', 1)
@@ -227,7 +231,8 @@ class TracerEngine(object):
         if engine == 'fast':
             return self._trace_fast(dev, bundle, reps, min_energy, seed, bool(accel), hit_capacity, fast_kernel, feed, last_capacity)
         if engine == 'ordered':
-            return self._trace_ordered(dev, bundle, reps, min_energy, seed, bool(accel), tree)
+            # (no tree on the device: the call was too small for one to pay, every surface's box is tested)
+            return self._trace_ordered(dev, bundle, reps, min_energy, seed, bool(accel) and self._kd_on_device is not None, tree)
         raise ValueError("unknown engine %r" % (engine,))
 
     # -- fast engine --------------------------------------------------------------------------------
