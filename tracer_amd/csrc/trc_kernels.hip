@@ -2684,15 +2684,14 @@ struct OrdScratch {
     uint32_t *key = nullptr, *ckey = nullptr, *cslot = nullptr, *skey = nullptr, *sslot = nullptr;
     unsigned *blk_cnt = nullptr, *blk_cul = nullptr;
     unsigned long long *blk_off = nullptr, *totals = nullptr;
-    void *sort_tmp = nullptr;
+    char *sort_tmp = nullptr;
     size_t cap_slots = 0, sort_bytes = 0;
     void release() {
         for (int i = 0; i < 9; ++i) dev_free(o[i]);
         dev_free(opay);
         dev_free(orid); dev_free(key); dev_free(ckey); dev_free(cslot); dev_free(skey); dev_free(sslot);
         dev_free(blk_cnt); dev_free(blk_cul); dev_free(blk_off); dev_free(totals);
-        if (sort_tmp) (void)hipFree(sort_tmp);
-        sort_tmp = nullptr;
+        dev_free(sort_tmp);
         cap_slots = 0; sort_bytes = 0;
     }
     int ensure(size_t slots, int n_pay) {
@@ -2712,9 +2711,9 @@ struct OrdScratch {
     }
     int ensure_sort(size_t bytes) {
         if (bytes <= sort_bytes && sort_tmp) return TRC_OK;
-        if (sort_tmp) (void)hipFree(sort_tmp);
-        sort_tmp = nullptr; sort_bytes = 0;
-        if (hipMalloc(&sort_tmp, bytes ? bytes : 1) != hipSuccess) return trc_fail(TRC_ERR_NOMEM, "sort scratch allocation failed");
+        dev_free(sort_tmp);
+        sort_bytes = 0;
+        TRC_TRY(dev_alloc(&sort_tmp, bytes));
         sort_bytes = bytes;
         return TRC_OK;
     }
