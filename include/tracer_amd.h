@@ -280,6 +280,18 @@ int trc_scene_set_fluxmap(trc_scene *scene, int32_t surf, int32_t nu, int32_t nv
 int trc_scene_set_hit_capacity(trc_scene *scene, int64_t capacity);
 /* empty the hit buffer (the accountants' per-trace lists live on the Python side) */
 int trc_scene_clear_hits(trc_scene *scene);
+/* A hit buffer of at least `capacity` hits that keeps what it holds (set_hit_capacity starts an empty one): the accountants of
+   the reference accumulate over calls until they are reset (optics_callables.py:1577-1643), so a script that traces again
+   before it has read the hits of its last call leaves them on the device and reads them all at once later. */
+int trc_scene_reserve_hits(trc_scene *scene, int64_t capacity);
+/* entries of the hit buffer reserved so far -- written hits and the unused parts of the chunks the streaming engine keeps
+   open -- and the capacity last asked for.  Either pointer may be NULL. */
+int trc_scene_hits_reserved(trc_scene *scene, int64_t *reserved, int64_t *capacity);
+/* Page-locked host memory for the large results of this library (the hit lists behind get_all_hits(), the levels of
+   engine.tree, trace_tree.py:6-55): device-to-host copies into it run at the rate of the link.  Freed blocks are kept for
+   the next request of their size. */
+int trc_host_alloc(int64_t bytes, void **out);
+int trc_host_free(void *p);
 /* Assembly.reset_all_optics() (assembly.py:148-151) */
 int trc_scene_reset_tallies(trc_scene *scene);
 /* per-surface totals: absorbed = sum(E_in - sum E_out) (AbsorptionAccountant :1638-1643),

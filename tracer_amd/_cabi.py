@@ -6,6 +6,7 @@ __graft_entry__.build()).  There is no CPU implementation behind this module: if
 missing, or no GPU is present when a context is created, the caller gets an exception.
 """
 import ctypes as C
+import weakref
 import os
 import threading
 
@@ -102,6 +103,10 @@ SIGNATURES = {
     'trc_scene_set_fluxmap': (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _p_f64, _p_f64, _p_f64]),
     'trc_scene_set_hit_capacity': (C.c_int, [_vp, C.c_int64]),
     'trc_scene_clear_hits': (C.c_int, [_vp]),
+    'trc_scene_reserve_hits': (C.c_int, [_vp, C.c_int64]),
+    'trc_scene_hits_reserved': (C.c_int, [_vp, _p_i64, _p_i64]),
+    'trc_host_alloc': (C.c_int, [C.c_int64, _pvp]),
+    'trc_host_free': (C.c_int, [_vp]),
     'trc_scene_reset_tallies': (C.c_int, [_vp]),
     'trc_scene_get_tallies': (C.c_int, [_vp, _p_f64, _p_f64, _p_i64]),
     'trc_scene_get_fluxmap': (C.c_int, [_vp, C.c_int32, _p_f64]),
@@ -199,6 +204,29 @@ class TracerAmdUnsupported(TracerAmdError, NotImplementedError):
 def f64(a):
     """C-contiguous float64 view/copy of a."""
     return N.ascontiguousarray(a, dtype=N.float64)
+
+
+PINNED_FROM = 1 << 20       # bytes from which a result array is placed in page-locked memory (pinned_empty)
+
+
+def pinned_empty(shape, dtype=N.float64):
+    """
+    An uninitialised array for a large result of the library -- a hit list, a level of the ray tree -- in page-locked host
+    memory (trc_host_alloc): the device-to-host copy into it runs at the rate of the link instead of through the driver's
+    bounce buffers.  The block goes back to the library's pool when the last view of the array is gone.  Small arrays
+    are ordinary numpy arrays.
+    """
+    dtype = N.dtype(dtype)
+    shape = (shape,) if N.isscalar(shape) else tuple(shape)
+    nbytes = int(N.prod(shape, dtype=N.int64)) * dtype.itemsize
+    if nbytes < PINNED_FROM:
+        return N.empty(shape, dtype=dtype)
+    lib = load_library()
+    p = C.c_void_p()
+    check(lib.trc_host_alloc(nbytes, C.byref(p)))
+    buf = (C.c_char * nbytes).from_address(p.value)
+    weakref.finalize(buf, lib.trc_host_free, C.c_void_p(p.value))
+    return N.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
 def ptr(a, typ=_p_f64):

@@ -1186,11 +1186,17 @@ TRC_HD double trc_hg_theta(double g, double Rv) {
     return acos(c);
 }
 
-TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int extra_off, int extra_len,
+// KINDS: bit mask of the optics kinds the caller promises (the compiler drops the others); FULL = false further promises that no
+// surface has an Incidence Angle Modifier and no Lambertian wall stands in an absorbing medium (a_r == 0, opt[2] == 0): the
+// class-split shading kernels of the streaming engine are built from these.  The arithmetic of a kind is the same in every
+// instance (a factor of exactly 1.0 is left out).
+template <unsigned KINDS, bool FULL>
+TRC_HD int trc_shade_k(int opt_kind, const double *opt, const double *extra, int extra_off, int extra_len,
                      double ux, double uy, double uz, double dx, double dy, double dz, double e, double ref,
                      double wl, double path, double nx, double ny, double nz, uint64_t seed, uint64_t rid,
                      uint32_t event, trc_ray_out out[2]) {
     // path: distance the ray travelled to this hit (Absorbant.attenuate, optics_callables.py:874-889: |hit - previous vertex|)
+    if (opt_kind >= 0 && opt_kind < 32 && !((KINDS >> opt_kind) & 1u)) __builtin_unreachable();
     out[0].ref = ref;
     out[0].blk = 0;
     out[1].blk = 1;
@@ -1205,7 +1211,8 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
     case TRC_OPT_REFLECTIVE:
     case TRC_OPT_ONE_SIDED_REFLECTIVE: {                            // :130-140, :201-212
         trc_reflect(dx, dy, dz, nx, ny, nz, &out[0].dx, &out[0].dy, &out[0].dz);
-        double eo = e * (1.0 - opt[0]) * trc_iam(opt[1], opt[2], dx, dy, dz, nx, ny, nz);       // Reflective_IAM :283-300
+        double eo = e * (1.0 - opt[0]);
+        if (FULL) eo *= trc_iam(opt[1], opt[2], dx, dy, dz, nx, ny, nz);       // Reflective_IAM :283-300
         if (opt_kind == TRC_OPT_ONE_SIDED_REFLECTIVE && (dx * ux + dy * uy + dz * uz) > 0.0) eo = 0.0;
         out[0].e = eo;
         out[0].sf = 1.0 - opt[0];                                   // :137-138
@@ -1234,7 +1241,8 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
             rx *= inv; ry *= inv; rz *= inv;
         }
         trc_reflect(dx, dy, dz, rx, ry, rz, &out[0].dx, &out[0].dy, &out[0].dz);
-        double eo = e * (1.0 - opt[0]) * trc_iam(opt[3], opt[4], dx, dy, dz, nx, ny, nz);       // RealReflective_IAM :320-329 (ideal normal)
+        double eo = e * (1.0 - opt[0]);
+        if (FULL) eo *= trc_iam(opt[3], opt[4], dx, dy, dz, nx, ny, nz);       // RealReflective_IAM :320-329 (ideal normal)
         if (opt_kind == TRC_OPT_ONE_SIDED_REAL_REFLECTIVE && (dx * ux + dy * uy + dz * uz) > 0.0) eo = 0.0;
         out[0].e = eo;
         out[0].sf = 1.0 - opt[0];                                   // :266-267
@@ -1245,9 +1253,10 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
         trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
         trc_pillbox_dir(TRC_TWO_PI * u0, u1, opt[1], &ax, &ay, &az);
         trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
-        if (opt[2] != 0.0) out[0].e = e * exp(-opt[2] * (path * opt[3])) * (1.0 - opt[0]);      // LambertianAbsorbant :895-906
+        if (FULL && opt[2] != 0.0) out[0].e = e * exp(-opt[2] * (path * opt[3])) * (1.0 - opt[0]);      // LambertianAbsorbant :895-906
         else {
-            out[0].e = e * (1.0 - opt[0]) * trc_iam(opt[4], opt[5], dx, dy, dz, nx, ny, nz);   // Lambertian_IAM :302-318
+            out[0].e = e * (1.0 - opt[0]);
+            if (FULL) out[0].e *= trc_iam(opt[4], opt[5], dx, dy, dz, nx, ny, nz);   // Lambertian_IAM :302-318
             out[0].sf = 1.0 - opt[0];                               // :173-174 (LambertianAbsorbant builds its Lambertian with 0, :897)
         }
         return 1;
@@ -1367,6 +1376,14 @@ TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int e
         out[0].dx = dx; out[0].dy = dy; out[0].dz = dz; out[0].e = 0.0;
         return 1;
     }
+}
+
+TRC_HD int trc_shade(int opt_kind, const double *opt, const double *extra, int extra_off, int extra_len,
+                     double ux, double uy, double uz, double dx, double dy, double dz, double e, double ref,
+                     double wl, double path, double nx, double ny, double nz, uint64_t seed, uint64_t rid,
+                     uint32_t event, trc_ray_out out[2]) {
+    return trc_shade_k<0xFFFFFFFFu, true>(opt_kind, opt, extra, extra_off, extra_len, ux, uy, uz, dx, dy, dz, e, ref, wl, path, nx, ny, nz,
+                                          seed, rid, event, out);
 }
 
 

@@ -32,6 +32,7 @@
 #include "trc_core.h"
 #include "trc_bounds.h"
 #include "trc_footprint.h"
+#include "trc_device.h"
 
 // ================================================================================================
 // error handling
@@ -73,66 +74,6 @@ struct trc_ctx {
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     int n_cu;
-};
-
-struct FluxMapDev {
-    int32_t surf, nu, nv, pad;
-    int64_t edges_u, edges_v;  // offsets into fm_edges
-    int64_t bins;              // offset into the tally buffer
-    double proj[12];           // global -> local (rows 0..2 of round(inv(frame), 9), surface.py:125)
-};
-
-// device view of a scene, passed by value to kernels
-struct DScene {
-    const double *recs;
-    const double *opt;       // n_surf * 8
-    const int32_t *sflags;   // n_surf
-    const double *extra;
-    int32_t stride, n_surf, n_extra, has_kd;
-    // Kd-tree
-    const int32_t *kd_a, *kd_b, *kd_leaf, *kd_always;
-    const double *kd_split;
-    int32_t kd_nodes, kd_nleaf, kd_nalways, kd_pad;
-    double kd_bmin[3], kd_bmax[3];
-    // single-precision acceleration data (trc_bounds.h)
-    const float *a_sbox;
-    const float *a_obb;        // TRC_OBB_STRIDE floats per surface: oriented boxes (trc_obb_hit32)
-    const uint32_t *a_nodes;
-    const uint16_t *a_leaf;
-    const int32_t *a_unbounded;
-    const uint16_t *a_bleaf;
-    int32_t a_n_unbounded, a_kd_depth, a_ok, a_kd_ok;
-    int32_t a_n_bleaf, a_pad2;
-    uint32_t a_bnodes[2];
-    float a_broot[6];
-    float a_root[6];
-    float a_delta, a_pad;
-    double a_cen[3], a_slo[3], a_shi[3];
-    // uniform grid (streaming engine)
-    const uint16_t *a_goff, *a_glist;
-    const int32_t *a_gapart;    // bounded surfaces kept out of the grid (box-tested for every ray)
-    int32_t a_g_ok, a_g_ncell, a_g_nlist, a_g_napart, a_gdim[3];
-    float a_glo[3], a_gcs[3], a_ginv[3], a_groot[6];
-    // the grid of scenes too large for LDS (trc_accel_build_grid32): 32-bit offsets and lists in global memory
-    const uint32_t *a_bg_off, *a_bg_list;
-    const int32_t *a_bg_apart;  // bounded surfaces kept out of that grid (box-tested for every ray)
-    int32_t a_bg_napart, a_bg_pad;
-    int32_t a_bg_ok, a_bg_dim[3];
-    float a_bg_lo[3], a_bg_cs[3], a_bg_inv[3], a_bg_root[6];
-    // tallies: [absorbed S | received S | count S | segments, hits | flux bins ... | transfer (S+1) x S]
-    double *tally;
-    long long tr_off;           // offset of the surface-to-surface transfer matrix in `tally`, -1 when it is not kept
-    // flux maps
-    int32_t n_fm, n_fm_edges;   // flux maps and the total length of their edge arrays
-    const int32_t *fm_of_surf;  // n_surf, -1 = none
-    const FluxMapDev *fms;
-    const double *fm_edges;
-    // hit capture
-    unsigned long long *counters;  // [0] hit cursor, [1] hits dropped, [2] last cursor, [3] rays left
-    double *energy_left;
-    long long hit_cap;
-    int32_t *h_surf;
-    double *h_eabs, *h_ein, *h_px, *h_py, *h_pz, *h_dx, *h_dy, *h_dz;
 };
 
 struct trc_scene {
@@ -188,6 +129,7 @@ struct trc_scene {
     int64_t hit_cap;      // entries allocated: the capacity asked for + TRC_HIT_SLACK
     int64_t hit_cap_user;
     uint32_t hit_epoch;   // bumped whenever the cursor is reset: chunks left open by earlier launches are stale
+    uint32_t hit_chunk;   // entries a wave of the streaming engine's shading kernels reserves per atomic (set with the capacity)
     int32_t *d_h_surf;
     double *d_h[8];
 };
@@ -328,236 +270,6 @@ static void dev_free(T *&p) {
     if (p) pool_free((void *)p);
     p = nullptr;
 }
-
-// ================================================================================================
-// device helpers
-// ================================================================================================
-struct LocalKdStack {
-    int node[TRC_KD_STACK];
-    float tmax[TRC_KD_STACK];
-    __device__ __forceinline__ void push(int sp, int n, double t) {
-        node[sp] = n;
-        tmax[sp] = __double2float_ru(t);  // rounded up: the interval only ever grows (conservative)
-    }
-    __device__ __forceinline__ void pop(int sp, int *n, double *t) {
-        *n = node[sp];
-        *t = (double)tmax[sp];
-    }
-};
-
-__device__ __forceinline__ trc_kd_view make_kd_view(const DScene &sc, const int32_t *a, const int32_t *b,
-                                                    const double *split, const int32_t *leaf,
-                                                    const int32_t *always) {
-    trc_kd_view kd;
-    kd.node_a = a; kd.node_b = b; kd.split = split; kd.leaf_surfs = leaf; kd.always = always;
-    kd.n_always = sc.kd_nalways;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { kd.bmin[i] = sc.kd_bmin[i]; kd.bmax[i] = sc.kd_bmax[i]; }
-    return kd;
-}
-
-__device__ __forceinline__ unsigned lane_id() { return __lane_id(); }
-
-// wave-level sum of a double (64 lanes)
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// Queue append without a hot atomic: a wave reserves CHUNK entries at a time from the global counter (one atomic per
-// chunk; a single word sustains only ~88 returning atomics per microsecond) and fills them; what is left of a chunk
-// when the wave moves on is marked invalid and skipped by the consumers.  base/used are wave-uniform.
-#ifndef SQ_CHUNK
-#define SQ_CHUNK 256
-#endif
-#define SQ_INVALID 0xFFFFFFFFu
-
-#define SQ_CHUNK_MAX 1024        /* large launches reserve more per atomic; queue slack is sized for this */
-
-struct WaveChunk {
-    unsigned long long base;
-    unsigned used;
-    unsigned open;
-    unsigned size;      // entries reserved per atomic (SQ_CHUNK, or up to SQ_CHUNK_MAX in the largest launches)
-};
-
-__device__ __forceinline__ WaveChunk chunk_init(unsigned size = SQ_CHUNK) {
-    WaveChunk c;
-    c.base = 0; c.used = size; c.open = 0; c.size = size;
-    return c;
-}
-
-// The first chunk of a wave can be handed out without an atomic: chunk number `wave` of a queue whose counter the host
-// starts at (number of waves) * size.  Every wave of a launch reserving its first chunk at the same moment is otherwise
-// thousands of atomics on one word before any work starts (~88 per microsecond).  A wave that never appends leaves the
-// whole chunk marked invalid (chunk_close).
-__device__ __forceinline__ WaveChunk chunk_init_static(unsigned size, unsigned long long wave) {
-    WaveChunk c;
-    c.base = wave * size; c.used = 0; c.open = 1; c.size = size;
-    return c;
-}
-
-// the same with the chunk's first entry given (chunks of different sizes pre-assigned in one list)
-__device__ __forceinline__ WaveChunk chunk_init_static_at(unsigned size, unsigned long long base) {
-    WaveChunk c;
-    c.base = base; c.used = 0; c.open = 1; c.size = size;
-    return c;
-}
-
-// after a chunk_append made by a subset of the lanes: every lane takes the state of `lane` (one that took part)
-__device__ __forceinline__ void chunk_rebroadcast(WaveChunk &c, int lane) {
-    c.base = __shfl(c.base, lane, 64);
-    c.used = (unsigned)__shfl((int)c.used, lane, 64);
-    c.open = (unsigned)__shfl((int)c.open, lane, 64);
-    c.size = (unsigned)__shfl((int)c.size, lane, 64);
-}
-
-// marks the unused tail of the current chunk invalid (wave-uniform call)
-__device__ __forceinline__ void chunk_close(WaveChunk &c, uint32_t *tag, long long cap) {
-    if (c.open) {
-        for (unsigned k = c.used + lane_id(); k < c.size; k += 64)
-            if ((long long)(c.base + k) < cap) tag[c.base + k] = SQ_INVALID;
-    }
-    c.open = 0;
-    c.used = c.size;
-}
-
-// returns this lane's index in the queue (meaningful when `want`).  Call it with the whole wave, or -- inside a
-// divergent region -- re-broadcast the chunk afterwards from a lane that took part (chunk_rebroadcast).  A request that does not fit the
-// open chunk fills it up and continues in a new one, so entries are only wasted at the end of a kernel (< CHUNK per wave).
-__device__ __forceinline__ unsigned long long chunk_append(unsigned long long *counter, WaveChunk &c, bool want, uint32_t *tag,
-                                                           long long cap) {
-    unsigned long long m = __ballot(want);
-    if (!m) return 0;
-    const unsigned need = (unsigned)__popcll(m);
-    const unsigned rank = (unsigned)__popcll(m & ((1ull << lane_id()) - 1ull));
-    unsigned long long idx;
-    if (c.used + need > c.size) {
-        const unsigned rem = c.open ? c.size - c.used : 0u;
-        const unsigned long long old_pos = c.base + c.used;
-        const int leader = __ffsll((long long)m) - 1;          // a lane that is certainly active here
-        unsigned long long b = 0;
-        if ((int)lane_id() == leader) b = atomicAdd(counter, (unsigned long long)c.size);
-        c.base = __shfl(b, leader, 64);
-        c.used = need - rem;
-        c.open = 1;
-        idx = rank < rem ? old_pos + rank : c.base + (rank - rem);
-    } else {
-        idx = c.base + c.used + rank;
-        c.used += need;
-    }
-    (void)tag; (void)cap;
-    return idx;
-}
-
-#define SHADE_MAX_WAVES 4096     /* waves of one k_s_shade launch (at most n_cu * 4 workgroups of 4 waves, n_cu <= 256) */
-#define SQ_HIT_CHUNK 1024        /* entries of the hit buffer a wave of k_s_shade reserves per atomic: the cursor is one word (~88 returning
-                                    atomics per microsecond), and at 256 the 12 000 reservations of an NSTTF batch were half of the kernel */
-#define TRC_HIT_SLACK (8ll * SHADE_MAX_WAVES * SQ_HIT_CHUNK + 64)   /* unused entries the open chunks of four slots can hold (k_s_shade and
-                                                                     k_s_absorb each keep one open chunk per wave and slot) */
-#define TRC_SURF_TERMINAL 0x10000   /* device copy of the surface flags only: every ray that lands here ends here -- the optics absorb all of
-                                       it whatever the angle (absorptivity 1, no incidence-angle factor): no direction needs to be drawn */
-
-// per-hit bookkeeping shared by both engines: tallies, flux map, hit capture
-template <bool LDS_TALLY>
-__device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, int s, double e_in,
-                                           double e_abs, double hx, double hy, double hz, double dx,
-                                           double dy, double dz, bool capture_enabled, int prev, WaveChunk *hc = nullptr,
-                                           double *lds_fm = nullptr, bool volume = false, bool tallied = false) {
-    // tallied: the caller has added the three per-surface sums itself (k_s_absorb: once per wave)
-    // volume: the ray was scattered in the medium before it reached the surface -- nothing is recorded, but the lane takes part
-    // in the appends of the wave below (their bookkeeping is per wave)
-    const int S = sc.n_surf;
-    // energy carried from the surface the ray left (S = the source) to the one it lands on
-    if (sc.tr_off >= 0 && !volume) atomicAdd(&sc.tally[sc.tr_off + (long long)prev * S + s], e_in);
-    if (volume || tallied) {
-    } else if (LDS_TALLY) {
-        atomicAdd(&lds_tally[s], e_abs);
-        atomicAdd(&lds_tally[S + s], e_in);
-        atomicAdd(&lds_tally[2 * S + s], 1.0);
-    } else {
-        atomicAdd(&sc.tally[s], e_abs);
-        atomicAdd(&sc.tally[S + s], e_in);
-        atomicAdd(&sc.tally[2 * S + s], 1.0);
-    }
-    int fm = (!volume && sc.fm_of_surf) ? sc.fm_of_surf[s] : -1;
-    if (fm >= 0) {
-        const FluxMapDev &m = sc.fms[fm];
-        double u = m.proj[0] * hx + m.proj[1] * hy + m.proj[2] * hz + m.proj[3];
-        double v = m.proj[4] * hx + m.proj[5] * hy + m.proj[6] * hz + m.proj[7];
-        int iu = trc_bin_index(sc.fm_edges + m.edges_u, m.nu, u);
-        int iv = trc_bin_index(sc.fm_edges + m.edges_v, m.nv, v);
-        if (iu >= 0 && iv >= 0) {
-            // lds_fm: the workgroup's private copy of all flux-map bins (they follow the 3S+2 per-surface sums in the tally buffer);
-            // scattered global float64 atomics run at ~1/17 of the rate of the contiguous ones the copy is flushed with
-            if (lds_fm) atomicAdd(&lds_fm[m.bins - (3 * (int64_t)S + 2) + (int64_t)iu * m.nv + iv], e_abs);
-            else atomicAdd(&sc.tally[m.bins + (int64_t)iu * m.nv + iv], e_abs);
-        }
-    }
-    if (capture_enabled && hc) {
-        // chunked append (streaming engine): one atomic per 256 captured hits instead of one per wave and iteration --
-        // the cursor of the hit buffer is a single word, and a word sustains only ~88 returning atomics per microsecond
-        const int fl = sc.sflags[s];
-        bool want = !volume && (fl & TRC_SURF_CAPTURE_HITS) != 0;
-        unsigned long long slot = chunk_append(&sc.counters[0], *hc, want, nullptr, 0);
-        if (want) {
-            if ((long long)slot < sc.hit_cap) {
-                sc.h_surf[slot] = s;
-                sc.h_eabs[slot] = e_abs;
-                sc.h_px[slot] = hx; sc.h_py[slot] = hy; sc.h_pz[slot] = hz;
-                if (!(fl & TRC_SURF_CAPTURE_LEAN)) { sc.h_ein[slot] = e_in; sc.h_dx[slot] = dx; sc.h_dy[slot] = dy; sc.h_dz[slot] = dz; }
-            } else {
-                atomicAdd(&sc.counters[1], 1ull);
-            }
-        }
-    } else if (capture_enabled) {
-        // wave-aggregated append: one atomic per wave per iteration
-        const int fl = sc.sflags[s];
-        bool want = !volume && (fl & TRC_SURF_CAPTURE_HITS) != 0;
-        unsigned long long mask = __ballot(want);
-        if (mask) {
-            int leader = __ffsll((long long)mask) - 1;
-            unsigned long long base = 0;
-            if ((int)lane_id() == leader) base = atomicAdd(&sc.counters[0], (unsigned long long)__popcll(mask));
-            base = __shfl(base, leader, 64);
-            if (want) {
-                unsigned long long slot = base + __popcll(mask & ((1ull << lane_id()) - 1ull));
-                if ((long long)slot < sc.hit_cap) {
-                    sc.h_surf[slot] = s;
-                    sc.h_eabs[slot] = e_abs;
-                    sc.h_px[slot] = hx; sc.h_py[slot] = hy; sc.h_pz[slot] = hz;
-                    if (!(fl & TRC_SURF_CAPTURE_LEAN)) { sc.h_ein[slot] = e_in; sc.h_dx[slot] = dx; sc.h_dy[slot] = dy; sc.h_dz[slot] = dz; }
-                } else {
-                    atomicAdd(&sc.counters[1], 1ull);
-                }
-            }
-        }
-    }
-}
-
-// ================================================================================================
-// fast engine
-// ================================================================================================
-struct FastParams {
-    DScene sc;
-    // given bundle (NULL when a source descriptor is used)
-    const double *x, *y, *z, *dx, *dy, *dz, *e, *ref, *wl;
-    const uint64_t *rid;
-    const trc_source_desc *src;  // device copy
-    long long n;
-    int reps;
-    int flags;
-    double min_energy;
-    unsigned long long seed, ray_offset;
-    // rays left after `reps` bounces
-    double *lx, *ly, *lz, *ldx, *ldy, *ldz, *le;
-    long long last_cap;
-    // LDS carve-up (in doubles / flags)
-    int lds_scene;    // surfaces (+ Kd arrays) staged in LDS
-    int lds_tally;    // tallies privatised in LDS
-    int capture;      // some surface captures hits
-};
 
 // ------------------------------------------------------------------------------------------------
 // Wave-cooperative fast path (k_trace_coop).  Same candidates, same exact float64 tests and the same winner as
@@ -728,60 +440,6 @@ __device__ __forceinline__ void coop_drain_leaves(const trc_accel_view &A, const
         }
     }
     WAVE_SYNC();
-}
-
-// optics kinds of the "mirrors and diffuse walls" family: what a heliostat field, a dish or a cavity of opaque walls is made of.
-// A scene of flat surfaces with only these gets an instance of k_s_shade that carries nothing else (SIMPLE below).
-#define TRC_OPT_SIMPLE_MASK ((1u << TRC_OPT_TRANSPARENT) | (1u << TRC_OPT_REFLECTIVE) | (1u << TRC_OPT_ONE_SIDED_REFLECTIVE) | \
-                             (1u << TRC_OPT_REAL_REFLECTIVE) | (1u << TRC_OPT_ONE_SIDED_REAL_REFLECTIVE) | (1u << TRC_OPT_LAMBERTIAN) | \
-                             (1u << TRC_OPT_LAMBERTIAN_SPECULAR))
-
-// shading + bookkeeping of one hit, shared by the two fast kernels.  Returns false when the ray stops here.
-// SIMPLE promises a flat geometry kind and an optics kind of TRC_OPT_SIMPLE_MASK on every surface: the compiler drops the rest.
-template <bool LDS_TALLY, bool SIMPLE = false>
-__device__ __forceinline__ bool fast_shade(const FastParams &P, const double *recs, double *l_tally, double t, int s, double &px,
-                                           double &py, double &pz, double &dx, double &dy, double &dz, double &e, double &ref,
-                                           double wl, unsigned long long rid, int &bounce, int &prev, WaveChunk *hc = nullptr,
-                                           double *lds_fm = nullptr, bool tallied = false, bool *was_volume = nullptr) {
-    // tallied: the caller adds the three per-surface sums itself (k_s_shade: per wave), unless *was_volume comes back true
-    const DScene &sc = P.sc;
-    bounce += 1;
-    const double *rec = recs + (size_t)s * sc.stride;
-    double hx = px + t * dx, hy = py + t * dy, hz = pz + t * dz;
-    double nx, ny, nz;
-    if (SIMPLE && !trc_gm_is_flat(trc_rec_gm_kind(rec))) __builtin_unreachable();
-    trc_normal(rec, hx, hy, hz, dx, dy, dz, &nx, &ny, &nz);
-    trc_ray_out out[2];
-    const double path = sqrt((hx - px) * (hx - px) + (hy - py) * (hy - py) + (hz - pz) * (hz - pz));
-    if (SIMPLE && !((TRC_OPT_SIMPLE_MASK >> trc_rec_opt_kind(rec)) & 1u)) __builtin_unreachable();
-    int n_out = trc_shade(trc_rec_opt_kind(rec), sc.opt + (size_t)s * 8, sc.extra, trc_rec_extra_off(rec), trc_rec_extra_len(rec),
-                          rec[2], rec[5], rec[8], dx, dy, dz, e, ref, wl, path, nx, ny, nz, P.seed, rid, (uint32_t)bounce, out);
-    (void)n_out;  // scenes whose optics split rays are routed to the ordered engine by the host
-    // a volume event (scattering in the medium): the ray never reached the surface -- it goes on from a point before the hit,
-    // the surface records nothing, the surface the ray left stays the one it left
-    const bool volume = out[0].back > 0.0;
-    if (was_volume) *was_volume = volume;
-    if (volume) { hx -= out[0].back * dx; hy -= out[0].back * dy; hz -= out[0].back * dz; }
-    double e_abs = e - out[0].e;
-    record_hit<LDS_TALLY>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0, prev, hc, lds_fm, volume, tallied);
-    if (!volume) prev = s;
-    px = hx; py = hy; pz = hz;
-    dx = out[0].dx; dy = out[0].dy; dz = out[0].dz;
-    e = out[0].e; ref = out[0].ref;
-    if (e <= P.min_energy) return false;                      // tracer_engine.py:242
-    if (bounce >= P.reps) {                                   // still alive after the last iteration
-        atomicAdd(&sc.counters[3], 1ull);
-        atomicAdd(sc.energy_left, e);
-        if (P.flags & TRC_TRACE_KEEP_LAST) {
-            unsigned long long slot = atomicAdd(&sc.counters[2], 1ull);
-            if ((long long)slot < P.last_cap) {
-                P.lx[slot] = px; P.ly[slot] = py; P.lz[slot] = pz;
-                P.ldx[slot] = dx; P.ldy[slot] = dy; P.ldz[slot] = dz; P.le[slot] = e;
-            }
-        }
-        return false;
-    }
-    return true;
 }
 
 // fresh ray for a lane: from the source descriptor or from the given bundle
@@ -1669,6 +1327,7 @@ static int scene_upload_surfaces(trc_scene *sc) {
                            ((ok == TRC_OPT_REAL_REFLECTIVE || ok == TRC_OPT_ONE_SIDED_REAL_REFLECTIVE) && sd.opt[3] == 0.0) ||
                            (ok == TRC_OPT_LAMBERTIAN && sd.opt[2] == 0.0 && sd.opt[4] == 0.0) || ok == TRC_OPT_LAMBERTIAN_SPECULAR;
         if (plain && sd.opt[0] == 1.0) flags[i] |= TRC_SURF_TERMINAL;
+        flags[i] |= trc_shade_class_of(sd) << TRC_SURF_CLS_SHIFT;      // which shading kernel of the streaming engine serves the surface
     }
     HIP_TRY(hipMemcpy(sc->d_recs, recs.data(), recs.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(sc->d_opt, opt.data(), opt.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1913,7 +1572,11 @@ extern "C" int trc_scene_set_hit_capacity(trc_scene *sc, int64_t capacity) {
     HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
     // the same capacity again (an engine sizes the buffer before every trace): the buffer is kept and emptied -- freeing and
     // allocating 15 GB per call was a tenth of a second at 1e8 rays
-    if (capacity > 0 && capacity == sc->hit_cap_user && sc->d_h_surf) return scene_reset_hit_buffer(sc);
+    if (capacity > 0 && capacity == sc->hit_cap_user && sc->d_h_surf) {
+        HIP_TRY(hipMemset(sc->d_counters, 0, 2 * sizeof(unsigned long long)));      // cursor and dropped count start over
+        sc->cnt_host[0] = sc->cnt_host[1] = 0ull;
+        return scene_reset_hit_buffer(sc);
+    }
     dev_free(sc->d_h_surf);
     for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
     sc->hit_cap = 0;
@@ -1922,8 +1585,14 @@ extern "C" int trc_scene_set_hit_capacity(trc_scene *sc, int64_t capacity) {
     HIP_TRY(hipMemset(sc->d_counters, 0, 2 * sizeof(unsigned long long)));
     sc->cnt_host[0] = sc->cnt_host[1] = 0ull;
     if (capacity == 0) return TRC_OK;
-    // the streaming engine appends in chunks that stay open between launches: room for what they can leave unused
-    const int64_t slack = (4 * capacity + 4096 < TRC_HIT_SLACK) ? 4 * capacity + 4096 : TRC_HIT_SLACK;   // small buffers see few waves
+    // The streaming engine appends in chunks that stay open between launches: room for what they can leave unused.  The chunk
+    // follows the buffer -- 1024 entries per atomic for the buffers of full-size runs (the cursor is one word), less for modest
+    // ones -- and the slack is what every wave that can hold an open chunk may leave unused of one: a call whose hits fit the
+    // capacity asked for never drops one, whatever its size.
+    int64_t chunk = 64;          // (never below a wave's worth: one append of a wave must fit a fresh chunk)
+    while (chunk < SQ_HIT_CHUNK && 2048 * (chunk * 2) <= capacity) chunk *= 2;
+    sc->hit_chunk = (uint32_t)chunk;
+    const int64_t slack = TRC_HIT_HOLDERS * chunk + 64;
     const int64_t alloc = capacity + slack;
     TRC_TRY(dev_alloc(&sc->d_h_surf, (size_t)alloc));
     for (int i = 0; i < 8; ++i) TRC_TRY(dev_alloc(&sc->d_h[i], (size_t)alloc));
@@ -1931,6 +1600,120 @@ extern "C" int trc_scene_set_hit_capacity(trc_scene *sc, int64_t capacity) {
     sc->hit_dirty_to = 0;
     sc->hit_cap = alloc;
     sc->hit_cap_user = capacity;
+    return TRC_OK;
+}
+
+// A buffer of at least `capacity` hits that keeps what it holds: the accountants of a script that traces again before it has
+// read the hits of its last call (optics_callables.py:1577-1643 accumulate over calls) are served from the device when they are
+// read at last.  Grows by half at least; the chunk size stays (chunks left open by earlier launches go on being filled).
+extern "C" int trc_scene_reserve_hits(trc_scene *sc, int64_t capacity) {
+    if (!sc || capacity < 0) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    if (!sc->d_h_surf || sc->hit_cap_user == 0) return trc_scene_set_hit_capacity(sc, capacity);
+    if (capacity <= sc->hit_cap_user) return TRC_OK;
+    HIP_TRY(hipSetDevice(sc->ctx->device));
+    HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+    if (capacity < sc->hit_cap_user + sc->hit_cap_user / 2) capacity = sc->hit_cap_user + sc->hit_cap_user / 2;
+    unsigned long long c[2];
+    HIP_TRY(hipMemcpy(c, sc->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    const int64_t used = (int64_t)c[0] < sc->hit_cap ? (int64_t)c[0] : sc->hit_cap;
+    const int64_t alloc = capacity + (sc->hit_cap - sc->hit_cap_user);
+    int32_t *n_surf = nullptr;
+    double *n_col[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int st = dev_alloc(&n_surf, (size_t)alloc);
+    for (int i = 0; i < 8 && st == TRC_OK; ++i) st = dev_alloc(&n_col[i], (size_t)alloc);
+    if (st != TRC_OK) { dev_free(n_surf); for (int i = 0; i < 8; ++i) dev_free(n_col[i]); return st; }
+    HIP_TRY(hipMemset(n_surf, 0xFF, (size_t)alloc * sizeof(int32_t)));
+    if (used > 0) {
+        HIP_TRY(hipMemcpy(n_surf, sc->d_h_surf, (size_t)used * sizeof(int32_t), hipMemcpyDeviceToDevice));
+        for (int i = 0; i < 8; ++i) HIP_TRY(hipMemcpy(n_col[i], sc->d_h[i], (size_t)used * sizeof(double), hipMemcpyDeviceToDevice));
+    }
+    dev_free(sc->d_h_surf);
+    for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
+    sc->d_h_surf = n_surf;
+    for (int i = 0; i < 8; ++i) sc->d_h[i] = n_col[i];
+    sc->hit_dirty_to = used;
+    sc->hit_cap = alloc;
+    sc->hit_cap_user = capacity;
+    return TRC_OK;
+}
+
+// entries of the hit buffer reserved so far (written ones and the unused parts of chunks still open) and its capacity
+extern "C" int trc_scene_hits_reserved(trc_scene *sc, int64_t *reserved, int64_t *capacity) {
+    if (!sc) return trc_fail(TRC_ERR_INVALID, "scene is NULL");
+    if (reserved) {
+        if (sc->cnt_host_ok) *reserved = (int64_t)sc->cnt_host[0];
+        else {
+            HIP_TRY(hipSetDevice(sc->ctx->device));
+            HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
+            unsigned long long c = 0;
+            HIP_TRY(hipMemcpy(&c, sc->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+            *reserved = (int64_t)c;
+        }
+    }
+    if (capacity) *capacity = sc->hit_cap_user;
+    return TRC_OK;
+}
+
+// Page-locked host memory for large results (hit lists, levels of the ray tree): a device-to-host copy into pageable memory is
+// staged through the driver's own bounce buffers at a third of the rate.  Blocks are kept by size class when they are freed
+// (page-locking 250 MB takes longer than copying them): at most HOST_KEEP bytes wait idle.
+struct HostPool {
+    std::mutex mu;
+    std::unordered_map<void *, size_t> live;
+    std::multimap<size_t, void *> idle;
+    size_t idle_bytes = 0;
+};
+static HostPool g_host_pool;
+static const size_t HOST_KEEP = (size_t)4 << 30;
+
+extern "C" int trc_host_alloc(int64_t bytes, void **out) {
+    if (!out || bytes < 0) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    *out = nullptr;
+    const size_t cls = pool_class((size_t)(bytes > 0 ? bytes : 1));
+    {
+        std::lock_guard<std::mutex> g(g_host_pool.mu);
+        auto it = g_host_pool.idle.find(cls);
+        if (it != g_host_pool.idle.end()) {
+            *out = it->second;
+            g_host_pool.idle.erase(it);
+            g_host_pool.idle_bytes -= cls;
+            g_host_pool.live[*out] = cls;
+            return TRC_OK;
+        }
+    }
+    hipError_t e = hipHostMalloc(out, cls, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        std::vector<void *> gone;
+        {
+            std::lock_guard<std::mutex> g(g_host_pool.mu);
+            for (auto &kv : g_host_pool.idle) gone.push_back(kv.second);
+            g_host_pool.idle.clear();
+            g_host_pool.idle_bytes = 0;
+        }
+        for (void *p : gone) (void)hipHostFree(p);
+        e = hipHostMalloc(out, cls, hipHostMallocDefault);
+        if (e != hipSuccess) return trc_fail(TRC_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", cls, hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> g(g_host_pool.mu);
+    g_host_pool.live[*out] = cls;
+    return TRC_OK;
+}
+
+extern "C" int trc_host_free(void *p) {
+    if (!p) return TRC_OK;
+    size_t cls = 0;
+    bool keep = false;
+    {
+        std::lock_guard<std::mutex> g(g_host_pool.mu);
+        auto it = g_host_pool.live.find(p);
+        if (it == g_host_pool.live.end()) return trc_fail(TRC_ERR_INVALID, "trc_host_free: not a block of trc_host_alloc");
+        cls = it->second;
+        g_host_pool.live.erase(it);
+        keep = g_host_pool.idle_bytes + cls <= HOST_KEEP;
+        if (keep) { g_host_pool.idle.insert(std::make_pair(cls, p)); g_host_pool.idle_bytes += cls; }
+    }
+    if (!keep) (void)hipHostFree(p);
     return TRC_OK;
 }
 

@@ -1,0 +1,227 @@
+// trc_shade.hip -- the shading stage of the streaming engine, split by optics class.
+//
+// k_s_shade (trc_stream.inc) carries every optics kind of optics_callables.py in one kernel: 243-256 registers, two waves per SIMD,
+// more than half of its wave cycles waiting.  The registers are not held by any one kind -- a mirror with slope error
+// (optics_callables.py:214-269 on ray_trace_utils/vector_manipulations.py:56-74) needs 66 -- but by the union of them and by what
+// was built around them to live with two waves (entries and ray records of the next two hits fetched ahead in registers).
+// Here one kernel per CLASS of optics walks the bounce's hit list and takes the hits on surfaces of its class; what a class does
+// not need is not compiled into its kernel (trc_shade_k<KINDS, false>), nothing is fetched ahead, and the tables the host passes
+// are few: the instances fit 128 registers and less, so a CU holds sixteen waves of them and their loads hide each other.
+//
+//   TRC_CLS_MIRROR    Transparent, Reflective, OneSidedReflective, RealReflective, OneSidedRealReflective (:93-140, :195-269, :492-504)
+//   TRC_CLS_DIFFUSE   Lambertian, LambertianSpecular, SemiLambertian, Reflective_spectral and the table-driven
+//                     Lambertian_directional_axisymmetric_piecewise family (:143-193, :331-391, :427-487, :506-585)
+//   (TRC_CLS_GENERAL  everything else stays with k_s_shade)
+//
+// Per hit the arithmetic is the one of the other engines: trc_normal, trc_shade_k = trc_shade with the other kinds left out.
+#include "trc_device.h"
+
+// FLATN: every surface of the scene is flat (its normal is the z axis of its frame, flat_surface.py:84-91)
+// LDS:   tallies, records, optics parameters, flux-map tables, flags (and the optics tables for the DIFFUSE class) are staged in
+//        LDS -- all of them or none, so that every access has a known address space (see k_s_shade)
+template <int CLS, bool FLATN, bool LDS>
+__global__ __launch_bounds__(SHC_THREADS) void k_s_shade_c(StreamParams S) {
+    extern __shared__ double lds[];
+    const FastParams &P = S.P;
+    const DScene &sc = P.sc;
+    const StreamWs &W = S.W;
+    const int Sn = sc.n_surf;
+    if (W.cnt[CN(4)]) return;
+    constexpr unsigned KINDS = CLS == TRC_CLS_MIRROR ? TRC_CLS_MIRROR_KINDS : TRC_CLS_DIFFUSE_KINDS;
+    DScene L = sc;
+    L.tally = W.tally_part + (size_t)(blockIdx.x % TALLY_PARTS) * (size_t)W.tally_n;
+    double *l_tally = lds;
+    double *cur = lds + (LDS ? 3 * Sn + 2 : 2);
+    for (int i = threadIdx.x; i < (LDS ? 3 * Sn + 2 : 2); i += blockDim.x) l_tally[i] = 0.0;
+    if (LDS) {
+        double *l_recs = cur; cur += Sn * sc.stride;
+        for (int i = threadIdx.x; i < Sn * sc.stride; i += blockDim.x) l_recs[i] = sc.recs[i];
+        double *l_opt = cur; cur += 8 * Sn;
+        for (int i = threadIdx.x; i < 8 * Sn; i += blockDim.x) l_opt[i] = sc.opt[i];
+        double *l_edges = cur; cur += sc.n_fm_edges;
+        for (int i = threadIdx.x; i < sc.n_fm_edges; i += blockDim.x) l_edges[i] = sc.fm_edges[i];
+        FluxMapDev *l_fms = (FluxMapDev *)cur; cur += (sc.n_fm * sizeof(FluxMapDev) + 7) / 8;
+        for (int i = threadIdx.x; i < sc.n_fm; i += blockDim.x) l_fms[i] = sc.fms[i];
+        int32_t *l_fm_of = (int32_t *)cur;
+        int32_t *l_flags = l_fm_of + Sn;
+        for (int i = threadIdx.x; i < Sn; i += blockDim.x) { l_fm_of[i] = sc.fm_of_surf ? sc.fm_of_surf[i] : -1; l_flags[i] = sc.sflags[i]; }
+        L.recs = l_recs; L.opt = l_opt; L.fm_edges = l_edges; L.fms = l_fms; L.fm_of_surf = l_fm_of; L.sflags = l_flags;
+        cur = (double *)(((uintptr_t)(l_flags + Sn) + 7) & ~(uintptr_t)7);
+        if (CLS != TRC_CLS_MIRROR) {        // (no mirror reads a table)
+            double *l_extra = cur; cur += sc.n_extra;
+            for (int i = threadIdx.x; i < sc.n_extra; i += blockDim.x) l_extra[i] = sc.extra[i];
+            L.extra = l_extra;
+        }
+    }
+    double *l_fm = nullptr;         // private copy of the flux-map bins (S.lds_fm_bins of them)
+    if (S.lds_fm_bins > 0) {
+        l_fm = cur; cur += S.lds_fm_bins;
+        for (int i = threadIdx.x; i < S.lds_fm_bins; i += blockDim.x) l_fm[i] = 0.0;
+    }
+    const double src_energy = P.src ? P.src->energy : 0.0;
+    __syncthreads();
+    long long nh = (long long)W.cnt[CN(2)];
+    if (nh > SQ_ROOM(W)) nh = SQ_ROOM(W);   // never read beyond the allocation, whatever the counter says
+    const long long padded = (nh + 63) & ~63ll;
+    const unsigned wave_g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    WaveChunk ca = S.static_first ? chunk_init_static_at(S.chunk_act, (unsigned long long)S.act_base0 + (unsigned long long)wave_g * S.chunk_act) : chunk_init(S.chunk_act);
+    // this wave's open chunk of the scene's hit buffer, carried over from earlier launches (see k_s_shade)
+    WaveChunk hc = chunk_init(S.chunk_hitbuf);
+    unsigned long long *hstate = W.hit_state;
+    if (P.capture && wave_g < SHADE_MAX_WAVES) {
+        const unsigned long long st = hstate[2 * wave_g + 1];
+        if ((unsigned)(st >> 32) == S.hit_epoch && (st & 1ull)) { hc.base = hstate[2 * wave_g]; hc.used = (unsigned)(st >> 1) & 0x7FFFFFFFu; hc.open = 1; }
+    }
+    unsigned n_hit = 0, n_alive = 0;
+    const int bounce0 = S.bounce_no;          // every ray of a launch is at the same bounce
+    const bool aux_in = !P.src || bounce0 > 0;     // fresh rays of a source carry (energy, 1, 0): nothing was written for them
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += stride) {
+        uint32_t slot = SQ_INVALID, hs = SQ_INVALID;
+        double t = TRC_INF;
+        if (i < nh) { slot = W.hit_slot[i]; hs = W.hit_surf[i]; t = W.hit_t[i]; }
+        bool mine = false;
+        int s = 0, fl = 0;
+        SRayGeo g;
+        g.px = g.py = g.pz = g.dx = g.dy = 0.0; g.dz = 1.0; g.head = SQ_INVALID; g.idx = 0u; g.tail = 0ull;
+        if (slot != SQ_INVALID) {
+            bool have = false;
+            if (hs == SQ_INVALID) {
+                // general path: the nearest of the ray's linked hits; on equal t the lowest surface index (tracer_engine.py:58-63)
+                g = W.geo[slot];
+                have = true;
+                t = TRC_INF;
+                int sb = 0x7FFFFFFF;
+                for (uint32_t k = g.head; k != SQ_INVALID;) {
+                    const SCand c = W.q3n[k];
+                    if (c.t < t || (c.t == t && (int)c.surf < sb)) { t = c.t; sb = (int)c.surf; }
+                    k = c.next;
+                }
+                s = sb;
+            } else s = (int)hs;
+            if ((unsigned)s < (unsigned)Sn) {
+                fl = L.sflags[s];
+                const int cls = (fl >> TRC_SURF_CLS_SHIFT) & TRC_SURF_CLS_MASK;
+                mine = (S.shade_term_cls >= 0 && (fl & TRC_SURF_TERMINAL)) ? (S.shade_term_cls == CLS) : (cls == CLS);
+            }
+            if (mine && !have) g = W.geo[slot];
+        }
+        const unsigned long long my_lanes = __ballot(mine);
+        if (!my_lanes) continue;            // the unused tail of a chunk of the list, or hits of other classes only
+        bool alive = false;
+        int ts = -1;                         // the surface this lane's hit is tallied on, with absorbed and incident energy
+        double tea = 0.0, tei = 0.0;
+        if (mine) {
+            n_hit += 1;
+            const int prev = bounce0 == 0 ? Sn : (int)((uint32_t)(g.tail >> 32) & ~SQ_SKIP_SELF);      // the surface the ray left; Sn = the source
+            double e = src_energy, wl = 0.0;
+            if (aux_in) { e = W.aux[slot].e; if (CLS != TRC_CLS_MIRROR) wl = W.aux[slot].wl; }
+            const double *rec = L.recs + (size_t)s * sc.stride;
+            const double hx = g.px + t * g.dx, hy = g.py + t * g.dy, hz = g.pz + t * g.dz;
+            double ox = g.dx, oy = g.dy, oz = g.dz, e_out = 0.0;
+            if (!(S.shade_term_cls >= 0 && (fl & TRC_SURF_TERMINAL))) {
+                double nx, ny, nz;
+                if (FLATN) {
+                    if (!trc_gm_is_flat(trc_rec_gm_kind(rec))) __builtin_unreachable();
+                }
+                trc_normal(rec, hx, hy, hz, g.dx, g.dy, g.dz, &nx, &ny, &nz);
+                trc_ray_out out[2];
+                const unsigned long long rid = P.rid ? P.rid[S.base + (long long)g.idx] : (P.ray_offset + (unsigned long long)(S.base + (long long)g.idx));
+                trc_shade_k<KINDS, false>(trc_rec_opt_kind(rec), L.opt + (size_t)s * 8, L.extra, trc_rec_extra_off(rec), trc_rec_extra_len(rec),
+                                          rec[2], rec[5], rec[8], g.dx, g.dy, g.dz, e, 1.0, wl, 0.0, nx, ny, nz, P.seed, rid, (uint32_t)(bounce0 + 1), out);
+                ox = out[0].dx; oy = out[0].dy; oz = out[0].dz; e_out = out[0].e;
+            }
+            const double e_abs = e - e_out;
+            record_hit<LDS>(L, l_tally, s, e, e_abs, hx, hy, hz, g.dx, g.dy, g.dz, P.capture != 0, prev, &hc, l_fm, false, LDS);
+            if (LDS) { ts = s; tea = e_abs; tei = e; }
+            if (e_out > P.min_energy) {                               // tracer_engine.py:242
+                if (bounce0 + 1 >= P.reps) {                          // still alive after the last iteration
+                    atomicAdd(&sc.counters[3], 1ull);
+                    atomicAdd(sc.energy_left, e_out);
+                    if (P.flags & TRC_TRACE_KEEP_LAST) {
+                        const unsigned long long q = atomicAdd(&sc.counters[2], 1ull);
+                        if ((long long)q < P.last_cap) {
+                            P.lx[q] = hx; P.ly[q] = hy; P.lz[q] = hz;
+                            P.ldx[q] = ox; P.ldy[q] = oy; P.ldz[q] = oz; P.le[q] = e_out;
+                        }
+                    }
+                } else {
+                    alive = true;
+                    SRayGeo go;
+                    go.px = hx; go.py = hy; go.pz = hz; go.dx = ox; go.dy = oy; go.dz = oz;
+                    go.head = SQ_INVALID;          // ready for the next bounce's search
+                    go.idx = g.idx;
+                    // leaving a flat surface the ray cannot meet it again when its own plane test is certain to give t < 1e-7
+                    // (flat_surface.py:39-51: t = -((p - c).n) / (d.n), the hit point p is on the plane up to rounding)
+                    uint32_t pw = (uint32_t)s;
+                    if (trc_gm_is_flat(trc_rec_gm_kind(rec))) {
+                        const double dtn = ox * rec[2] + oy * rec[5] + oz * rec[8];
+                        const double vt = rec[2] * (hx - rec[9]) + rec[5] * (hy - rec[10]) + rec[8] * (hz - rec[11]);
+                        const double scale = 1.0 + fabs(hx) + fabs(hy) + fabs(hz) + fabs(rec[9]) + fabs(rec[10]) + fabs(rec[11]);
+                        if (fabs(dtn) > 1e-6 && fabs(vt) + 1e-12 * scale < 5e-8 * fabs(dtn)) pw |= SQ_SKIP_SELF;
+                    }
+                    go.tail = sray_tail(bounce0 + 1, pw);
+                    W.geo[slot] = go;
+                    if (aux_in) W.aux[slot].e = e_out;        // (index and wavelength stay as they are: no optics of these classes changes them)
+                    else { SRayAux ao; ao.e = e_out; ao.ref = 1.0; ao.wl = 0.0; ao.pad = 0.0; W.aux[slot] = ao; }
+                }
+            }
+        }
+        if (LDS) {
+            // the three sums per surface: lanes that share the surface of the first lane still to be served are summed in registers
+            // and added once while at least 8 of them do (see k_s_shade); the others add for themselves
+            unsigned long long todo = Sn <= 64 ? __ballot(ts >= 0) : 0ull;
+            for (int round = 0; round < 6 && todo; ++round) {
+                const int s0 = __shfl(ts, __ffsll((long long)todo) - 1, 64);
+                const bool in = ts == s0;
+                const unsigned long long m = __ballot(in);
+                if (__popcll(m) < 8) break;
+                const double a = wave_sum(in ? tea : 0.0), b = wave_sum(in ? tei : 0.0);
+                if (lane_id() == 0) { atomicAdd(&l_tally[s0], a); atomicAdd(&l_tally[Sn + s0], b); atomicAdd(&l_tally[2 * Sn + s0], (double)__popcll(m)); }
+                if (in) ts = -1;
+                todo &= ~m;
+            }
+            if (ts >= 0) { atomicAdd(&l_tally[ts], tea); atomicAdd(&l_tally[Sn + ts], tei); atomicAdd(&l_tally[2 * Sn + ts], 1.0); }
+        }
+        if (P.capture) chunk_rebroadcast(hc, __ffsll((long long)my_lanes) - 1);   // hc was advanced by the lanes with a hit only
+        const unsigned long long q = chunk_append(&W.cnt[CN(3)], ca, alive, S.act_out, W.act_room);
+        if (alive) { if ((long long)q < W.act_room) S.act_out[q] = slot; else W.cnt[CN(4)] = 2ull; n_alive += 1; }
+    }
+    chunk_close(ca, S.act_out, W.act_room);
+    if (P.capture && wave_g < SHADE_MAX_WAVES && lane_id() == 0) {
+        hstate[2 * wave_g] = hc.base;
+        hstate[2 * wave_g + 1] = ((unsigned long long)S.hit_epoch << 32) | ((unsigned long long)hc.used << 1) | (hc.open ? 1ull : 0ull);
+    }
+    // real (unpadded) counts of this bounce: hits and rays that go on -- one pair of atomics per workgroup
+    {
+        const double h = wave_sum((double)n_hit), a = wave_sum((double)n_alive);
+        double *spare = l_tally + (LDS ? 3 * Sn : 0);
+        if (lane_id() == 0) { atomicAdd(&spare[0], h); atomicAdd(&spare[1], a); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (spare[0] > 0.0) { atomicAdd(&W.cnt[CN(6)], (unsigned long long)(spare[0] + 0.5)); atomicAdd(&W.cnt[CN(13 + CLS)], (unsigned long long)(spare[0] + 0.5)); }
+            if (spare[1] > 0.0) atomicAdd(&W.cnt[CN(7)], (unsigned long long)(spare[1] + 0.5));
+        }
+    }
+    if (LDS)
+        for (int i = threadIdx.x; i < 3 * Sn; i += blockDim.x) {
+            const double v = l_tally[i];
+            if (v != 0.0) atomicAdd(&L.tally[i], v);
+        }
+    if (l_fm) {
+        double *gt = L.tally + 3 * Sn + 2;
+        for (int i = threadIdx.x; i < S.lds_fm_bins; i += blockDim.x) {
+            const double v = l_fm[i];
+            if (v != 0.0) atomicAdd(&gt[i], v);
+        }
+    }
+}
+
+const void *trc_shade_lean_kernel(int cls, bool flat, bool lds) {
+#define SHC_PICK(C) (flat ? (lds ? (const void *)k_s_shade_c<C, true, true> : (const void *)k_s_shade_c<C, true, false>) \
+                          : (lds ? (const void *)k_s_shade_c<C, false, true> : (const void *)k_s_shade_c<C, false, false>))
+    if (cls == TRC_CLS_MIRROR) return SHC_PICK(TRC_CLS_MIRROR);
+    if (cls == TRC_CLS_DIFFUSE) return SHC_PICK(TRC_CLS_DIFFUSE);
+#undef SHC_PICK
+    return nullptr;
+}
