@@ -27,11 +27,14 @@ FPFLAGS := -ffp-contract=off
 
 HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -munsafe-fp-atomics $(FPFLAGS) -fPIC -Wno-unused-result
 
-# trc_shade.hip: no machine-level loop-invariant code motion.  The kernels are grid-stride loops around chains of float64 library
-# code (logarithm, sine / cosine, tangent, arc cosine), and the pass moves the materialisation of every constant of those chains
-# in front of the loop, where each then holds two registers for the whole kernel: 170 / 241 registers with it, 94 / 116 without.
+# No machine-level loop-invariant code motion.  The kernels are grid-stride loops around chains of float64 library code
+# (logarithm, sine / cosine, tangent, arc cosine, square roots and divisions), and the pass moves the materialisation of every
+# constant of those chains in front of the loop, where each then holds two registers for the whole kernel: the lean shading
+# kernels 170 / 241 registers with it, 94 / 116 without; k_s_shade 243 -> 131, k_s_fresh 168 -> 95, k_s_bounce 128 + 180 bytes of
+# scratch -> 119, k_trace_coop 256 + 408 bytes -> 165, k_ord_bounce 166 -> 121 (build/*.resources.txt, `make asm`).
+# Measured (profiles/README.md): NSTTF +3 %, dish +4 %, cavity +9 %, the megakernel on the dish +17 %.
 SHADE_FLAGS := -mllvm -disable-machine-licm
-KERNELS_FLAGS :=
+KERNELS_FLAGS := -mllvm -disable-machine-licm
 
 $(OBJDIR)/trc_shade.o: $(CSRC)/trc_shade.hip $(HDR)
 	mkdir -p $(OBJDIR)

@@ -391,7 +391,7 @@ struct __attribute__((aligned(32))) SRayAux {
 
 // counters live 128 bytes apart: atomics on words of one cache line serialise in the same L2 bank
 #define CN(k) ((k) << 4)
-#define CN_WORDS (24 << 4)
+#define CN_WORDS (32 << 4)
 
 struct StreamWs {
     long long cap;      // rays per batch
@@ -415,10 +415,16 @@ struct StreamWs {
     double *tally_part;        // TALLY_PARTS private copies of the scene's tally buffer (merged at the end of the call)
     long long tally_n;
     unsigned long long *hit_state;   // per wave of k_s_shade: open chunk of the scene's hit buffer, kept across launches
+    // the hit list of a bounce parted by optics class (k_s_partition; scenes with more than one shading class): list c holds the
+    // hits on surfaces of class c, resolved (surface and distance), pl_room entries each; null for classes the scene does not have
+    uint32_t *pl_slot[3], *pl_surf[3];
+    double *pl_t[3];
+    long long pl_room;
     unsigned long long *cnt;   // CN(k): [0] Q1, [1] Q3, [2] hit list, [3] next active list, [4] overflow flag, [5] entries of the
                                // active list coming in, [6] hits and [7] rays going on (real counts), [8] slots of the ray table
                                // handed out, [9] general-path list and [10] footprint list of k_s_cull, [11] hits on terminal surfaces
-                               // (k_s_bounce -> k_s_absorb) and [12] their real count; [16..22] SW_STATS
+                               // (k_s_bounce -> k_s_absorb) and [12] their real count; [13..15] hits shaded per class; [16..22] SW_STATS;
+                               // [24..26] entries of the class lists of k_s_partition
 };
 
 // the footprint map of the call's source on the device (trc_footprint.h)
@@ -470,6 +476,14 @@ struct StreamParams {
     long long act_base0;       // first entry of the pre-assigned chunks of the active list that belong to this launch (the shading
                                // kernels of a bounce append to one list; wave w starts at act_base0 + w * chunk_act)
     unsigned chunk_hitbuf;     // entries of the scene's hit buffer a wave reserves per atomic (<= SQ_HIT_CHUNK; small buffers: less)
+    // the list a shading kernel walks: the bounce's hit list (counter CN(2)), or its class's part of it (k_s_partition, CN(24 + class))
+    const uint32_t *hl_slot, *hl_surf;
+    const double *hl_t;
+    long long hl_room;
+    int hl_cn;                 // index of the counter word that holds the list's length (CN(...) applied)
+    // k_s_partition: per class, entries pre-assigned to every wave (0: the waves reserve as they go) and where those chunks start
+    unsigned part_chunk[3];
+    int part_static[3];
 };
 
 // optics classes of the shading stage.  MIRROR and DIFFUSE are served by lean kernels (trc_shade.hip: <= 128 registers, four

@@ -60,8 +60,8 @@ __global__ __launch_bounds__(SHC_THREADS) void k_s_shade_c(StreamParams S) {
     }
     const double src_energy = P.src ? P.src->energy : 0.0;
     __syncthreads();
-    long long nh = (long long)W.cnt[CN(2)];
-    if (nh > SQ_ROOM(W)) nh = SQ_ROOM(W);   // never read beyond the allocation, whatever the counter says
+    long long nh = (long long)W.cnt[S.hl_cn];
+    if (nh > S.hl_room) nh = S.hl_room;     // never read beyond the allocation, whatever the counter says
     const long long padded = (nh + 63) & ~63ll;
     const unsigned wave_g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     WaveChunk ca = S.static_first ? chunk_init_static_at(S.chunk_act, (unsigned long long)S.act_base0 + (unsigned long long)wave_g * S.chunk_act) : chunk_init(S.chunk_act);
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(SHC_THREADS) void k_s_shade_c(StreamParams S) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += stride) {
         uint32_t slot = SQ_INVALID, hs = SQ_INVALID;
         double t = TRC_INF;
-        if (i < nh) { slot = W.hit_slot[i]; hs = W.hit_surf[i]; t = W.hit_t[i]; }
+        if (i < nh) { slot = S.hl_slot[i]; hs = S.hl_surf[i]; t = S.hl_t[i]; }
         bool mine = false;
         int s = 0, fl = 0;
         SRayGeo g;

@@ -17,6 +17,7 @@ from itertools import combinations
 from copy import deepcopy
 
 import numpy as N
+from .deferred import settle_marks
 
 from . import _cabi, rng
 from .geometry_manager import fill_desc
@@ -585,7 +586,21 @@ class Accountant(object):
     def _empty(self):
         return N.array([])
 
+    def __getstate__(self):
+        settle_marks(self)          # (a copy or a pickle of an accountant holds arrays, not promises of the device)
+        return self.__dict__
+
+    def __deepcopy__(self, memo):
+        settle_marks(self)
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__dict__.update(deepcopy(self.__dict__, memo))
+        return new
+
     def get_data(self):
+        # chunks the device engines still owe this accountant are fetched now (deferred.py): the hits of a fast trace stay in the
+        # device's hit buffer, the levels of an ordered trace on the device, until somebody reads them
+        settle_marks(self)
         chunks = [c for c in self._data if c.shape[-1]]
         if not chunks:
             return self._empty()
@@ -701,6 +716,7 @@ class PolychromaticAccountant(Accountant):
         self._data.append(hit['spectra_in'] - hit['spectra_out'])
 
     def get_data(self):
+        settle_marks(self)
         if not self._data:
             return N.array([]), N.array([]).reshape(2, 0)
         return N.concatenate(self._wavelengths, axis=-1), N.concatenate(self._data, axis=-1)

@@ -16,6 +16,7 @@ import numpy as N
 
 from . import _cabi
 from .geometry_manager import NativeGeometryManager, fill_desc
+from .deferred import Delivery
 from .optics_callables import OpticsCallable, native_optics_of, LocationAccountant, DirectionAccountant, \
     AbsorptionAccountant, ReceptionAccountant, ScatteringAccountant, NormalAccountant
 
@@ -180,11 +181,15 @@ class DeviceScene(object):
         self.hit_capacity = 0
         self.form_rate = {}         # segments per ms of kernel time seen from each form of the fast engine on this scene (TracerEngine)
         self._kd_keep = None
+        self.pending_hits = None    # PendingHits: what the hit buffer holds for accountants that have not read it yet
 
     def close(self):
         if self.handle is not None and self.handle.value:
-            self.lib.trc_scene_destroy(self.handle)
-            self.handle = None
+            try:
+                self.settle_pending()
+            finally:
+                self.lib.trc_scene_destroy(self.handle)
+                self.handle = None
 
     def __del__(self):
         try:
@@ -195,6 +200,7 @@ class DeviceScene(object):
     def update_frames(self, compiled):
         """New poses for the same surfaces (trc_scene_update_frames): boxes and grid are rebuilt by the library, a Kd-tree
         set before is dropped (it described the old poses); tallies, flux maps and the hit buffer stay."""
+        self.settle_pending()       # (normals of hits that wait for a NormalAccountant are those of the poses they were made in)
         fr = _cabi.f64(compiled.frames12())
         _cabi.check(self.lib.trc_scene_update_frames(self.handle, compiled.n_surf, _cabi.ptr(fr)))
         self.compiled = compiled
@@ -247,12 +253,34 @@ class DeviceScene(object):
         return out
 
     def set_hit_capacity(self, capacity):
+        """an empty hit buffer of this capacity (what it held is delivered first to the accountants that wait for it)"""
         capacity = int(capacity)
+        self.settle_pending()
         if capacity != self.hit_capacity:
             _cabi.check(self.lib.trc_scene_set_hit_capacity(self.handle, capacity))
             self.hit_capacity = capacity
 
+    def hits_reserved(self):
+        """(entries of the hit buffer reserved so far, capacity last asked for)"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        _cabi.check(self.lib.trc_scene_hits_reserved(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def reserve_hits(self, capacity):
+        """room for `capacity` hits in all, keeping the hits the buffer holds"""
+        _cabi.check(self.lib.trc_scene_reserve_hits(self.handle, int(capacity)))
+        self.hit_capacity = self.hits_reserved()[1]
+
+    def settle_pending(self):
+        """hits the fast engine left in the device buffer for accountants that have not read them yet are delivered now
+        (before the buffer is emptied, re-sized or the scene goes away)"""
+        p = self.pending_hits
+        self.pending_hits = None
+        if p is not None:
+            p.settle()
+
     def reset_tallies(self):
+        self.settle_pending()           # (the reset empties the hit buffer)
         _cabi.check(self.lib.trc_scene_reset_tallies(self.handle))
 
     def get_tallies(self):
@@ -273,10 +301,11 @@ class DeviceScene(object):
         k = n.value
         fl = [self.compiled.descs[i].flags for i in range(self.n_surf)]
         lean = all((f & _cabi.SURF_CAPTURE_LEAN) for f in fl if (f & _cabi.SURF_CAPTURE_HITS)) and any(f & _cabi.SURF_CAPTURE_HITS for f in fl)
-        surf = N.empty(k, dtype=N.int32)
-        e_abs, points = N.empty(k), N.empty((3, k))
-        e_in = e_abs if lean else N.empty(k)
-        directions = None if lean else N.empty((3, k))
+        # (large lists land in page-locked memory: 6.5e6 hits of 36 bytes cross the link in 5 ms, not 15)
+        surf = _cabi.pinned_empty(k, dtype=N.int32)
+        e_abs, points = _cabi.pinned_empty(k), _cabi.pinned_empty((3, k))
+        e_in = e_abs if lean else _cabi.pinned_empty(k)
+        directions = None if lean else _cabi.pinned_empty((3, k))
         cols = [e_abs, None if lean else e_in, points[0], points[1], points[2]] + ([None] * 3 if lean else [directions[0], directions[1], directions[2]])   # rows: no copy afterwards
         if k:
             _cabi.check(self.lib.trc_scene_get_hits(self.handle, C.byref(n), surf.ctypes.data_as(C.POINTER(C.c_int32)),
@@ -304,6 +333,7 @@ class DeviceScene(object):
 
     def enable_transfer(self, on=True):
         """keep (or drop) the surface-to-surface transfer matrix of the fast engine; resets the tallies"""
+        self.settle_pending()
         _cabi.check(self.lib.trc_scene_enable_transfer(self.handle, 1 if on else 0))
 
     def get_transfer(self):
@@ -451,10 +481,39 @@ class OrderedResult(object):
         return out
 
 
-def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavelengths=None, spectra=None, e_abs=None):
+class PendingHits(Delivery):
+    """
+    The hits a DeviceScene's buffer holds for the accountants of its capturing surfaces (fast engine): fetched and fed when
+    the first of them is read, or when the buffer has to be emptied.  Traces that follow each other without a read in
+    between go on filling the same buffer and are delivered together.
+    """
+    def __init__(self, dev):
+        Delivery.__init__(self)
+        self.dev = dev
+        self.surfaces = dev.compiled.surfaces
+
+    def deliver(self, holders):
+        dev = self.dev
+        if dev.handle is None:
+            return
+        h = dev.get_hits()
+        if h['directions'] is None:         # Receiver accountants only: absorbed energy and hit points
+            feed_accountants(self.surfaces, h['surf'], h['e_in'], None, h['points'], None, e_abs=h['e_abs'], only=holders)
+        else:
+            feed_accountants(self.surfaces, h['surf'], h['e_in'], h['e_in'] - h['e_abs'], h['points'], h['directions'], only=holders)
+
+    def release(self):
+        if self.dev.pending_hits is self:
+            self.dev.pending_hits = None
+        self.dev = None
+        self.surfaces = None
+
+
+def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavelengths=None, spectra=None, e_abs=None, only=None):
     """
     Hand per-hit data to the accountants of each surface's optics (fused engines).  Inside one call
-    the hits of a surface are kept in the order given.
+    the hits of a surface are kept in the order given.  only: ids of the accountants to feed (a delivery settled late,
+    deferred.py: the others were reset since the trace), None = all.
     """
     surf_ids = N.asarray(surf_ids)
     if len(surf_ids) == 0:
@@ -508,4 +567,5 @@ def feed_accountants(surfaces, surf_ids, e_in, e_out, points, directions, wavele
         if spectra is not None:     # polychromatic bundles: (spectra of the incident rays, of the outgoing ones, their wavelength grids)
             hit['spectra_in'], hit['spectra_out'], hit['wavelengths'] = spectra[0][:, idx], spectra[1][:, idx], spectra[2][:, idx]
         for acc in opt.accountants:
-            acc.feed(hit)
+            if only is None or id(acc) in only:
+                acc.feed(hit)

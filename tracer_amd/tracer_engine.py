@@ -20,15 +20,17 @@ raises.
 """
 import logging
 import time
+import weakref
 
 import numpy as N
 
 from . import rng
 from .accel_tree import KdTree
 from .ray_bundle import RayBundle, concatenate_rays
-from .scene import compile_scene, DeviceScene, NotNativeError, feed_accountants
+from .scene import compile_scene, DeviceScene, NotNativeError, feed_accountants, PendingHits
 from .optics_callables import OpticsCallable
 from .trace_tree import RayTree
+from .ordered_levels import OrderedLevels, LazyLevelBundle, PendingLevels, level_columns
 
 
 class TracerEngine(object):
@@ -44,6 +46,8 @@ class TracerEngine(object):
         self._transfer_host = None      # contribution of ordered-engine runs (from the tree's parents)
         self._kd_on_device = None
         self._auto_kd = None
+        self._ordered_pending = []      # weak references to what ordered traces still owe to accountants (ordered_levels.PendingLevels)
+        self._transfer_pending = []     # those of them that carry a contribution to the transfer matrix (kept alive until it is read)
         self.stats = {}
 
     # -- the Kd-tree of the last accelerated call (tracer_engine.py:171-185) -------------------------------
@@ -72,6 +76,7 @@ class TracerEngine(object):
         if self._dev is not None and sig == self._dev_sig:
             self._dev.compiled = compiled   # same numbers, fresh Surface objects
             return self._dev
+        self._settle_engine_pendings()      # (what earlier traces owe to accountants is delivered in the poses it was made in)
         if self._dev is not None and compiled.signature_without_frames() == self._dev_static_sig and \
                 self._fluxmaps_unmoved(compiled):
             # the scene only moved (a heliostat field following the sun): new frames for the scene already on the device
@@ -137,11 +142,18 @@ class TracerEngine(object):
     def get_transfer_matrix(self):
         if not self._transfer:
             raise ValueError('call enable_transfer_matrix() before tracing')
+        for p in self._transfer_pending:        # contributions of ordered traces whose levels are still on the device
+            p.settle()
+        self._transfer_pending = []
         n = len(self._asm.get_surfaces())
         T = self._dev.get_transfer() if self._dev is not None else N.zeros((n + 1, n))
         return T if self._transfer_host is None else T + self._transfer_host
 
     def reset_tallies(self):
+        for p in self._transfer_pending:
+            p.transfer = False
+            p.always = False
+        self._transfer_pending = []
         self._transfer_host = None
         if self._dev is not None:
             self._dev.reset_tallies()
@@ -152,6 +164,8 @@ class TracerEngine(object):
     TUNE_MIN_RAYS = 1 << 21  # calls from which the two forms of the fast engine are compared on a scene (fast_kernel='auto')
     TUNE_MAX_SURFACES = 512  # ... and the scene size up to which the megakernel is worth a try
     SLOW_STREAM = 1.5e6      # segments per ms of kernel time below which the streaming form counts as slow
+    HITS_RESIDENT_MAX = 1 << 30     # entries up to which unread hits of successive calls are kept in the device's buffer (68 B each)
+    LEVELS_RESIDENT_MAX = 16 << 30  # bytes of unread ray-tree levels of earlier calls that may stay on the device
 
     def ray_tracer(self, bundle, reps=100, min_energy=1e-10, tree=True, accel=False, Kd_Tree=None, **kwargs):
         """
@@ -239,9 +253,29 @@ class TracerEngine(object):
     def _trace_fast(self, dev, bundle, reps, min_energy, seed, accel, hit_capacity, fast_kernel='auto', feed=True, last_capacity=None):
         n = bundle.get_num_rays()
         capture = any(dev.compiled.capture)
+        accs = []
+        pend = None
         if capture:
-            dev.set_hit_capacity(hit_capacity if hit_capacity is not None else 2 * n + 1024)
-            dev.lib.trc_scene_clear_hits(dev.handle)
+            # The hits stay in the device's buffer until an accountant is read (scene.PendingHits).  A call that finds the hits
+            # of the calls before still unread there -- every accountant concerned still holds its mark -- goes on filling the
+            # same buffer, grown if need be; otherwise what it holds is delivered (or dropped, when nobody waits for it any more)
+            # and the buffer emptied.  An explicit hit_capacity is taken literally: an empty buffer of that size.
+            need = int(hit_capacity) if hit_capacity is not None else 2 * n + 1024
+            accs = [a for sf, cap in zip(dev.compiled.surfaces, dev.compiled.capture) if cap for a in sf.get_optics_manager().accountants]
+            pend = dev.pending_hits
+            keep = bool(feed and hit_capacity is None and pend is not None and pend.wanted() and accs and all(pend.holds_mark(a) for a in accs))
+            if keep:
+                used = dev.hits_reserved()[0]
+                keep = used + need <= self.HITS_RESIDENT_MAX
+            if keep:
+                dev.reserve_hits(used + need)
+            else:
+                pend = None
+                if hit_capacity is None and dev.hit_capacity >= need and dev.hit_capacity <= 4 * need:
+                    dev.settle_pending()        # (a buffer that is large enough already is kept: freeing and allocating 15 GB costs 0.1 s)
+                else:
+                    dev.set_hit_capacity(need)
+                dev.lib.trc_scene_clear_hits(dev.handle)
         t0 = time.time()
         stream = {'auto': None, 'stream': True, 'megakernel': False}[fast_kernel]
         if stream is None and accel and dev.n_surf > self.KD_BUILD_MAX:
@@ -269,12 +303,12 @@ class TracerEngine(object):
         if stats.hits_dropped:
             raise RuntimeError("%d hits were not captured: the hit buffer holds %d; pass hit_capacity=..."
                                % (stats.hits_dropped, dev.hit_capacity))
-        if capture and feed:
-            h = dev.get_hits()
-            if h['directions'] is None:         # Receiver accountants only: absorbed energy and hit points
-                feed_accountants(dev.compiled.surfaces, h['surf'], h['e_in'], None, h['points'], None, e_abs=h['e_abs'])
-            else:
-                feed_accountants(dev.compiled.surfaces, h['surf'], h['e_in'], h['e_in'] - h['e_abs'], h['points'], h['directions'])
+        if capture and feed and accs:
+            if pend is None:
+                pend = dev.pending_hits = PendingHits(dev)
+            pend.surfaces = dev.compiled.surfaces
+            for a in accs:
+                pend.give_mark(a)
         self._warn_left(stats.rays_left, stats.energy_left, bundle)
         vertices, directions = N.vstack(last[0:3]), N.vstack(last[3:6])
         # "otherwise only register the last bundle" (tracer_engine.py:288-291): scripts read engine.tree[-1] after tree=False
@@ -289,77 +323,59 @@ class TracerEngine(object):
         cplx = bool(dev.compiled.materials) or (not _pending(bundle) and bundle.has_complex_index())
         if n_spec:
             has_wl = False          # `wavelengths` is the (W, N) grid of the spectra
+        self._trim_resident_levels()
         t0 = time.time()
         res, stats = dev.trace_ordered(bundle, reps, min_energy, seed, accel=accel)
         wall = time.time() - t0
         self._set_stats(stats, wall, 'ordered')
-        try:
-            nlev = res.num_levels()
-            if tree is True:
-                self.tree.append(bundle)
-            prev = None
-            prev_surf = None
-            last = None
-            acc_table = None
-            for lv in range(1, nlev):
-                L = res.level(lv, with_ref_index=True, with_wavelength=has_wl, complex_index=cplx, n_spec=n_spec)
-                if prev is None:
-                    prev = dict(energy=N.asarray(bundle.get_energy()), directions=N.asarray(bundle.get_directions()),
-                                wavelengths=bundle.get_wavelengths() if has_wl else None,
-                                spectra=N.asarray(bundle.get_spectra()) if n_spec else None)
-                # accountants: hits of a surface in the order the reference selects them (ascending parent).  Only the hits on
-                # surfaces that have accountants are touched, and they are only sorted when the device's order -- (culled, surface,
-                # block) with ascending parents inside -- is not that order already (no culled rays, one block: the usual case)
-                par = L['parents']
-                if acc_table is None:
-                    acc_table = N.array([isinstance(sf.get_optics_manager(), OpticsCallable) and len(sf.get_optics_manager().accountants) > 0
-                                         for sf in dev.compiled.surfaces]) if dev.compiled.surfaces is not None else N.zeros(dev.n_surf, dtype=bool)
-                order = N.nonzero(acc_table[L['surf']])[0] if acc_table.any() else N.zeros(0, dtype=int)
-                if len(order):
-                    whole = len(order) == len(par)           # every ray of the level ended on a surface with accountants: no gathering
-                    so, po = (L['surf'], par) if whole else (L['surf'][order], par[order])
-                    key = so.astype(N.int64) * (1 << 40) + po
-                    if not (key[1:] >= key[:-1]).all():
-                        order = order[N.argsort(key, kind='stable')]
-                        whole = False
-                        so, po = L['surf'][order], par[order]
-                    sel = slice(None) if whole else order
-                    # (copies, not views, of what the recorded bundle of the tree holds: a script may edit engine.tree in place)
-                    feed_accountants(dev.compiled.surfaces, so, prev['energy'][po], L['energy'].copy() if whole else L['energy'][order],
-                                     L['vertices'].copy() if whole else L['vertices'][:, order], prev['directions'][:, po],
-                                     None if prev['wavelengths'] is None else prev['wavelengths'][po],
-                                     spectra=None if not n_spec else (prev['spectra'][:, po], L['spectra'][:, sel], L['wavelengths'][:, sel]))
-                if self._transfer:
-                    ns = dev.n_surf
-                    left = N.full(len(prev['energy']), ns) if prev_surf is None else prev_surf
-                    if self._transfer_host is None:
-                        self._transfer_host = N.zeros((ns + 1, ns))
-                    N.add.at(self._transfer_host, (left[par], L['surf']), prev['energy'][par])
-                prev_surf = L['surf']
-                kw = {}
-                if has_ref or dev.compiled.splits or _has_refractive(dev):
-                    kw['ref_index'] = L['ref_index']
-                if has_wl:
-                    kw['wavelengths'] = L['wavelengths']
-                if n_spec:
-                    kw['wavelengths'] = L['wavelengths']
-                    kw['spectra'] = L['spectra']
-                rec = RayBundle(vertices=L['vertices'], directions=L['directions'], energy=L['energy'],
-                                parents=L['parents'], **kw)
-                if tree is True or lv == nlev - 1:
-                    self.tree.append(rec)
-                prev = dict(energy=L['energy'], directions=L['directions'], wavelengths=L.get('wavelengths') if has_wl else None,
-                            spectra=L.get('spectra'))
-                last = L
-        finally:
-            res.close()
-        if last is None or stats.rays_left == 0:
-            if stats.rays_left == 0 and nlev > 1 or nlev == 1:
-                logging.log(self.loglevel, 'Ray bundle depleted')
+        # Nothing is copied here: the levels stay on the device (ordered_levels.py).  engine.tree holds bundles whose columns
+        # arrive when they are read, the accountants hold marks that the first get_data() / get_all_hits() settles.
+        levels = OrderedLevels(res, has_wl, cplx, n_spec)
+        nlev = levels.nlev
+        names = level_columns(has_ref or dev.compiled.splits or _has_refractive(dev), has_wl, n_spec)
+        if tree is True:
+            self.tree.append(bundle)
+        for lv in range(1, nlev):
+            if tree is True or lv == nlev - 1:
+                self.tree.append(LazyLevelBundle(levels, lv, names))
+        surfaces = dev.compiled.surfaces
+        accs = [a for sf in surfaces if isinstance(sf.get_optics_manager(), OpticsCallable) for a in sf.get_optics_manager().accountants] \
+            if surfaces is not None else []
+        if nlev > 1 and (accs or self._transfer):
+            pend = PendingLevels(self, surfaces, levels, bundle, dev.n_surf, self._transfer)
+            for a in accs:
+                pend.give_mark(a)
+            self._ordered_pending.append(weakref.ref(pend))
+            if self._transfer:
+                self._transfer_pending.append(pend)
+        if nlev <= 1 or stats.rays_left == 0:
+            logging.log(self.loglevel, 'Ray bundle depleted')
             return N.zeros((3, 0)), N.zeros((3, 0))
+        last = levels.level(nlev - 1)
         k = last['n_live']
         self._warn_left(stats.rays_left, stats.energy_left, bundle)
         return last['vertices'][:, :k], last['directions'][:, :k]
+
+    def _trim_resident_levels(self):
+        """unread levels of earlier ordered traces stay on the device up to LEVELS_RESIDENT_MAX bytes: beyond, the oldest are
+        delivered to their accountants now"""
+        live = [r() for r in self._ordered_pending]
+        live = [p for p in live if p is not None and not p.settled and p.levels is not None]
+        self._ordered_pending = [weakref.ref(p) for p in live]
+        total = sum(p.levels.nbytes() for p in live)
+        for p in live:
+            if total <= self.LEVELS_RESIDENT_MAX:
+                break
+            total -= p.levels.nbytes()
+            p.settle()
+
+    def _settle_engine_pendings(self):
+        for r in self._ordered_pending:
+            p = r()
+            if p is not None:
+                p.settle()
+        self._ordered_pending = []
+        self._transfer_pending = []
 
     # -- protocol engine ----------------------------------------------------------------------------
     def intersect_ray(self, bundle, surfaces, surf_relevancy):
