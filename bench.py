@@ -17,8 +17,12 @@ Prints ONE JSON line on rank 0: metric/value/unit per BASELINE.json, plus
                 kernels for one step, measured with HIP events on the launch stream, against the 8 TB/s HBM peak;
                 `traffic` = HBM bytes per step from the rocprofv3 PMC passes kept in profiles/traffic.json
   api_level     the same step through the public entry point, TracerEngine.ray_tracer(tree=False, accel=True): scene
-                signature check, hit buffer sized by the engine, receiver hits fetched and fed to the accountants
+                signature check, hit buffer sized by the engine; the receiver's hits stay on the device until its
+                accountants are read -- timed without and with that read after every call
                 (N=1 only, after the timed region; `value` above is the C-ABI call trc_trace_fast)
+  other_configs the other single-GPU configurations of BASELINE.json through the same C-ABI call, for the record (the
+                headline is unchanged): configs[1], dish + receiver at 1e7 rays, and one rank's share of configs[4],
+                dish into the spectral cavity at 1.25e8 rays
   check         receiver power, hit fractions; the process exits with status 3 when the receiver power is more than
                 5 sigma from the reference's own Monte-Carlo mean (tests/golden/mc_reference.npz)
   cpu_baseline  the oracle (NumPy restatement of the reference's algorithm = the reference's own CPU path, which
@@ -106,6 +110,58 @@ def traffic_for(n, accel):
     return None, None
 
 
+def other_configs(ctx, log):
+    """
+    The other single-GPU configurations of BASELINE.json through the same C-ABI call (trc_trace_fast, streaming form), third
+    run of three each: segments per second by the time of the kernels (HIP events) and by the wall clock of the call.
+      configs[1]  parabolic dish + circular receiver, Buie sunshape, 1e7 rays from the source descriptor
+      configs[4]  one rank's share (1.25e8 of 1e9 rays over 8 GPUs) of the dish into the cavity with spectral optics and slope
+                  error; every ray carries a wavelength, so the bundle is handed over as host arrays (7 columns over PCIe in
+                  the wall-clock figure, not in the kernel one)
+    """
+    import numpy as N
+    from tracer_amd import scenes
+    from tracer_amd.scene import compile_scene, DeviceScene
+    from tracer_amd.ray_bundle import RayBundle
+    out = {}
+    asm, dish_s, rec_s, src = scenes.dish()
+    dev = DeviceScene(compile_scene(asm), ctx)
+    n1 = 10 ** 7
+    for r in range(3):
+        t0 = time.time()
+        st, _ = dev.trace_fast(scenes.dish_source(n1, src, seed=3 + r), 100, 1e-10, 3 + r, accel=True, stream=True)
+        wall = time.time() - t0
+    a, rcv, h = dev.get_tallies()
+    dev.close()
+    out['configs[1]'] = {'workload': 'parabolic dish (D 5 m, f 3 m, slope error 2 mrad) + circular receiver, Buie sunshape CSR 0.05, 1e7 rays',
+                         'rays': n1, 'segments': int(st.segments), 'kernel_ms': st.kernel_ms, 'wall_ms': wall * 1e3,
+                         'Gsegments_per_s_kernels': st.segments / st.kernel_ms / 1e6, 'Gsegments_per_s_wall': st.segments / wall / 1e9,
+                         'roofline_frac_algorithmic': st.segments * B_SEG / (st.kernel_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                         'intercept': float(a[1] / (a[0] / 0.06 if a[0] > 0 else 1.))}
+    log('configs[1]: %.2f ms of kernels, %.1f G segments/s' % (st.kernel_ms, st.segments / st.kernel_ms / 1e6))
+    ts, src = scenes.dish_cavity()
+    n4 = 125000000
+    b0 = scenes.dish_source(n4, src, seed=9)
+    v, d, e = N.asarray(b0.get_vertices()), N.asarray(b0.get_directions()), N.asarray(b0.get_energy())
+    wl = N.random.default_rng(4).uniform(0.3e-6, 2.5e-6, n4)
+    dev = DeviceScene(ts, ctx)
+    for r in range(3):
+        dev.reset_tallies()
+        t0 = time.time()
+        st, _ = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e, wavelengths=wl), 12, 1e-3 * e[0], 31, stream=True)
+        wall = time.time() - t0
+    a, rcv, h = dev.get_tallies()
+    dev.close()
+    out['configs[4]'] = {'workload': 'one rank\'s share of 1e9 rays over 8 GPUs: dish with slope error into a cavity of seven walls with angle- and '
+                                     'wavelength-tabulated optics, rays with wavelengths handed over as host arrays, reps=12',
+                         'rays': n4, 'segments': int(st.segments), 'kernel_ms': st.kernel_ms, 'wall_ms': wall * 1e3,
+                         'Gsegments_per_s_kernels': st.segments / st.kernel_ms / 1e6, 'Gsegments_per_s_wall': st.segments / wall / 1e9,
+                         'roofline_frac_algorithmic': st.segments * B_SEG / (st.kernel_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                         'absorbed_share': float(a.sum() / e.sum()), 'launches': int(st.launches)}
+    log('configs[4]: %.1f ms of kernels, %.1f G segments/s' % (st.kernel_ms, st.segments / st.kernel_ms / 1e6))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -118,6 +174,10 @@ def main():
     ap.add_argument('--cpu-worker', nargs=3, metavar=('RAYS', 'SEED', 'BATCHES'), help=argparse.SUPPRESS)
     ap.add_argument('--api-steps', type=int, default=2, help='steps timed through TracerEngine.ray_tracer (N=1 only; 0 = skip)')
     ap.add_argument('--no-accel', action='store_true', help='brute force instead of the accelerated candidate search')
+    ap.add_argument('--no-extras', action='store_true', help='skip the other single-GPU configurations (other_configs; N=1 only)')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help="weak: every rank traces --rays rays per step (the driver's contract); strong: the ranks share the --rays rays of "
+                         "a step (distributed.shard), results identical for every number of GPUs")
     ap.add_argument('--kernel', choices=['auto', 'stream', 'megakernel'], default='auto',
                     help='fast-engine form: streaming kernels (default at this size) or the single persistent kernel')
     args = ap.parse_args()
@@ -169,17 +229,28 @@ def main():
         dev.set_kdtree(KdTree(plant, 8 + 1.3 * N.log(cs.n_surf), min_leaf=1))
     ue, ve = scenes.nsttf_fluxmap_edges()
     dev.set_fluxmap(218, ue, ve)
-    dev.set_hit_capacity(int(0.08 * n * (args.steps + args.warmup)) + 4096)   # receiver hits ~6.4 % of the source rays
+    dev.set_hit_capacity(int(0.08 * n * (args.steps + args.warmup)) + 4096 + 16 * 4096)   # receiver hits ~6.4 % of the source rays
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    strong = args.scaling == 'strong'
+    n_total = n                     # rays of a step over all ranks when they share it (strong scaling)
+    if strong:
+        from tracer_amd.distributed import shard
+        lo, hi = shard(n_total, rank, world)
+        n = hi - lo
+
     def step(k):
         # stream ids: disjoint per (step, rank) -- results do not depend on the number of GPUs
-        offset = (k * world + rank) * n
-        b = scenes.nsttf_source(n, src, seed=2024, ray_offset=offset)
+        offset = (k * n_total + lo) if strong else (k * world + rank) * n
+        if strong:
+            # (the energy of a ray is flux x area / rays of the WHOLE step, whichever rank traces it)
+            b = scenes.nsttf_source(n, src, seed=2024, ray_offset=offset, n_total=n_total)
+        else:
+            b = scenes.nsttf_source(n, src, seed=2024, ray_offset=offset)
         stats, _ = dev.trace_fast(b, 100, 1e-10, 2024, accel=accel, stream={'auto': None, 'stream': True, 'megakernel': False}[args.kernel])
         return stats
 
@@ -223,25 +294,38 @@ def main():
             eng = TracerEngine(plant)
             eng.set_fluxmap(218, ue, ve)
             mk = lambda k: scenes.nsttf_source(n, src, seed=2024, ray_offset=(args.steps + args.warmup + 1 + k) * n)
-            eng.ray_tracer(mk(0), reps=100, min_energy=1e-10, tree=False, accel=accel, seed=2024)       # warm-up: allocations, Kd-tree
+            rec_opt = plant.get_surfaces()[218].get_optics_manager()
+            eng.ray_tracer(mk(0), reps=100, min_energy=1e-10, tree=False, accel=accel, seed=2024)       # warm-up: allocations
+            rec_opt.get_all_hits()                                                                      # ... and the page-locked blocks
             plant.reset_all_optics()
             torch.cuda.synchronize()
-            t1 = time.time()
-            aseg = 0
-            for k in range(args.api_steps):
-                eng.ray_tracer(mk(1 + k), reps=100, min_energy=1e-10, tree=False, accel=accel, seed=2024)
-                aseg += eng.stats['segments']
-                plant.reset_all_optics()           # the accountants' lists of the step (filled from the device hit buffer)
-            torch.cuda.synchronize()
-            adt = time.time() - t1
+
+            def api_loop(read):
+                t1 = time.time()
+                aseg, got = 0, 0
+                for k in range(args.api_steps):
+                    eng.ray_tracer(mk(1 + k), reps=100, min_energy=1e-10, tree=False, accel=accel, seed=2024)
+                    aseg += eng.stats['segments']
+                    if read:
+                        got += len(rec_opt.get_all_hits()[0])     # absorbed energies and hit points of the step, on the host
+                        plant.reset_all_optics()
+                torch.cuda.synchronize()
+                adt = time.time() - t1
+                plant.reset_all_optics()
+                return adt / args.api_steps * 1e3, aseg / adt / 1e6, got
+            ms_unread, v_unread, _ = api_loop(False)
+            ms_read, v_read, got = api_loop(True)
             api = {'entry': 'TracerEngine.ray_tracer(bundle, reps=100, min_energy=1e-10, tree=False, accel=%r)' % accel,
-                   'steps': args.api_steps, 'ms_per_step': adt / args.api_steps * 1e3, 'value': aseg / adt / 1e6, 'unit': 'Mray-bounces/s',
-                   'includes': 'scene signature check, hit buffer of 2n+1024 entries emptied (the part the last trace used), trc_trace_fast, '
-                               '%d receiver hits per step (absorbed energy + hit point: 36 B each) packed on the device, copied to the host '
-                               'and fed to the receiver\'s accountants' % int(h[218] / max(args.steps, 1))}
-        total_rays = float(n) * args.steps * world
-        e_ray = 1000. * N.pi * src['radius'] ** 2 / n        # energy per ray of ONE step's bundle
-        receiver_kw = a[218] / args.steps / world / 1e3       # mean over the independent batches
+                   'steps': args.api_steps, 'ms_per_step': ms_unread, 'value': v_unread, 'unit': 'Mray-bounces/s',
+                   'ms_per_step_hits_read': ms_read, 'value_hits_read': v_read, 'hits_read_per_step': got // max(args.api_steps, 1),
+                   'includes': 'scene signature check, hit buffer kept or grown (the hits of successive calls stay on the device until an '
+                               'accountant is read), trc_trace_fast, marks handed to the receiver\'s accountants; hits_read: plus '
+                               'get_all_hits() of the receiver after every call -- the step\'s receiver hits (absorbed energy + hit point, '
+                               '36 B each) packed on the device and copied into page-locked host arrays -- and reset_all_optics()'}
+        total_rays = float(n_total) * args.steps * (1 if strong else world)
+        e_ray = 1000. * N.pi * src['radius'] ** 2 / n_total  # energy per ray of ONE step's bundle
+        n_bundles = args.steps * (1 if strong else world)     # independent bundles of n_total rays the job traced
+        receiver_kw = a[218] / n_bundles / 1e3                # mean over the independent batches
         ach = (seg * B_SEG / 1e9) / (kms / 1e3) if kms > 0 else 0.0     # GB/s, this rank's launches
         traffic, traffic_raw = traffic_for(n, accel)
         out = {
@@ -250,7 +334,7 @@ def main():
             'unit': 'Mray-bounces/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt_max / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'Sandia NSTTF heliostat field: 218 heliostats + receiver, Buie sunshape CSR 0.01, '
                                    '%.0e source rays per step per GPU, %s, reps=100, min_energy=1e-10; tallies + 50x50 '
@@ -258,7 +342,7 @@ def main():
                                    % (n, 'accel=True (Kd-tree built on the host as in the reference; the device searches a '
                                          'uniform grid over the same geometry boxes)' if accel else 'brute force'),
                        'rays_per_step_per_gpu': n, 'segments_per_step_per_gpu': seg / args.steps, 'accel': accel,
-                       'parallelism': 'rays sharded by stream id over %d GPU(s), one all-reduce of tallies at the end' % world},
+                       'parallelism': 'rays sharded by stream id over %d GPU(s) (%s), one all-reduce of tallies at the end' % (world, 'the ranks share the rays of a step' if strong else 'every rank its own rays per step')},
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_fetch_as_counted': traffic_raw,
                          'kernel': 'k_trace_coop<512>' if launches == 1 else
@@ -269,21 +353,30 @@ def main():
             'check': {'receiver_kW': receiver_kw, 'receiver_hits': int(h[218]), 'heliostat_hits': int(h[:218].sum()),
                       'segments_total': int(round(total_segments)), 'receiver_hits_per_ray': h[218] / total_rays,
                       'heliostat_hits_per_ray': float(h[:218].sum()) / total_rays,
-                      'fluxmap_sum_kW': float(fm.sum()) / args.steps / world / 1e3, 'energy_per_ray_W': e_ray},
+                      'fluxmap_sum_kW': float(fm.sum()) / n_bundles / 1e3, 'energy_per_ray_W': e_ray},
         }
         out['api_level'] = api
         out['cpu_baseline'] = cpu
+        if world == 1 and not args.no_extras and args.kernel == 'auto' and n >= 10 ** 7:
+            try:
+                if dev is not None:
+                    dev.close()
+                    dev = None
+                out['other_configs'] = other_configs(ctx, log)
+            except Exception as err:        # (for the record only: the headline stands without them)
+                log('other_configs skipped: %r' % (err,))
+                out['other_configs'] = None
         # the reference's own Monte-Carlo mean of the receiver power (10 runs of 1e5 rays): 5 sigma of both estimates
         ok = True
         try:
             mc = N.load(os.path.join(ROOT, 'tests', 'golden', 'mc_reference.npz'))
             p_ref, se_ref = float(mc['nsttf_receiver_mean']) / 1e3, float(mc['nsttf_receiver_se']) / 1e3
-            se_gpu = e_ray * N.sqrt(max(h[218], 1.)) / (args.steps * world) / 1e3
+            se_gpu = e_ray * N.sqrt(max(h[218], 1.)) / n_bundles / 1e3
             sig = float(N.sqrt(se_ref ** 2 + se_gpu ** 2))
             out['check']['reference_receiver_kW'] = p_ref
             out['check']['sigma_kW'] = sig
             out['check']['deviation_sigma'] = abs(receiver_kw - p_ref) / sig
-            ok = abs(receiver_kw - p_ref) <= 5. * sig and abs(float(fm.sum()) / args.steps / world / 1e3 - receiver_kw) <= 1e-6 * receiver_kw
+            ok = abs(receiver_kw - p_ref) <= 5. * sig and abs(float(fm.sum()) / n_bundles / 1e3 - receiver_kw) <= 1e-6 * receiver_kw
             out['check']['ok'] = bool(ok)
         except Exception as err:        # no fixture: nothing to compare with
             out['check']['ok'] = None

@@ -115,7 +115,11 @@ typedef enum trc_optics_kind {
                                            spectrum (trc_rays.spectra over trc_rays.spec_wl); each sample is scaled by 1 - absorptance(theta_in,
                                            lambda_w), the ray energy is the trapezoid integral of the result.  extra as
                                            LAMBERTIAN_DIRECTIONAL_SPECTRAL.  Ordered engine and protocol. */
-    TRC_OPT_KIND_COUNT = 16
+    TRC_OPT_PERIODIC_BOUNDARY = 16,     /* PeriodicBoundary :690-723: the ray stops on the surface (a stub of energy 0 keeps the tree
+                                           connected: block 0) and goes on, unchanged, from the hit point moved by `period` along
+                                           the oriented normal (block 1).  opt: period.  The fast engines follow the moved ray;
+                                           the ordered engine records both, the stub among the culled rays. */
+    TRC_OPT_KIND_COUNT = 17
 } trc_optics_kind;
 
 /* surface flags */
@@ -299,7 +303,8 @@ int trc_scene_reset_tallies(trc_scene *scene);
 int trc_scene_get_tallies(trc_scene *scene, double *absorbed, double *received, int64_t *hits);
 int trc_scene_get_fluxmap(trc_scene *scene, int32_t surf, double *out /* nu*nv, row-major u */);
 /* captured hits: in device arrival order when one surface captures; when several do, surface by surface (ascending index),
-   arrival order inside a surface. Query n first with all arrays NULL. */
+   arrival order inside a surface. Query n first with all arrays NULL -- or hand over arrays with room for every entry
+   reserved so far (trc_scene_hits_reserved: an upper bound of n) and read n afterwards. */
 int trc_scene_get_hits(trc_scene *scene, int64_t *n, int32_t *surf, double *e_abs, double *e_in,
                        double *px, double *py, double *pz, double *dx, double *dy, double *dz);
 /* View-factor allocation (emissive_losses/view_factors_3D.py:239-356 and :598-674, `alloc_VF`): the absorbed energy of
@@ -368,6 +373,10 @@ int trc_result_num_levels(trc_result *res, int32_t *n_levels);
 /* n_total rays recorded at this level, the first n_live of which continued to the next bounce */
 int trc_result_level_size(trc_result *res, int32_t level, int64_t *n_total, int64_t *n_live);
 /* copy a level to host arrays (capacity out->n >= n_total); surf[i] = surface that produced ray i (-1 at level 0) */
+/* surf[] of a level: the surface each ray of the level comes from.  TRC_LEVEL_VOLUME set: the ray never reached that surface --
+   it was scattered in the medium in front of it (RefractiveScatteringHomogenous, optics_callables.py:946-1036) and is filed
+   in the surface's scattered block; accountants of the surface do not see it. */
+#define TRC_LEVEL_VOLUME 0x40000000
 int trc_result_level_get(trc_result *res, int32_t level, trc_rays *out, int32_t *surf);
 int trc_result_destroy(trc_result *res);
 

@@ -89,6 +89,8 @@ def trace(scene, v, d, e, ref, wl, rid, reps, min_energy, seed, mat=None, spec=N
             for b in blocks:
                 k = b['sel']
                 start = pts[:, k] if 'back' not in b else pts[:, k] - b['back'][None, :] * d[:, sel][:, k]
+                if 'shift' in b:            # a periodic boundary: the ray goes on one period along the oriented normal
+                    start = start + b['shift'][None, :] * nrm[:, k]
                 o = dict(vertices=start, directions=b['directions'], energy=b['energy'], parents=sel[k],
                          surf=N.full(len(k), si), ref=b['ref'], wl=wl[sel][k], rid=b['rid'])
                 if 'mat' in carried:

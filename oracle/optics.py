@@ -258,6 +258,8 @@ def shade(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event, path=N
         f = spectral_factor(opt_kind, opt, extra, d, nrm)
         for b in blocks:
             b['spectra'] = spec[:, b['sel']] * f[b['sel']]
+        if opt_kind == OPT_PERIODIC_BOUNDARY:                    # the stub's spectrum is cancelled with its energy (:710-713)
+            blocks[0]['spectra'] = N.zeros_like(blocks[0]['spectra'])
     return blocks
 
 
@@ -271,6 +273,9 @@ def shade_core(opt_kind, opt, extra, up, d, e, ref, wl, nrm, seed, rid, event, p
     allsel = N.arange(H)
     if opt_kind == OPT_TRANSPARENT:                              # optics_callables.py:106-113
         return [dict(sel=allsel, directions=d.copy(), energy=e.copy(), ref=ref.copy(), rid=rid)]
+    if opt_kind == OPT_PERIODIC_BOUNDARY:                        # :703-723: the stub of energy 0, then the ray one period along the normal
+        return [dict(sel=allsel, directions=d.copy(), energy=N.zeros(H), ref=ref.copy(), rid=philox.child_rid(rid, event)),
+                dict(sel=allsel, directions=d.copy(), energy=e.copy(), ref=ref.copy(), rid=rid, shift=N.full(H, float(opt[0])))]
     if opt_kind in (OPT_REFLECTIVE, OPT_ONE_SIDED_REFLECTIVE):   # :130-140, :201-212
         eo = e * (1. - opt[0]) * iam(opt, 1, 2, d, nrm)
         if opt_kind == OPT_ONE_SIDED_REFLECTIVE:

@@ -406,6 +406,11 @@ def make_optics(ref, amd, out):
     run('poly_refractive_split', oc.RefractiveHomogenous(1.0, 1.5, single_ray=False), A.RefractiveHomogenous(1.0, 1.5, single_ray=False),
         ref_index=n_in, wavelengths=swl, spectra=spec)
 
+    # periodic boundary (:690-723): stub of energy 0 at the hit point, the ray itself one period along the oriented normal;
+    # (last in the list: the cases before keep their numbers and their seeds)
+    run('periodic_boundary', oc.PeriodicBoundary(0.7), A.PeriodicBoundary(0.7))
+    run('poly_periodic_boundary', oc.PeriodicBoundary(1.3), A.PeriodicBoundary(1.3), wavelengths=swl, spectra=spec)
+
     # O1: optics.fresnel_to_attenuating on a grid of incidence angles x complex indices (optics.py:63-81)
     th = N.tile(N.linspace(0., N.pi / 2. - 1e-3, 40), 6)
     m2 = N.repeat(N.array([1.5 + 0.01j, 0.2 + 3.4j, 2.7 + 2.9j, 1.0 + 0.j, 0.05 + 6.j, 3.9 + 0.2j]), 40)

@@ -58,7 +58,8 @@ def _worker(rank, world, port, n_total, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_shards_sum_to_single_process():
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_two_rank_shards_sum_to_single_process(world):
     import torch.multiprocessing as mp
     from tracer_amd import scenes
     from tracer_amd.scene import compile_scene
@@ -66,8 +67,8 @@ def test_two_rank_shards_sum_to_single_process():
     n_total = 6001
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    port = 29500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
     for p in procs:
         p.start()
     total = q.get(timeout=240)

@@ -367,7 +367,7 @@ def test_minidish_upright_and_rotated():
 
 def test_engines_built_in_a_loop_leave_device_memory_bounded():
     """scripts build an assembly and an engine per run: freed device blocks wait in the library's pool for the next request of
-    their size class (DevPool: blocks up to 128 MiB, at most 2 GiB idle).  Thirty runs of growing size -- 60 GB of levels, scratch and hit buffers
+    their size class (DevPool: blocks up to 128 MiB, at most 2 GiB idle; larger ones by exact size, 2 GiB more).  Thirty runs of growing size -- 60 GB of levels, scratch and hit buffers
     allocated and released in all -- end with no more than that held back, and every run gives the same physics."""
     import ctypes
     from tracer_amd.models.tau_minidish import MiniDish
@@ -393,7 +393,7 @@ def test_engines_built_in_a_loop_leave_device_memory_bounded():
         if i == 0:
             free_before = free_bytes()                          # after the first run: context and library are up
     held = free_before - free_bytes()
-    assert held < 2.5 * 2 ** 30, held
+    assert held < 4.5 * 2 ** 30, held
     assert max(share) - min(share) < 0.004 and abs(N.mean(share) - 0.6012) < 0.001
 
 

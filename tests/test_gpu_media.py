@@ -217,3 +217,76 @@ def test_polychromatic_wall_without_spectra_is_an_error(ctx):
     with pytest.raises(TracerAmdError) as err:
         TracerEngine(asm).ray_tracer(b, reps=2, min_energy=1e-9)
     assert 'spectra' in str(err.value)
+
+
+def test_periodic_cell_vs_oracle_and_known_answer(ctx):
+    """
+    PeriodicBoundary as a native optics kind (optics_callables.py:690-723): a cell 2 m wide between two
+    periodic walls at x = -1 and x = +1, a diffuse floor and a black ceiling that captures its hits.  Rays cross the walls,
+    re-enter one period along the wall's normal and go on.  The ordered engine records the reference's bundle -- per wall
+    the stubs of energy 0 (culled: behind the live rays) and the moved rays -- level by level as the oracle does; both forms
+    of the fast engine follow the moved ray and end with the oracle's tallies; a ray aimed by hand lands where the
+    periodic image says.
+    """
+    from tracer_amd import optics_callables as opt
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM
+    from tracer_amd.spatial_geometry import roty, rotx, translate
+    from tracer_amd.tracer_engine import TracerEngine
+    from tracer_amd.ray_bundle import RayBundle
+    from tracer_amd.scene import compile_scene, DeviceScene
+    from oracle import engine as oracle_engine
+
+    def cell():
+        left = Surface(RectPlateGM(8., 4.), opt.PeriodicBoundary(2.))      # plates in the y-z plane: local z along global x
+        right = Surface(RectPlateGM(8., 4.), opt.PeriodicBoundary(2.))
+        floor = Surface(RectPlateGM(2., 4.), opt.Lambertian(0.3))
+        top = Surface(RectPlateGM(2., 4.), opt.LambertianReceiver(1.))
+        objs = [AssembledObject(surfs=[left], transform=N.dot(translate(-1., 0., 2.), roty(N.pi / 2.))),
+                AssembledObject(surfs=[right], transform=N.dot(translate(1., 0., 2.), roty(N.pi / 2.))),
+                AssembledObject(surfs=[floor]),
+                AssembledObject(surfs=[top], transform=N.dot(translate(0., 0., 3.), rotx(N.pi)))]
+        return Assembly(objects=objs), top
+    n = 6000
+    rng = N.random.default_rng(11)
+    v = N.vstack((rng.uniform(-0.9, 0.9, n), rng.uniform(-1.5, 1.5, n), N.full(n, 2.5)))
+    d = N.vstack((rng.uniform(-1.5, 1.5, n), rng.uniform(-0.2, 0.2, n), -N.ones(n)))
+    d /= N.sqrt(N.sum(d ** 2, axis=0))
+    e = N.ones(n) / n
+    asm, top = cell()
+    cs = compile_scene(asm)
+    from tracer_amd import _cabi
+    assert [dsc.optics_kind for dsc in cs.descs][:2] == [_cabi.OPT_PERIODIC_BOUNDARY] * 2 and not cs.splits
+    with N.errstate(all='ignore'):
+        o = oracle_engine.trace_bundle(cs, v, d, e, 8, 1e-9, 33)
+    # ordered engine: the tree, level by level
+    eng = TracerEngine(asm)
+    eng.ray_tracer(RayBundle(vertices=v, directions=d, energy=e), reps=8, min_energy=1e-9, tree=True, seed=33)
+    assert eng.stats['engine'] == 'ordered'
+    _compare_levels(eng.tree, o, complex_index=False)
+    L1 = eng.tree[1]
+    crossed = int((o['levels'][1]['surf'] <= 1).sum()) // 2
+    assert crossed > n // 4, "a good share of the rays crosses a wall before the floor"
+    assert (L1.get_energy() == 0).sum() == crossed and (L1.get_energy()[-crossed:] == 0).all(), "the stubs: energy 0, behind the live rays"
+    a_ord, r_ord, h_ord = eng.get_tallies()
+    assert N.array_equal(h_ord, o['hits']) and N.allclose(a_ord, o['absorbed'], rtol=1e-9, atol=1e-12)
+    assert a_ord[0] == 0. and a_ord[1] == 0., "a periodic boundary keeps nothing"
+    # the fast engine, both forms: the moved ray is the ray
+    for stream in (False, True):
+        dev = DeviceScene(cs, ctx)
+        st, _ = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e), 8, 1e-9, 33, stream=stream)
+        a, r, h = dev.get_tallies()
+        dev.close()
+        assert N.array_equal(h, o['hits']) and N.allclose(a, o['absorbed'], rtol=1e-9, atol=1e-12), stream
+        assert st.segments == o['segments']
+    # known answer: from (0.5, 0, 1) along (+1, 0, +1) / sqrt 2 the ray meets the right wall at (1, 0, 1.5), re-enters at
+    # (-1, 0, 1.5) -- one period along the normal that faces it -- and reaches the ceiling z = 3 at x = -1 + 1.5 = 0.5
+    asm, top = cell()
+    eng = TracerEngine(asm)
+    eng.ray_tracer(RayBundle(vertices=N.c_[[0.5, 0., 1.]], directions=N.c_[[1., 0., 1.]] / N.sqrt(2.), energy=N.r_[1.]), reps=5,
+                   min_energy=1e-9, tree=True, seed=1)
+    absorbed, hits = top.get_optics_manager().get_all_hits()
+    assert N.allclose(absorbed, [1.]) and N.allclose(hits[:, 0], [0.5, 0., 3.], atol=1e-12)
+    assert N.allclose(eng.tree[1].get_vertices(), N.c_[[-1., 0., 1.5], [1., 0., 1.5]], atol=1e-12) and N.allclose(eng.tree[1].get_energy(), [1., 0.])

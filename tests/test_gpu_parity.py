@@ -166,7 +166,9 @@ def test_optics_vs_reference_and_oracle(ctx):
                      'refractive_split', 'fresnel_conductor', 'refractive_transmissive_split', 'refractive_transmissive_one_coefficient',
                      # SURVEY 8(f)2, rest: complex indices of tabulated materials, attenuation from Im m; polychromatic bundles
                      'material_split', 'material_absorbant_split', 'material_absorbant_scaled',
-                     'poly_transparent', 'poly_reflective', 'poly_one_sided_reflective', 'poly_real_reflective', 'poly_refractive_split')
+                     'poly_transparent', 'poly_reflective', 'poly_one_sided_reflective', 'poly_real_reflective', 'poly_refractive_split',
+                     # the periodic boundary as a native kind (stub + the ray one period along the normal)
+                     'periodic_boundary', 'poly_periodic_boundary')
     seen = 0
     for i, name in enumerate(names):
         pre = 'o%d_' % i
@@ -485,8 +487,25 @@ def test_kdtree_traversal_standalone(ctx):
         any_o, rel_o = accel.traversal(kd.flat(), S, N.asarray(b.get_vertices()), N.asarray(b.get_directions()))
     assert any2 == any_o and N.array_equal(rel2, rel_o)
     assert rel2[:-1].any(axis=0).sum() > 5000
-    with pytest.raises(NotImplementedError):
-        kd.traversal(b, lightweight=True)
+    # lightweight=True (accel_tree.py:227-233, :281-286, :301-305): per surface, batches of ray numbers in the order of the leaves a
+    # ray passes.  Every (surface, ray) pair the matrix marks appears in exactly one batch, and nothing else does; a ray's batch
+    # number for a surface is the count of leaves it passed before the first one that lists the surface.
+    sub = RayBundle(vertices=v[:, :300], directions=d[:, :300], energy=N.ones(300))
+    any_l, lists = kd.traversal(sub, lightweight=True)
+    assert any_l == any_inter and len(lists) == S
+    back = N.zeros((S, 300), dtype=bool)
+    first_batch = N.full((S, 300), -1)
+    for s_i, batches in enumerate(lists):
+        flat = [r for bt in batches for r in bt]
+        assert len(flat) == len(set(flat)), "a ray is listed once per surface"
+        for k, bt in enumerate(batches):
+            back[s_i, bt] = True
+            first_batch[s_i, bt] = k
+    assert N.array_equal(back, rel[:, :300])
+    always = N.asarray(kd.always_relevant, dtype=int)
+    assert (first_batch[always] == 0).all()
+    crossing = N.nonzero(rel[:-1, :300].any(axis=0))[0]
+    assert len(crossing) > 20 and first_batch[:-1][:, crossing].max() >= 1, "some rays meet a mirror in the second leaf they cross or later"
 
 
 def test_full_size_properties(ctx):

@@ -245,20 +245,21 @@ def test_terminal_surfaces_are_finished_by_k_s_absorb(ctx):
             assert N.allclose(a[key], b[key], rtol=1e-9, atol=1e-12), (what, key)
 
 
-def test_dish_into_spectral_cavity_at_scale(ctx):
+@pytest.mark.parametrize('n', [20000000, 125000000])
+def test_dish_into_spectral_cavity_at_scale(ctx, n):
     """
-    BASELINE configs[4] on one rank, 2e7 rays here (tools/gpu_cavity.py runs the 1.25e8 of a rank's share): a dish with slope error
+    BASELINE configs[4] on one rank, at 2e7 rays and at the 1.25e8 of a rank's share of 1e9 rays over 8 GPUs: a dish with slope error
     focuses a Buie sun into a cavity whose walls have angle- and wavelength-dependent optics (frustum, cylinder, cone, annulus, a
     Fresnel conductor, a spectral mirror); every ray carries a wavelength.  Streaming form (two batches in flight) == megakernel:
     hit counts and segments exactly, energies to 1e-9; the first 3000 rays == the oracle ray for ray; the shares of the 2e7 rays
-    per surface agree with those 3000 within 5 sigma; nothing is created: absorbed + still alive <= sent.
+    per surface agree with those 3000 within 5 sigma; nothing is created: absorbed + still alive <= sent.  The classes of optics present -- mirror, diffuse walls, the
+    conductor -- are shaded by three kernels off a hit list parted by class (k_s_partition).
     """
     from tracer_amd import scenes
     from tracer_amd.scene import DeviceScene
     from tracer_amd.ray_bundle import RayBundle
     from oracle import engine as oracle_engine
     ts, src = scenes.dish_cavity()
-    n = 20000000
     b0 = scenes.dish_source(n, src, seed=9)
     v, d, e = N.asarray(b0.get_vertices()), N.asarray(b0.get_directions()), N.asarray(b0.get_energy())
     wl = N.random.RandomState(4).uniform(0.3e-6, 2.5e-6, n)
@@ -418,8 +419,11 @@ def test_full_size_routes_agree(ctx):
     _same(out[n], _trace(ctx, cs, bundle, kd=kd, fluxmap=(218, ue, ve), reps=100, stream=None, accel=False), 'brute force, 1e8')
 
 
-def test_bench_as_two_ranks_on_one_gpu(ctx):
+@pytest.mark.parametrize('world', [2, 4])
+def test_bench_as_two_ranks_on_one_gpu(ctx, world):
     """
+    (world 2 and 4: the GPU box allows six processes on its card, and this one is the fifth; eight ranks are rehearsed on the CPU,
+    tests/test_distributed_cpu.py)
     bench.py under torch.distributed.run with two ranks sharing this GPU (TRC_BENCH_BACKEND=gloo: the tallies cross ranks through
     the host; on an 8-GPU node the same code path uses RCCL): rays sharded by stream id, one reduction of the packed tally buffer.
     The line it prints must hold the sum of both ranks -- hits and segments equal to the same four batches traced in this
@@ -430,8 +434,8 @@ def test_bench_as_two_ranks_on_one_gpu(ctx):
     from tracer_amd.accel_tree import KdTree
     from tracer_amd.scene import compile_scene, DeviceScene
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    n, steps, warmup, world = 3000000, 2, 1, 2
-    port = 29600 + os.getpid() % 300
+    n, steps, warmup = 3000000, 2, 1
+    port = 29600 + os.getpid() % 300 + world
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', str(steps), '--warmup', str(warmup),
            '--rays', str(n), '--cpu-rays', '0', '--api-steps', '0']
@@ -457,6 +461,36 @@ def test_bench_as_two_ranks_on_one_gpu(ctx):
     assert c['receiver_hits'] == h[218] and c['heliostat_hits'] == h[:218].sum() and c['segments_total'] == seg
     assert N.isclose(c['receiver_kW'], a[218] / (steps * world) / 1e3, rtol=1e-9)
     assert N.isclose(out['value'], seg / (out['ms_per_step'] * 1e-3 * steps) / 1e6, rtol=1e-6)
+
+
+def test_bench_strong_scaling_gives_the_same_tallies_for_every_world_size(ctx):
+    """
+    bench.py --scaling strong: the ranks share the rays of a step (distributed.shard over the stream ids), so the job's
+    tallies do not depend on the number of ranks -- hit counts and segments to the last ray, energies to rounding (the
+    reference's multi-process driver, tracer_engine_mp.py:19-124, merges independent bundles; here one bundle is split).
+    """
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, steps, warmup = 4000001, 2, 1
+    outs = {}
+    for world in (1, 2, 4):
+        port = 29900 + os.getpid() % 300 + world
+        tail = [os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', str(steps), '--warmup', str(warmup), '--rays', str(n),
+                '--cpu-rays', '0', '--api-steps', '0', '--scaling', 'strong']
+        cmd = [sys.executable] + tail if world == 1 else \
+            [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+             '--master-port', str(port)] + tail
+        envv = dict(os.environ, TRC_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        p = subprocess.run(cmd, cwd=root, env=envv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        outs[world] = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
+        assert outs[world]['scaling'] == 'strong' and outs[world]['n_gpus'] == world and outs[world]['check']['ok'] is True
+    c1 = outs[1]['check']
+    for world in (2, 4):
+        c = outs[world]['check']
+        for key in ('receiver_hits', 'heliostat_hits', 'segments_total'):
+            assert c[key] == c1[key], (world, key)
+        assert N.isclose(c['receiver_kW'], c1['receiver_kW'], rtol=1e-12) and N.isclose(c['fluxmap_sum_kW'], c1['fluxmap_sum_kW'], rtol=1e-12)
 
 
 def test_forms_of_the_fast_engine_end_every_ray_alike(ctx):

@@ -282,3 +282,40 @@ def test_bench_reports_the_committed_traffic():
     hi, lo = bench.traffic_for(1e8, True)
     assert hi is not None and lo is not None and 1e9 < lo <= hi < 2 * lo
     assert bench.traffic_for(1e7, True) == (None, None) and bench.traffic_for(1e8, False) == (None, None)
+
+
+def test_estimator_running_mean_and_interval():
+    """tracer_amd.estimator (the reference's ray_trace_utils/estimator.py:3-56 by name and arguments): the running weighted mean
+    and its confidence interval against a direct evaluation of the formulas, batches of unequal size, vector-valued samples"""
+    from tracer_amd.estimator import Estimator, MCRT_to_CI
+    rng = N.random.default_rng(3)
+    w = N.array([100., 250., 80., 400., 170.])
+    x = rng.normal(5., 0.3, size=(5, 3))
+    est = Estimator(n_sigmas=2.5, relative_CI=False)
+    assert N.isinf(est.get_CI()).all()
+    est.update(x[0], w[0])
+    assert N.isinf(est.get_CI()).all() and N.allclose(est.mean, x[0])
+    for k in range(1, 5):
+        est.update(x[k], w[k])
+    W, W2 = w.sum(), (w ** 2).sum()
+    mean = (w[:, None] * x).sum(axis=0) / W
+    S = (w[:, None] * (x - mean) ** 2).sum(axis=0)
+    half = 2.5 * N.sqrt(S / (W - W2 / W)) / N.sqrt(W * W / W2)
+    assert N.allclose(est.mean, mean, rtol=1e-13) and N.allclose(est.M2, S, rtol=1e-10) and N.allclose(est.get_CI(), half, rtol=1e-10)
+    rel = Estimator(n_sigmas=2.5)
+    for k in range(5):
+        rel.update(x[k], w[k])
+    assert N.allclose(rel.get_CI(), half / mean, rtol=1e-10)
+    same = Estimator()
+    same.update(N.r_[2.], 10); same.update(N.r_[2.], 30)
+    assert same.get_CI()[0] == 0.
+    calls = []
+    def batch(num_rays):
+        calls.append(num_rays)
+        return N.r_[1. + 0.01 * rng.normal()]
+    out = MCRT_to_CI(batch, 0.01, 1000)
+    assert len(calls) >= 2 and out.get_CI()[0] <= 0.01 and abs(out.mean[0] - 1.) < 0.05
+    import tracer_amd.compat as compat
+    compat.install()
+    from ray_trace_utils.estimator import Estimator as E2
+    assert E2 is Estimator

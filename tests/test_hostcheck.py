@@ -109,7 +109,7 @@ def test_core_optics_vs_oracle_same_streams(hc):
         if spec is not None:
             assert N.allclose(o_spec[:, slots], N.hstack([b['spectra'] for b in blocks]), rtol=1e-12, atol=0), name
         carried += int(mat is not None or spec is not None)
-    assert carried == 15
+    assert carried == 16
 
 
 def test_core_sources_vs_oracle(hc):

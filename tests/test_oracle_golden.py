@@ -60,7 +60,7 @@ def test_optics_variate_replay():
     # deterministic kinds go through shade() itself
     rid = N.arange(H, dtype=N.uint64)
     for name in ('transparent', 'reflective', 'one_sided_reflective', 'real_reflective_sigma0', 'reflective_spectral',
-                 'refractive_split', 'fresnel_conductor'):
+                 'refractive_split', 'fresnel_conductor', 'periodic_boundary'):
         pre = _optics_case(o, name)
         blocks = optics.shade(int(o[pre + 'kind']), list(o[pre + 'opt']), o[pre + 'extra'], up, d, e, o[pre + 'ref_in'], wl, nrm, 1, rid, 1)
         dirs = N.hstack([b['directions'] for b in blocks])
@@ -68,7 +68,12 @@ def test_optics_variate_replay():
         par = N.hstack([b['sel'] for b in blocks])
         ref = N.hstack([b['ref'] for b in blocks]) if (pre + 'out_ref') in o.files else None
         check(pre, dirs, en, par, ref)
-        assert N.allclose(o[pre + 'out_vertices'], pts[:, par], **TOL)
+        # outgoing rays start at the hit points -- but for a periodic boundary, whose second block starts one period along the normal
+        start = N.hstack([pts[:, b['sel']] + (b['shift'][None, :] * nrm[:, b['sel']] if 'shift' in b else 0.) for b in blocks])
+        assert N.allclose(o[pre + 'out_vertices'], start, **TOL)
+        if name == 'periodic_boundary':         # (optics_callables.py:703-723: stubs of energy 0, then the rays themselves, moved)
+            assert len(blocks) == 2 and (en[:H] == 0).all() and N.array_equal(en[H:], e) and N.array_equal(dirs[:, H:], d)
+            assert N.allclose(o[pre + 'out_vertices'][:, H:], pts + 0.7 * nrm, **TOL)
     # slope error: replay numpy's normal / uniform draws
     for name, bi, onesided in (('real_reflective_bivar', True, False), ('real_reflective_radial', False, False),
                                ('one_sided_real_reflective', True, True), ('real_reflective_iam', True, False)):
@@ -247,7 +252,10 @@ def test_optics_carried_columns_replay():
         assert N.allclose(cat(b, 'spectra'), o[pre + 'out_spectra'], rtol=1e-12, atol=0), name
         assert N.allclose(cat(b, 'energy'), o[pre + 'out_energy'], rtol=1e-9, atol=1e-12), name
         scaled += int(not N.array_equal(o[pre + 'out_spectra'], o[pre + 'spec_in'][:, o[pre + 'out_parents']]))
-    assert scaled == 5, "Reflective, OneSidedReflective, RealReflective, Lambertian and the directional wall scale the spectrum"
+    assert scaled == 6, "Reflective, OneSidedReflective, RealReflective, Lambertian and the directional wall scale the spectrum; " \
+                        "PeriodicBoundary cancels its stub's"
+    pre = _optics_case(o, 'poly_periodic_boundary')
+    assert (o[pre + 'out_spectra'][:, :H] == 0).all() and N.array_equal(o[pre + 'out_spectra'][:, H:], o[pre + 'spec_in'])
 
 
 def test_fresnel_to_attenuating_grid():

@@ -29,6 +29,7 @@ TRACE_MEGAKERNEL = 0x8
 # surface flags
 SURF_CAPTURE_HITS = 0x1
 SURF_CAPTURE_LEAN = 0x2
+LEVEL_VOLUME = 0x40000000        # TRC_LEVEL_VOLUME: bit of a level's surf[] entries (trc_result_level_get)
 
 # enum trc_gm_kind
 (GM_FLAT_INF, GM_RECT, GM_RECT_EXTRUDED, GM_RECT_PERFORATED, GM_ROUND, GM_ROUND_CUT, GM_TRIANGLE,
@@ -42,7 +43,7 @@ SURF_CAPTURE_LEAN = 0x2
  OPT_ONE_SIDED_REAL_REFLECTIVE, OPT_LAMBERTIAN, OPT_LAMBERTIAN_SPECULAR, OPT_REFRACTIVE_HOMOGENOUS,
  OPT_REFLECTIVE_SPECTRAL, OPT_LAMBERTIAN_DIRECTIONAL, OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL,
  OPT_FRESNEL_CONDUCTOR, OPT_SEMI_LAMBERTIAN, OPT_REFRACTIVE_SCATTERING, OPT_REFRACTIVE_MATERIAL,
- OPT_LAMBERTIAN_POLYCHROMATIC) = range(16)
+ OPT_LAMBERTIAN_POLYCHROMATIC, OPT_PERIODIC_BOUNDARY) = range(17)
 
 # enum trc_source_kind
 SRC_PILLBOX_DISK, SRC_PILLBOX_RECT, SRC_BUIE_DISK, SRC_BUIE_RECT, SRC_PILLBOX_TRIANGLE, SRC_VF_CYLINDER, SRC_VF_FRUSTUM = range(7)
@@ -301,11 +302,53 @@ def default_device():
     return int(os.environ.get('LOCAL_RANK', '0'))
 
 
+def _torch_first():
+    """
+    PyTorch-ROCm brings its own copy of the HIP runtime.  Whichever of the two runtimes in the process is initialised second
+    sees the GPUs only if it is torch's that came first; the other way round torch reports "No HIP GPUs are available"
+    (INTEGRATION.md).  So when torch is already imported -- a job that will exchange tallies through torch.distributed --
+    its runtime is initialised here, before the library's context exists.
+    """
+    import sys
+    torch = sys.modules.get('torch')
+    if torch is None or _contexts:
+        return
+    try:
+        cuda = torch.cuda
+        if cuda.is_available() and not cuda.is_initialized():
+            cuda.init()
+    except Exception:       # a CPU-only torch, or no GPU: nothing to order
+        pass
+
+
+def check_torch_order():
+    """
+    Called before a device tensor of torch meets the library (distributed.reduce_scene_tallies, nccl): a loud error instead of
+    torch's "No HIP GPUs are available" when torch was imported after the library's context had been created.
+    """
+    import sys
+    torch = sys.modules.get('torch')
+    if torch is None:
+        return
+    ok = False
+    try:
+        ok = torch.cuda.is_available()
+    except Exception:
+        ok = False
+    if not ok and _contexts:
+        raise RuntimeError(
+            "torch cannot see the GPU: the HIP runtime of libtracer_amd.so was initialised before torch's own copy of it. "
+            "Import torch (and call torch.cuda.init() or torch.cuda.set_device(...)) before the first tracer_amd context is "
+            "created -- tracer_amd._cabi.get_context() does this by itself when torch is already imported -- or exchange the "
+            "tallies through the host (backend 'gloo').")
+
+
 def get_context(device_id=None):
     if device_id is None:
         device_id = default_device()
     ctx = _contexts.get(device_id)
     if ctx is None:
+        _torch_first()
         ctx = Context(device_id)
         _contexts[device_id] = ctx
     return ctx

@@ -153,11 +153,11 @@ class KdTree(object):
         Which surfaces each ray of `bundle` has to be tested against (accel_tree.py:213-312): (any_inter, relevancy), relevancy a
         (n_surfs, n_rays) boolean array, True where the ray crosses a leaf holding the surface -- every leaf on its way through the
         root box -- or the surface has no bounds.  Walked on the device, one ray per lane (trc_kdtree_traversal).
-        lightweight=True is the reference's list-of-lists scheduling of the same information (:227-233, :281-286, :301-305); the
-        engines here never consume it (the device walks front to back): not offered.
+        lightweight=True: the reference's list-of-lists scheduling of the same information (:227-233, :281-286, :301-305), see
+        _traversal_lightweight.
         """
         if lightweight:
-            raise NotImplementedError("the lightweight scheduling lists are a CPU artefact of the reference; use lightweight=False")
+            return self._traversal_lightweight(bundle)
         import ctypes as C
         from . import _cabi
         ctx = _cabi.get_context()
@@ -180,6 +180,84 @@ class KdTree(object):
         return bool(any_inter.value), rel.view(bool)
 
     # ------------------------------------------------------------------------------------------
+    def _traversal_lightweight(self, bundle):
+        """
+        traversal(bundle, lightweight=True) (accel_tree.py:213-312): (any_inter, surfaces_relevancy) with
+        surfaces_relevancy[s] a list of batches of ray numbers -- batch k holds the rays whose k-th leaf on their way through
+        the tree lists surface s, a ray only in the first batch of a surface it appears in (:301-305) -- so that
+        intersect_ray_accel_seq (tracer_engine.py:66-122) can test a surface's near rays before its far ones.  The engines here
+        never consume it (the device walks front to back by itself); it is offered for scripts that read it.  The walk is the
+        reference's, ray by ray on the host (a scheduling list is host data by nature); which (surface, ray) pairs appear at
+        all is what the device traversal marks, and the two are compared in the tests.  Surfaces without bounds take every
+        ray in their first batch: the reference's own line for them (:229-231) appends bare ray numbers next to the batches
+        and its clean-up (:301-305) then fails on them, so there is no other behaviour to follow.
+        """
+        f = self.flat()
+        flag, split, child = f['flag'], f['split'], f['child']
+        leaf_off, leaf_cnt, leaf_surfs = f['leaf_off'], f['leaf_cnt'], f['leaf_surfs']
+        poss = N.asarray(bundle.get_vertices(), dtype=float)
+        dirs = N.asarray(bundle.get_directions(), dtype=float)
+        nrays = poss.shape[1]
+        with N.errstate(all='ignore'):
+            inv = 1. / dirs
+            bounds = N.array([N.ravel(self.minpoint), N.ravel(self.maxpoint)], dtype=float)
+            neg = N.array(dirs < 0, dtype=int)
+            t_mins, t_maxs = N.zeros(nrays), N.full(nrays, N.inf)
+            for i in range(3):                                  # intersect_bounds (:314-330)
+                lo = (bounds[neg[i], i] - poss[i]) * inv[i]
+                hi = (bounds[1 - neg[i], i] - poss[i]) * inv[i]
+                swap = lo > hi
+                lo[swap], hi[swap] = hi[swap], lo[swap]
+                t_mins, t_maxs = N.maximum(t_mins, lo), N.minimum(t_maxs, hi)
+            inters = t_maxs > 0
+            inters[t_mins > t_maxs] = False
+        rel = [[[]] for _ in range(self.n_surfs)]
+        for s in N.asarray(self.always_relevant, dtype=int):
+            rel[s][0] = list(range(nrays))
+        any_inter = False
+        order = N.zeros(nrays, dtype=int)
+        if inters.any() or len(self.always_relevant):
+            for r in N.nonzero(inters)[0]:
+                t_min, t_max = t_mins[r], t_maxs[r]
+                stack = []
+                node = 0
+                while True:
+                    if t_maxs[r] < t_min:
+                        break
+                    if flag[node] != 3:
+                        ax = flag[node]
+                        with N.errstate(all='ignore'):
+                            t_plane = (split[node] - poss[ax, r]) * inv[ax, r]
+                        c1, c2 = child[node], child[node] + 1
+                        below = (poss[ax, r] < split[node]) or (poss[ax, r] == split[node] and dirs[ax, r] <= 0.)
+                        if not below:
+                            c1, c2 = c2, c1
+                        if t_plane > t_max or t_plane <= 0.:
+                            node = c1
+                        elif t_plane < t_min:
+                            node = c2
+                        else:
+                            stack.append((c2, t_plane, t_max))
+                            node = c1
+                            t_max = t_plane
+                    else:
+                        for s in leaf_surfs[leaf_off[node]:leaf_off[node] + leaf_cnt[node]]:
+                            while len(rel[s]) <= order[r]:
+                                rel[s].append([])
+                            if r not in rel[s][order[r]]:
+                                rel[s][order[r]].append(int(r))
+                        order[r] += 1
+                        if not stack:
+                            break
+                        node, t_min, t_max = stack.pop()
+            for s in rel:                                        # a ray is tested once per surface: in its first batch (:301-305)
+                seen = set()
+                for batch in s:
+                    batch[:] = [r for r in batch if r not in seen]
+                    seen.update(batch)
+            any_inter = True
+        return any_inter, rel
+
     def flat(self):
         """Arrays for trc_kdtree_desc."""
         n = len(self.nodes)

@@ -53,4 +53,6 @@ def install(force=False):
     sys.modules.setdefault('ray_trace_utils.vector_manipulations', rtu.vector_manipulations)
     rtu.stl_utils = importlib.import_module('tracer_amd.stl_utils')
     sys.modules.setdefault('ray_trace_utils.stl_utils', rtu.stl_utils)
+    rtu.estimator = importlib.import_module('tracer_amd.estimator')
+    sys.modules.setdefault('ray_trace_utils.estimator', rtu.estimator)
     return root

@@ -951,6 +951,7 @@ struct trc_ray_out {
                // 1 reflected, 2 refracted (optics_callables.py:1136-1168: "stacking together the scattered, reflected and refracted rays")
     double back;   // 0: the ray leaves from the hit point.  > 0: a volume event on the way -- the ray never reached the surface, it
                    // leaves from the point `back` before the hit along its old direction, and the surface records nothing
+    double shift;  // the ray leaves from the hit point moved by `shift` along the oriented normal (PeriodicBoundary, :717); 0: from the hit
     double sf;     // factor on the spectrum a polychromatic ray carries (`outg._spectra *= ...` of the classes that have the line);
                    // read by the ordered engine and the per-surface protocol only
 };
@@ -1204,7 +1205,15 @@ TRC_HD int trc_shade_k(int opt_kind, const double *opt, const double *extra, int
     out[1].back = 0.0;
     out[0].sf = 1.0;
     out[1].sf = 1.0;
+    out[0].shift = 0.0;
+    out[1].shift = 0.0;
     switch (opt_kind) {
+    case TRC_OPT_PERIODIC_BOUNDARY:                                 // :703-723
+        // out[0] is the ray that goes on (the one the fast engines follow); the ordered engine files the children by block, so
+        // the stub (block 0, energy 0: culled) still stands before the moved ray (block 1) where the reference puts it
+        out[0].dx = dx; out[0].dy = dy; out[0].dz = dz; out[0].e = e; out[0].blk = 1; out[0].shift = opt[0];
+        out[1].dx = dx; out[1].dy = dy; out[1].dz = dz; out[1].e = 0.0; out[1].ref = ref; out[1].blk = 0; out[1].sf = 0.0;   // :710-713
+        return 2;
     case TRC_OPT_TRANSPARENT:                                       // :106-113
         out[0].dx = dx; out[0].dy = dy; out[0].dz = dz; out[0].e = e;
         return 1;

@@ -193,7 +193,7 @@ __device__ __forceinline__ unsigned long long chunk_append(unsigned long long *c
     return idx;
 }
 
-#define SHADE_MAX_WAVES 4096     /* waves of one k_s_shade launch (at most n_cu * 4 workgroups of 4 waves, n_cu <= 256) */
+#define SHADE_MAX_WAVES 5120     /* waves of one launch of a shading kernel (at most n_cu * 2 workgroups of 10 waves, n_cu <= 256) */
 #define SQ_HIT_CHUNK 1024        /* entries of the hit buffer a wave of k_s_shade reserves per atomic: the cursor is one word (~88 returning
                                     atomics per microsecond), and at 256 the 12 000 reservations of an NSTTF batch were half of the kernel */
 #define TRC_HIT_HOLDERS (4ll * SHADE_MAX_WAVES)   /* waves that can hold an open chunk of the hit buffer: SHADE_MAX_WAVES per slot (the shading
@@ -338,7 +338,7 @@ __device__ __forceinline__ bool fast_shade(const FastParams &P, const double *re
     double e_abs = e - out[0].e;
     record_hit<LDS_TALLY>(sc, l_tally, s, e, e_abs, hx, hy, hz, dx, dy, dz, P.capture != 0, prev, hc, lds_fm, volume, tallied);
     if (!volume) prev = s;
-    px = hx; py = hy; pz = hz;
+    px = hx + out[0].shift * nx; py = hy + out[0].shift * ny; pz = hz + out[0].shift * nz;      // (PeriodicBoundary: one period along the normal)
     dx = out[0].dx; dy = out[0].dy; dz = out[0].dz;
     e = out[0].e; ref = out[0].ref;
     if (e <= P.min_energy) return false;                      // tracer_engine.py:242

@@ -27,6 +27,7 @@
 #include <map>
 #include <mutex>
 #include <unordered_map>
+#include <deque>
 #include <utility>
 
 #include "trc_core.h"
@@ -105,6 +106,7 @@ struct trc_scene {
     int32_t *d_a_bg_apart;
     int32_t *d_a_gapart;
     struct StreamEngine *stream_eng;   // slots of the streaming fast engine (trc_stream.inc), allocated on first use
+    struct OrdScratch *ord_scratch;    // scratch of the ordered engine's bounce loop, kept between calls
     double *d_tally;
     int64_t tally_n;
     bool transfer_on;          // keep the transfer matrix (trc_scene_enable_transfer)
@@ -172,11 +174,14 @@ struct DevPool {
     std::unordered_map<void *, std::pair<size_t, int>> live;      // block handed out -> (bytes allocated, device)
     std::multimap<std::pair<int, size_t>, void *> idle;           // (device, bytes) -> block waiting
     size_t idle_bytes = 0;
+    size_t idle_large = 0;          // bytes of idle blocks beyond POOL_BLOCK_MAX (kept by exact size)
+    std::deque<void *> large_order; // ... in the order they became idle
     int enabled = -1;
 };
 static DevPool g_pool;
 static const size_t POOL_KEEP = (size_t)2 << 30;
 static const size_t POOL_BLOCK_MAX = (size_t)128 << 20;
+static const size_t POOL_KEEP_LARGE = (size_t)2 << 30;       // idle bytes of blocks beyond POOL_BLOCK_MAX (the oldest make room for a new one)
 
 static bool pool_enabled() {
     if (g_pool.enabled < 0) {
@@ -199,16 +204,46 @@ static void pool_trim() {
         std::lock_guard<std::mutex> g(g_pool.mu);
         for (auto &kv : g_pool.idle) gone.push_back(kv.second);
         g_pool.idle.clear();
+        g_pool.large_order.clear();
         g_pool.idle_bytes = 0;
+        g_pool.idle_large = 0;
     }
     for (void *p : gone) (void)hipFree(p);
 }
 
 static hipError_t pool_alloc(void **out, size_t bytes) {
     *out = nullptr;
-    // large requests are neither rounded nor kept: hipMalloc of a rounded size (2 GiB, 4 GiB, 7 x 256 MiB ...) was seen to take
-    // 1.2 s where the exact size takes a millisecond
-    if (!pool_enabled() || bytes > POOL_BLOCK_MAX) return hipMalloc(out, bytes);
+    // large requests are not rounded -- hipMalloc of a rounded size (2 GiB, 4 GiB, 7 x 256 MiB ...) was seen to take 1.2 s where
+    // the exact size takes milliseconds -- but a freed large block waits for the next request of exactly its size: a Monte-Carlo
+    // loop asks for the same 0.9 GB level of 1e7 source rays call after call, and mapping it anew was 10 ms of each
+    if (!pool_enabled()) return hipMalloc(out, bytes);
+    if (bytes > POOL_BLOCK_MAX) {
+        int dev_l = 0;
+        (void)hipGetDevice(&dev_l);
+        {
+            std::lock_guard<std::mutex> g(g_pool.mu);
+            auto it = g_pool.idle.find(std::make_pair(dev_l, bytes));
+            if (it != g_pool.idle.end()) {
+                *out = it->second;
+                g_pool.idle.erase(it);
+                g_pool.idle_large -= bytes;
+                for (auto q = g_pool.large_order.begin(); q != g_pool.large_order.end(); ++q)
+                    if (*q == *out) { g_pool.large_order.erase(q); break; }
+                g_pool.live[*out] = std::make_pair(bytes, dev_l);
+                return hipSuccess;
+            }
+        }
+        hipError_t el = hipMalloc(out, bytes);
+        if (el != hipSuccess) {
+            (void)hipGetLastError();
+            pool_trim();
+            el = hipMalloc(out, bytes);
+            if (el != hipSuccess) return el;
+        }
+        std::lock_guard<std::mutex> g(g_pool.mu);
+        g_pool.live[*out] = std::make_pair(bytes, dev_l);
+        return hipSuccess;
+    }
     const size_t cls = pool_class(bytes);
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -246,14 +281,28 @@ static void pool_free(void *p) {
             cls = it->second.first;
             dev = it->second.second;
             g_pool.live.erase(it);
-            keep = pool_enabled() && cls <= POOL_BLOCK_MAX && g_pool.idle_bytes + cls <= POOL_KEEP;
+            keep = pool_enabled() && (cls <= POOL_BLOCK_MAX ? g_pool.idle_bytes + cls <= POOL_KEEP : cls <= POOL_KEEP_LARGE);
         }
     }
     if (!keep) { (void)hipFree(p); return; }
     (void)hipDeviceSynchronize();        // nothing in flight may still use the block when the next owner gets it
-    std::lock_guard<std::mutex> g(g_pool.mu);
-    g_pool.idle.insert(std::make_pair(std::make_pair(dev, cls), p));
-    g_pool.idle_bytes += cls;
+    std::vector<void *> evict;
+    {
+        std::lock_guard<std::mutex> g(g_pool.mu);
+        if (cls > POOL_BLOCK_MAX) {
+            // large blocks wait by exact size; the oldest of them make room
+            while (g_pool.idle_large + cls > POOL_KEEP_LARGE && !g_pool.large_order.empty()) {
+                void *old = g_pool.large_order.front();
+                g_pool.large_order.pop_front();
+                for (auto it = g_pool.idle.begin(); it != g_pool.idle.end(); ++it)
+                    if (it->second == old) { g_pool.idle_large -= it->first.second; g_pool.idle.erase(it); evict.push_back(old); break; }
+            }
+            g_pool.large_order.push_back(p);
+            g_pool.idle_large += cls;
+        } else g_pool.idle_bytes += cls;
+        g_pool.idle.insert(std::make_pair(std::make_pair(dev, cls), p));
+    }
+    for (void *q : evict) (void)hipFree(q);
 }
 
 template <class T>
@@ -956,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_ord_bounce(OrdParams P) {
         }
         for (int c = 0; c < n_out; ++c) {
             long long slot = (c == 0) ? i : (P.n + i);
-            P.ox[slot] = hx; P.oy[slot] = hy; P.oz[slot] = hz;
+            P.ox[slot] = hx + out[c].shift * nx; P.oy[slot] = hy + out[c].shift * ny; P.oz[slot] = hz + out[c].shift * nz;
             P.odx[slot] = out[c].dx; P.ody[slot] = out[c].dy; P.odz[slot] = out[c].dz;
             P.oe[slot] = out[c].e; P.oref[slot] = out[c].ref; P.owl[slot] = wl;
             P.orid[slot] = (c == 0) ? rid : trc_child_rid(rid, (uint32_t)P.event);
@@ -1097,6 +1146,8 @@ struct GatherParams {
     const double *opay;     // n_pay rows, 2 n_parent apart
     double *pay;            // n_pay rows, m apart
     int n_pay;
+    const double *recs;     // surface records (optics kind): a ray of the scattered block of a scattering medium never reached the
+    int stride;             // surface it is filed under -- the level says so (TRC_LEVEL_VOLUME)
 };
 
 __global__ __launch_bounds__(256) void k_ord_gather(GatherParams G) {
@@ -1108,7 +1159,12 @@ __global__ __launch_bounds__(256) void k_ord_gather(GatherParams G) {
     G.e[j] = G.oe[slot]; G.ref[j] = G.oref[slot]; G.wl[j] = G.owl[slot];
     G.rid[j] = G.orid[slot];
     G.parent[j] = (int64_t)(slot >= G.n_parent ? slot - G.n_parent : slot);   // tracer_engine.py:235-236
-    G.surf[j] = (int32_t)((k & ~ORD_CULLED_BIT) >> 2);
+    {
+        const int32_t sj = (int32_t)((k & ~ORD_CULLED_BIT) >> 2);
+        // block 0 of a scattering medium is the scattered block (trc_shade: the blocks of the surface interaction come behind it)
+        const bool vol = (k & 3u) == 0u && trc_rec_opt_kind(G.recs + (size_t)sj * G.stride) == TRC_OPT_REFRACTIVE_SCATTERING;
+        G.surf[j] = vol ? (sj | TRC_LEVEL_VOLUME) : sj;
+    }
     for (int r = 0; r < G.n_pay; ++r) G.pay[(size_t)r * G.m + j] = G.opay[(size_t)r * 2 * G.n_parent + slot];
 }
 
@@ -1165,6 +1221,7 @@ struct OpticsParams {
     const double *ref_im, *mat, *spec_wl, *spec;
     int n_mat, W;
     double *o_im, *o_spec;
+    double *oshift;     // 2n: how far along the oriented normal the outgoing ray starts from the hit point (PeriodicBoundary)
 };
 
 __global__ __launch_bounds__(256) void k_optics_apply(OpticsParams P) {
@@ -1189,6 +1246,7 @@ __global__ __launch_bounds__(256) void k_optics_apply(OpticsParams P) {
         if (c < n_out) {
             P.odx[slot] = out[c].dx; P.ody[slot] = out[c].dy; P.odz[slot] = out[c].dz;
             P.oe[slot] = out[c].e; P.oref[slot] = out[c].ref; P.oblk[slot] = out[c].blk;
+            P.oshift[slot] = out[c].shift;
             if (P.o_im) P.o_im[slot] = out_im[c];
             if (P.o_spec) {
                 const double *tab = P.extra + trc_rec_extra_off(P.rec);
@@ -1447,11 +1505,13 @@ extern "C" int trc_scene_create(trc_ctx *ctx, int32_t n_surf, const trc_surface_
     return TRC_OK;
 }
 
+static void scene_free_ord_scratch(trc_scene *sc);
 extern "C" int trc_scene_destroy(trc_scene *sc) {
     if (!sc) return TRC_OK;
     (void)hipSetDevice(sc->ctx->device);
     (void)hipStreamSynchronize(sc->ctx->stream);
     scene_free_stream_ws(sc);
+    scene_free_ord_scratch(sc);
     dev_free(sc->d_recs); dev_free(sc->d_opt); dev_free(sc->d_extra); dev_free(sc->d_sflags);
     dev_free(sc->d_kd_a); dev_free(sc->d_kd_b); dev_free(sc->d_kd_leaf); dev_free(sc->d_kd_always);
     dev_free(sc->d_a_sbox); dev_free(sc->d_a_obb); dev_free(sc->d_a_nodes); dev_free(sc->d_a_leaf); dev_free(sc->d_a_unbounded); dev_free(sc->d_a_bleaf);
@@ -1842,7 +1902,7 @@ extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, doub
     double *dst[8] = {e_abs, e_in, px, py, pz, dx, dy, dz};
     uint32_t *d_flag = nullptr, *d_off = nullptr;
     uint32_t *d_key[2] = {nullptr, nullptr}, *d_ent[2] = {nullptr, nullptr};
-    void *d_tmp = nullptr;
+    char *d_tmp = nullptr;
     HitPack H;
     memset(&H, 0, sizeof(H));
     int st = TRC_OK;
@@ -1852,7 +1912,7 @@ extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, doub
         hipLaunchKernelGGL(k_hits_flag, dim3(nblk), dim3(256), 0, sc->ctx->stream, sc->d_h_surf, (long long)reserved, d_flag);
         size_t tmp_bytes = 0;
         if (rocprim::exclusive_scan(nullptr, tmp_bytes, d_flag, d_off, 0u, (size_t)reserved, rocprim::plus<uint32_t>(), sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "exclusive_scan (size query) failed"); break; }
-        if (hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) { st = trc_fail(TRC_ERR_NOMEM, "hipMalloc failed"); break; }
+        if ((st = dev_alloc(&d_tmp, tmp_bytes ? tmp_bytes : 1))) break;
         if (rocprim::exclusive_scan(d_tmp, tmp_bytes, d_flag, d_off, 0u, (size_t)reserved, rocprim::plus<uint32_t>(), sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "exclusive_scan failed"); break; }
         uint32_t last_off = 0, last_flag = 0;
         if (hipMemcpyAsync(&last_off, d_off + (reserved - 1), 4, hipMemcpyDeviceToHost, sc->ctx->stream) != hipSuccess ||
@@ -1886,20 +1946,22 @@ extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, doub
             while ((1u << bits) <= (unsigned)sc->n_surf) ++bits;
             size_t sort_bytes = 0;
             if (rocprim::radix_sort_pairs(nullptr, sort_bytes, d_key[0], d_key[1], d_ent[0], d_ent[1], (size_t)reserved, 0, bits, sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "radix_sort_pairs (size query) failed"); break; }
-            if (d_tmp) (void)hipFree(d_tmp);
-            d_tmp = nullptr;
-            if (hipMalloc(&d_tmp, sort_bytes ? sort_bytes : 1) != hipSuccess) { st = trc_fail(TRC_ERR_NOMEM, "hipMalloc failed"); break; }
+            dev_free(d_tmp);
+            if ((st = dev_alloc(&d_tmp, sort_bytes ? sort_bytes : 1))) break;
             if (rocprim::radix_sort_pairs(d_tmp, sort_bytes, d_key[0], d_key[1], d_ent[0], d_ent[1], (size_t)reserved, 0, bits, sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "radix_sort_pairs failed"); break; }
             hipLaunchKernelGGL(k_hits_gather, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, sc->ctx->stream, H, (const uint32_t *)d_ent[1], (long long)cnt);
         }
-        if (hipStreamSynchronize(sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "k_hits_pack failed"); break; }
-        if (surf && hipMemcpy(surf, H.o_surf, (size_t)cnt * 4, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        // one copy per column, all behind the packing on the context's stream (page-locked destinations -- trc_host_alloc -- take
+        // them at the rate of the link), one wait
+        if (surf && hipMemcpyAsync(surf, H.o_surf, (size_t)cnt * 4, hipMemcpyDeviceToHost, sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
         for (int k = 0; k < 8; ++k)
-            if (dst[k] && hipMemcpy(dst[k], H.o_col[k], (size_t)cnt * 8, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+            if (dst[k] && hipMemcpyAsync(dst[k], H.o_col[k], (size_t)cnt * 8, hipMemcpyDeviceToHost, sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        if (st == TRC_OK && hipStreamSynchronize(sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "fetching the hits failed"); break; }
     } while (0);
+    (void)hipStreamSynchronize(sc->ctx->stream);
     dev_free(d_flag); dev_free(d_off);
     dev_free(d_key[0]); dev_free(d_key[1]); dev_free(d_ent[0]); dev_free(d_ent[1]);
-    if (d_tmp) (void)hipFree(d_tmp);
+    dev_free(d_tmp);
     dev_free(H.o_surf);
     for (int k = 0; k < 8; ++k) dev_free(H.o_col[k]);
     return st;
@@ -2460,6 +2522,7 @@ static int level_alloc(Level &L, int64_t n, int n_pay) {
 
 // Scratch of the bounce loop: allocated for the first (usually the largest) bounce and kept; a bounce that needs more -- refractive
 // surfaces can double a level -- gets a new set.
+#define ORD_SCRATCH_KEEP ((size_t)1 << 26)
 struct OrdScratch {
     double *o[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint64_t *orid = nullptr;
@@ -2469,17 +2532,20 @@ struct OrdScratch {
     unsigned long long *blk_off = nullptr, *totals = nullptr;
     char *sort_tmp = nullptr;
     size_t cap_slots = 0, sort_bytes = 0;
+    int cap_pay = 0;
     void release() {
         for (int i = 0; i < 9; ++i) dev_free(o[i]);
         dev_free(opay);
         dev_free(orid); dev_free(key); dev_free(ckey); dev_free(cslot); dev_free(skey); dev_free(sslot);
         dev_free(blk_cnt); dev_free(blk_cul); dev_free(blk_off); dev_free(totals);
         dev_free(sort_tmp);
-        cap_slots = 0; sort_bytes = 0;
+        cap_slots = 0; sort_bytes = 0; cap_pay = 0;
     }
     int ensure(size_t slots, int n_pay) {
-        if (slots <= cap_slots) return TRC_OK;
+        if (slots <= cap_slots && n_pay <= cap_pay) return TRC_OK;
+        if (slots < cap_slots) slots = cap_slots;
         release();
+        cap_pay = n_pay;
         for (int i = 0; i < 9; ++i) TRC_TRY(dev_alloc(&o[i], slots));
         TRC_TRY(dev_alloc(&orid, slots));
         if (n_pay > 0) TRC_TRY(dev_alloc(&opay, slots * (size_t)n_pay));
@@ -2501,6 +2567,10 @@ struct OrdScratch {
         return TRC_OK;
     }
 };
+
+static void scene_free_ord_scratch(trc_scene *sc) {
+    if (sc->ord_scratch) { sc->ord_scratch->release(); delete sc->ord_scratch; sc->ord_scratch = nullptr; }
+}
 
 extern "C" int trc_result_destroy(trc_result *res) {
     if (!res) return TRC_OK;
@@ -2549,7 +2619,10 @@ extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_so
     res->lay = lay;
     trc_trace_stats s;
     memset(&s, 0, sizeof(s));
-    OrdScratch sx;
+    // the scratch of the bounce loop stays with the scene (an ordered trace of 1e7 rays allocated and freed 3 GB in twenty blocks
+    // beyond the pool's sizes per call: 30 of its 45 ms)
+    if (!sc->ord_scratch) { sc->ord_scratch = new (std::nothrow) OrdScratch(); if (!sc->ord_scratch) return trc_fail(TRC_ERR_NOMEM, "out of host memory"); }
+    OrdScratch &sx = *sc->ord_scratch;
     trc_source_desc *d_src = nullptr;
     int st = TRC_OK;
     float total_ms = 0;
@@ -2660,6 +2733,7 @@ extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_so
             G.m = m; G.n_parent = n_cur;
             G.x = Ln.x; G.y = Ln.y; G.z = Ln.z; G.dx = Ln.dx; G.dy = Ln.dy; G.dz = Ln.dz; G.e = Ln.e; G.ref = Ln.ref;
             G.wl = Ln.wl; G.rid = Ln.rid; G.parent = Ln.parent; G.surf = Ln.surf;
+            G.recs = sc->d_recs; G.stride = sc->stride;
             G.opay = sx.opay; G.pay = Ln.pay; G.n_pay = n_pay;
             hipLaunchKernelGGL(k_ord_gather, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, G);
             se = hipStreamSynchronize(ctx->stream);
@@ -2679,7 +2753,7 @@ extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_so
                 for (double v : eh) s.energy_left += v;
         }
     } while (0);
-    sx.release();
+    if (sx.cap_slots > ORD_SCRATCH_KEEP) sx.release();      // (beyond 2^26 slots -- 10 GB -- the scratch goes back after the call)
     dev_free(d_src);
     if (stats) *stats = s;
     if (st != TRC_OK) { trc_result_destroy(res); return st; }
@@ -3007,6 +3081,7 @@ extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int3
     double *d_path = nullptr;
     double *d_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int32_t *d_blk = nullptr;
+    double *d_shift = nullptr;
     // complex indices, material rows, spectra
     const int W = (in->spectra && in->spec_wl) ? in->n_spec : 0;
     const int n_mat = in->mat ? (int)in->n_mat : 0;
@@ -3058,6 +3133,7 @@ extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int3
         }
         for (int i = 0; i < 5 && st == TRC_OK; ++i) st = dev_alloc(&d_out[i], (size_t)(2 * n));
         if (st == TRC_OK) st = dev_alloc(&d_blk, (size_t)(2 * n));
+        if (st == TRC_OK) st = dev_alloc(&d_shift, (size_t)(2 * n));
         if (st) break;
         OpticsParams P;
         memset(&P, 0, sizeof(P));
@@ -3066,7 +3142,7 @@ extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int3
         P.rid = d_rid; P.ray_offset = 0;
         P.nx = d_in[6]; P.ny = d_in[7]; P.nz = d_in[8]; P.path = d_path;
         P.seed = seed; P.event = bounce;
-        P.odx = d_out[0]; P.ody = d_out[1]; P.odz = d_out[2]; P.oe = d_out[3]; P.oref = d_out[4]; P.oblk = d_blk;
+        P.odx = d_out[0]; P.ody = d_out[1]; P.odz = d_out[2]; P.oe = d_out[3]; P.oref = d_out[4]; P.oblk = d_blk; P.oshift = d_shift;
         P.ref_im = d_im; P.mat = d_mat; P.spec_wl = d_swl; P.spec = d_spec; P.n_mat = n_mat; P.W = W; P.o_im = d_oim; P.o_spec = d_ospec;
         hipLaunchKernelGGL(k_optics_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, P);
         hipError_t se = hipStreamSynchronize(ctx->stream);
@@ -3079,6 +3155,8 @@ extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int3
         }
         if (st) break;
         if (hipMemcpy(blk.data(), d_blk, (size_t)(2 * n) * 4, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        std::vector<double> h_shift((size_t)(2 * n));
+        if (hipMemcpy(h_shift.data(), d_shift, (size_t)(2 * n) * 8, hipMemcpyDeviceToHost) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
         std::vector<double> h_im, h_spec;
         if (d_oim) {
             h_im.resize((size_t)(2 * n));
@@ -3094,7 +3172,8 @@ extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int3
             for (int64_t slot = 0; slot < 2 * n; ++slot) {
                 if (blk[(size_t)slot] != b) continue;
                 int64_t i = slot < n ? slot : slot - n;
-                out->x[m] = hx[i]; out->y[m] = hy[i]; out->z[m] = hz[i];
+                const double sh = h_shift[(size_t)slot];        // (0 but for a periodic boundary: the ray goes on one period along the normal)
+                out->x[m] = hx[i] + sh * nx[i]; out->y[m] = hy[i] + sh * ny[i]; out->z[m] = hz[i] + sh * nz[i];
                 out->dx[m] = h[0][(size_t)slot]; out->dy[m] = h[1][(size_t)slot]; out->dz[m] = h[2][(size_t)slot];
                 out->e[m] = h[3][(size_t)slot];
                 if (out->ref_index) out->ref_index[m] = h[4][(size_t)slot];
@@ -3110,7 +3189,7 @@ extern "C" int trc_optics_apply(trc_ctx *ctx, const trc_surface_desc *surf, int3
             }
         out->n = m;
     } while (0);
-    dev_free(d_rec); dev_free(d_opt); dev_free(d_extra); dev_free(d_rid); dev_free(d_blk); dev_free(d_path);
+    dev_free(d_rec); dev_free(d_opt); dev_free(d_extra); dev_free(d_rid); dev_free(d_blk); dev_free(d_shift); dev_free(d_path);
     dev_free(d_im); dev_free(d_mat); dev_free(d_swl); dev_free(d_spec); dev_free(d_oim); dev_free(d_ospec);
     for (int i = 0; i < 9; ++i) dev_free(d_in[i]);
     for (int i = 0; i < 5; ++i) dev_free(d_out[i]);

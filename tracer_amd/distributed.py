@@ -43,7 +43,10 @@ def reduce_scene_tallies(dev):
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return
     if dist.get_backend() == 'nccl':
-        # (torch's HIP runtime must have been initialised before the library's context was created: INTEGRATION.md)
+        # (torch's HIP runtime must have been initialised before the library's context was created: _cabi.get_context sees to
+        # it when torch is imported first, and this says so loudly when it was not)
+        from . import _cabi
+        _cabi.check_torch_order()
         t = torch.empty(dev.tally_size(), dtype=torch.float64, device='cuda')
         dev.export_tallies(out=t.data_ptr())
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

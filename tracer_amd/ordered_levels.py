@@ -121,7 +121,9 @@ class PendingLevels(Delivery):
             # surfaces that have accountants are touched, and they are only sorted when the device's order -- (culled, surface,
             # block) with ascending parents inside -- is not that order already (no culled rays, one block: the usual case)
             par = L['parents']
-            order = N.nonzero(acc_table[L['surf']])[0] if acc_table.any() else N.zeros(0, dtype=int)
+            vol = L.get('volume')           # rays scattered in the medium in front of the surface they are filed under: not hits of it
+            wanted = acc_table[L['surf']] if vol is None else (acc_table[L['surf']] & ~vol)
+            order = N.nonzero(wanted)[0] if acc_table.any() else N.zeros(0, dtype=int)
             if len(order):
                 whole = len(order) == len(par)           # every ray of the level ended on a surface with accountants: no gathering
                 so, po = (L['surf'], par) if whole else (L['surf'][order], par[order])
@@ -142,8 +144,12 @@ class PendingLevels(Delivery):
                 left = N.full(len(prev['energy']), ns) if prev_surf is None else prev_surf
                 if self.engine._transfer_host is None:
                     self.engine._transfer_host = N.zeros((ns + 1, ns))
-                N.add.at(self.engine._transfer_host, (left[par], L['surf']), prev['energy'][par])
-            prev_surf = L['surf']
+                if vol is None:
+                    N.add.at(self.engine._transfer_host, (left[par], L['surf']), prev['energy'][par])
+                else:               # (a volume event lands nowhere, and the ray goes on from where it had left)
+                    keep = ~vol
+                    N.add.at(self.engine._transfer_host, (left[par][keep], L['surf'][keep]), prev['energy'][par][keep])
+            prev_surf = L['surf'] if vol is None or not self.transfer else N.where(vol, (N.full(len(prev['energy']), self.n_surf) if prev_surf is None else prev_surf)[par], L['surf'])
             prev = dict(energy=L['energy'], directions=L['directions'], wavelengths=L.get('wavelengths') if has_wl else None,
                         spectra=L.get('spectra'))
 

@@ -58,8 +58,11 @@ def nsttf_field(sigma=1e-3, n_heliostats=None):
     return plant, field, rec, src
 
 
-def nsttf_source(n, src, seed=None, ray_offset=0):
-    return sources.buie_sunshape(n, src['center'], src['direction'], src['radius'], src['CSR'], flux=src['flux'],
+def nsttf_source(n, src, seed=None, ray_offset=0, n_total=None):
+    """n rays of the field's source; n_total: they are a part of a bundle of n_total rays traced elsewhere as well (ranks that
+    share a bundle): every ray carries flux x area / n_total"""
+    flux = src['flux'] if n_total is None else src['flux'] * (float(n) / float(n_total))
+    return sources.buie_sunshape(n, src['center'], src['direction'], src['radius'], src['CSR'], flux=flux,
                                  pre_process_CSR=src['pre_process_CSR'], seed=seed, ray_offset=ray_offset)
 
 

@@ -56,9 +56,16 @@ class TracerEngine(object):
         lazy = getattr(self, '_kd_lazy', None)
         if lazy is not None:
             key, max_depth, fast, kw = lazy
-            if self._auto_kd is None or self._auto_kd[0] != key:
-                self._auto_kd = (key, KdTree(self._asm, max_depth, loglevel=self.loglevel, fast=fast, **kw))
-            self._Kd_Tree = self._auto_kd[1]
+            if self._auto_kd is not None and self._auto_kd[0] == key:
+                self._Kd_Tree = self._auto_kd[1]
+            else:
+                # built from the assembly as it stands NOW: kept for later traces only when that is still the scene the call
+                # traced (a script may have re-posed the assembly between the trace and this read -- a tree of the new poses
+                # under the old poses' key would be handed to the device the next time the old poses are traced)
+                tree = KdTree(self._asm, max_depth, loglevel=self.loglevel, fast=fast, **kw)
+                if compile_scene(self._asm).signature() == key[0]:
+                    self._auto_kd = (key, tree)
+                self._Kd_Tree = tree
             self._kd_lazy = None
         return getattr(self, '_Kd_Tree', None)
 
@@ -159,6 +166,7 @@ class TracerEngine(object):
             self._dev.reset_tallies()
 
     # -- the entry point ------------------------------------------------------------------------------
+    KD_KEYWORDS = ('min_leaf', 't_trav', 't_isec', 'empty_bonus', 'debug', 'split_threshold')    # KdTree's own (accel_tree.py:42-60)
     KD_BUILD_MAX = 8192      # surfaces beyond which accel=True does not build the reference's Kd-tree for the fast engine
     KD_WORTH_IT = 2e9        # rays x surfaces from which the ordered engine gets the reference's Kd-tree built for accel=True
     TUNE_MIN_RAYS = 1 << 21  # calls from which the two forms of the fast engine are compared on a scene (fast_kernel='auto')
@@ -218,6 +226,9 @@ class TracerEngine(object):
             num_surfs = dev.n_surf
             kw = dict(kwargs)
             kw.setdefault('min_leaf', 1)
+            unknown = [k for k in kw if k not in self.KD_KEYWORDS]       # (the tree is built later, if at all: complain now)
+            if unknown:
+                raise TypeError("ray_tracer() got unexpected keyword argument(s) %s" % ', '.join(repr(k) for k in unknown))
             self._Kd_Tree = None
             self._kd_lazy = None if num_surfs > self.KD_BUILD_MAX else \
                 ((self._dev_sig, accel == 'fast', tuple(sorted(kw.items()))), 8 + 1.3 * N.log(num_surfs), accel == 'fast', kw)
@@ -260,10 +271,16 @@ class TracerEngine(object):
             # of the calls before still unread there -- every accountant concerned still holds its mark -- goes on filling the
             # same buffer, grown if need be; otherwise what it holds is delivered (or dropped, when nobody waits for it any more)
             # and the buffer emptied.  An explicit hit_capacity is taken literally: an empty buffer of that size.
+            # Room for the hits of this call: two per ray unless the caller says otherwise -- or, once the scene in its present
+            # poses has been traced, four times the share of captured hits per ray seen so far (a field sends 6 % of its rays to
+            # the receiver: successive calls then fit the buffer of the first many times over before it has to grow).
             need = int(hit_capacity) if hit_capacity is not None else 2 * n + 1024
+            if hit_capacity is None and dev.capture_rate is not None:
+                need = min(need, int(4. * dev.capture_rate * n) + 65536)
             accs = [a for sf, cap in zip(dev.compiled.surfaces, dev.compiled.capture) if cap for a in sf.get_optics_manager().accountants]
             pend = dev.pending_hits
             keep = bool(feed and hit_capacity is None and pend is not None and pend.wanted() and accs and all(pend.holds_mark(a) for a in accs))
+            used = 0
             if keep:
                 used = dev.hits_reserved()[0]
                 keep = used + need <= self.HITS_RESIDENT_MAX
@@ -271,7 +288,8 @@ class TracerEngine(object):
                 dev.reserve_hits(used + need)
             else:
                 pend = None
-                if hit_capacity is None and dev.hit_capacity >= need and dev.hit_capacity <= 4 * need:
+                used = 0
+                if hit_capacity is None and dev.hit_capacity >= need:
                     dev.settle_pending()        # (a buffer that is large enough already is kept: freeing and allocating 15 GB costs 0.1 s)
                 else:
                     dev.set_hit_capacity(need)
@@ -303,6 +321,9 @@ class TracerEngine(object):
         if stats.hits_dropped:
             raise RuntimeError("%d hits were not captured: the hit buffer holds %d; pass hit_capacity=..."
                                % (stats.hits_dropped, dev.hit_capacity))
+        if capture and n > 0:
+            rate = max(dev.hits_reserved()[0] - used, 0) / float(n)
+            dev.capture_rate = rate if dev.capture_rate is None else max(dev.capture_rate, rate)
         if capture and feed and accs:
             if pend is None:
                 pend = dev.pending_hits = PendingHits(dev)
