@@ -162,6 +162,19 @@ def other_configs(ctx, log):
     return out
 
 
+def sq_counters_for(n):
+    """per-kernel SQ counter ratios of this workload from the committed single-batch PMC passes (profiles/sq_counters.json, made by
+    tools/pmc_kernels.py), or None when they were taken on another workload"""
+    try:
+        sj = json.load(open(os.path.join(ROOT, 'profiles', 'sq_counters.json')))
+        if int(sj.get('rays_per_launch', 0)) != int(n):
+            return None
+        return dict((k, dict((a, round(b, 4)) for a, b in v.items() if a != 'counters')) for k, v in sj['per_kernel'].items()
+                    if v.get('counters', {}).get('SQ_WAVES', 0) >= 64)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -349,7 +362,14 @@ def main():
                                    'fast engine, streaming form: k_s_cull + k_s_fresh (+ the general path for the aureole) + k_s_shade, '
                                    'then k_s_bounce + k_s_shade + k_s_absorb (the hits on the receiver) per bounce (%d launches per step)' % launches,
                          'kernel_ms_per_launch': kms / args.steps,
-                         'algorithmic_bytes_per_launch': seg / args.steps * B_SEG},
+                         'algorithmic_bytes_per_launch': seg / args.steps * B_SEG,
+                         # what the counters say moves through HBM, over the same kernel time: the fraction of the 8 TB/s actually used
+                         # (`frac` above prices every segment at 112 B, and 94 % of the segments end in registers)
+                         'hbm_measured_frac': (traffic / (kms / args.steps * 1e-3) / (HBM_PEAK_GBS * 1e9)) if (traffic and kms > 0) else None,
+                         'hbm_measured_frac_fetch_as_counted': (traffic_raw / (kms / args.steps * 1e-3) / (HBM_PEAK_GBS * 1e9)) if (traffic_raw and kms > 0) else None,
+                         # what binds each kernel: vector instructions issued per resident wave cycle and the share of those cycles spent
+                         # waiting, from the single-batch PMC passes kept in profiles/sq_counters.json (tools/pmc_kernels.py)
+                         'kernels': sq_counters_for(n)},
             'check': {'receiver_kW': receiver_kw, 'receiver_hits': int(h[218]), 'heliostat_hits': int(h[:218].sum()),
                       'segments_total': int(round(total_segments)), 'receiver_hits_per_ray': h[218] / total_rays,
                       'heliostat_hits_per_ray': float(h[:218].sum()) / total_rays,

@@ -235,7 +235,8 @@ def test_terminal_surfaces_are_finished_by_k_s_absorb(ctx):
     assert is_lean.any() and (~is_lean).any()
     assert N.array_equal(a['e_in'][is_lean], a['e_abs'][is_lean]) and not a['directions'][:, is_lean].any()
     assert N.allclose(N.sum(a['directions'][:, ~is_lean] ** 2, axis=0), 1.) and (a['e_in'][~is_lean] >= a['e_abs'][~is_lean]).all()
-    for what, knobs in (('no split', dict(TRC_STREAM_ABSORB=0)), ('megakernel', dict(stream=False)), ('general path', dict(TRC_STREAM_BOUNCE=0)),
+    for what, knobs in (('no split', dict(TRC_STREAM_ABSORB=0)), ('split behind a list', dict(TRC_STREAM_ABSORB=1)), ('megakernel', dict(stream=False)),
+                        ('general path', dict(TRC_STREAM_BOUNCE=0)),
                         ('no pre-assigned chunks', dict(TRC_STREAM_STATIC=0))):
         other = _trace(ctx, cs, bundle, **dict(kw, **knobs))
         _same(ref, other, what)
@@ -288,6 +289,34 @@ def test_dish_into_spectral_cavity_at_scale(ctx, n):
     p_small, p_big = o['hits'] / float(m), A['h'] / float(n)
     sigma = N.sqrt(N.maximum(p_big, 1e-4) / m) * 2.        # hits per ray are not Bernoulli (a ray hits a wall several times): factor 2
     assert (N.abs(p_small - p_big) < 5. * sigma).all(), (p_small, p_big, sigma)
+
+
+def test_modest_hit_buffer_on_a_large_streaming_call(ctx):
+    """
+    A caller-sized hit buffer just above the hits to come -- NSTTF, 1e7 rays, room for 1.2 times the 6.5 % of the rays that reach the
+    receiver -- drops nothing: the chunk the shading waves reserve per atomic follows the buffer's size (256 entries here, 1024 for
+    the buffers of full-size runs) and the buffer carries the room every wave that can hold an open chunk may leave unused.
+    """
+    from tracer_amd import scenes
+    from tracer_amd.scene import compile_scene, DeviceScene
+    plant, field, rec, src = scenes.nsttf_field()
+    cs = compile_scene(plant)
+    n = 10000000
+    dev = DeviceScene(cs, ctx)
+    dev.set_hit_capacity(int(1.2 * 0.065 * n))
+    for k in range(2):                   # (the second call continues the chunks the first left open)
+        dev.lib.trc_scene_clear_hits(dev.handle) if k == 0 else None
+        st, _ = dev.trace_fast(scenes.nsttf_source(n, src, seed=8, ray_offset=k * n), 100, 1e-10, 8, accel=True, stream=True)
+        assert st.hits_dropped == 0, (k, st.hits_dropped)
+        if k == 0:
+            a, r, h = dev.get_tallies()
+            hits = dev.get_hits()
+            assert len(hits['surf']) == h[218] and N.isclose(hits['e_abs'].sum(), a[218], rtol=1e-9)
+            dev.lib.trc_scene_clear_hits(dev.handle)
+            dev.reset_tallies()
+    a, r, h = dev.get_tallies()
+    assert len(dev.get_hits()['surf']) == h[218] > 0.06 * n
+    dev.close()
 
 
 def test_calls_in_sequence_accumulate_like_fresh_scenes(ctx):
@@ -843,3 +872,30 @@ def test_scattering_slab_vs_oracle(ctx):
     share = crossed.sum() / float(from_in.sum())
     sigma = N.sqrt(N.exp(-s_c * L) * (1 - N.exp(-s_c * L)) / from_in.sum())
     assert abs(share - N.exp(-s_c * L)) < 3.5 * sigma, (share, N.exp(-s_c * L), sigma)
+    # the levels say which rays were scattered in the medium (TRC_LEVEL_VOLUME): rays that start inside the slab, nothing else
+    for k in range(1, len(levels)):
+        vol = levels[k]['volume']
+        z = levels[k]['vertices'][2]
+        mid = (z > 1e-6) & (z < L - 1e-6)
+        assert (vol is None and not mid.any()) or N.array_equal(vol, mid), k
+    # accountants on the scattering plates see the hits on the plates and not the scattering events in front of them, through the
+    # ordered engine (which files those rays under the plate they were heading for) as through the fast one
+    from tracer_amd.tracer_engine import TracerEngine
+    mk_acc = lambda: opt.RefractiveScatteringHomogenousDetector(1., 1.5, 0., s_c, 0., g)
+    plates = [Surface(RectPlateGM(40., 40.), mk_acc()), Surface(RectPlateGM(40., 40.), mk_acc())]
+    asm = Assembly(objects=[AssembledObject(surfs=[plates[0]], transform=translate(0., 0., L)),
+                            AssembledObject(surfs=[plates[1]], transform=translate(0., 0., 0.)),
+                            AssembledObject(surfs=[Surface(RectPlateGM(60., 60.), opt.LambertianReceiver(1.))], transform=translate(0., 0., -1.))])
+    got = {}
+    for tree in (True, False):
+        asm.reset_all_optics()
+        eng = TracerEngine(asm)
+        eng.ray_tracer(RayBundle(vertices=v[:, :m], directions=d[:, :m], energy=e[:m], ref_index=N.ones(m)), reps, 1e-10, tree=tree, seed=11)
+        assert eng.stats['engine'] == ('ordered' if tree else 'fast')
+        got[tree] = [p.get_optics_manager().get_all_hits() for p in plates]
+    for pi in range(2):
+        (e_o, loc_o, dir_o), (e_f, loc_f, dir_f) = got[True][pi], got[False][pi]
+        assert len(e_o) == len(e_f) == o2['hits'][pi], pi
+        assert N.allclose(N.abs(loc_o[2] - (L if pi == 0 else 0.)), 0., atol=1e-9), "every hit the accountants hold lies on the plate"
+        ko, kf = N.lexsort((loc_o[1], loc_o[0], e_o)), N.lexsort((loc_f[1], loc_f[0], e_f))
+        assert N.allclose(loc_o[:, ko], loc_f[:, kf], rtol=1e-9, atol=1e-9) and N.allclose(dir_o[:, ko], dir_f[:, kf], rtol=1e-9, atol=1e-9)

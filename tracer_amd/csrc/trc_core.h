@@ -158,11 +158,32 @@ TRC_HD void trc_uniform_quad(uint64_t seed, uint64_t rid, uint32_t event, uint32
 // Box-Muller: two independent N(0,1) from two uniforms (1-u0 keeps the log argument in (0,1])
 TRC_HD void trc_normal_pair(double u0, double u1, double *g0, double *g1) {
     double r = sqrt(-2.0 * log(1.0 - u0));
-    double a = TRC_TWO_PI * u1;
     double sa, ca;
-    trc_sincos(a, &sa, &ca);
+    trc_sincos_2pi(u1, &sa, &ca);           // (sine and cosine of 2 pi u1 with the exact reduction of sincospi: a third of sincos(2 pi u1))
     *g0 = r * ca;
     *g1 = r * sa;
+}
+
+// Tangent of a small angle by its Maclaurin series (the slope errors of mirrors are milliradians): below 1/8 the first term left
+// out, 6404582 / 10854718875 x^17, is under 3e-19 of x; beyond, the library's tangent with its argument reduction
+TRC_HD double trc_tan_small(double x) {
+    if (!(fabs(x) <= 0.125)) return tan(x);
+    const double x2 = x * x;
+    double p = 929569.0 / 638512875.0;
+    p = p * x2 + 21844.0 / 6081075.0;
+    p = p * x2 + 1382.0 / 155925.0;
+    p = p * x2 + 62.0 / 2835.0;
+    p = p * x2 + 17.0 / 315.0;
+    p = p * x2 + 2.0 / 15.0;
+    p = p * x2 + 1.0 / 3.0;
+    return x + x * (x2 * p);
+}
+
+// sine and cosine of an angle that is usually small (the polar angle of a slope error): the series of trc_sincos_small up to
+// 0.05 rad, the library beyond
+TRC_HD void trc_sincos_mostly_small(double x, double *s, double *c) {
+    if (fabs(x) <= 0.05) trc_sincos_small(x, s, c);
+    else trc_sincos(x, s, c);
 }
 
 // stream id of the second ray created when an interaction splits a ray in two
@@ -328,6 +349,9 @@ TRC_HD bool trc_quadric_aperture(int kind, const double *rec, const double *g, d
         return true;
     }
     case TRC_GM_CYL_FINITE: {                                                           // cylinder.py:97-103
+        // a full turn of wall: the azimuth, brought to [0, 2 pi), passes whatever it is (and a nan hit point fails on its height
+        // as it would on its angle) -- no arc tangent, twice per ray and cylinder
+        if (g[2] <= 0.0 && g[3] >= TRC_TWO_PI) return fabs(lz) <= g[1];
         double ang = atan2(ly, lx);
         if (ang < 0.0) ang = TRC_TWO_PI + ang;
         return (fabs(lz) <= g[1]) && (ang >= g[2]) && (ang <= g[3]);
@@ -964,21 +988,22 @@ TRC_HD void trc_reflect(double dx, double dy, double dz, double nx, double ny, d
     *oz = dz - 2.0 * (dn * nz);
 }
 
-TRC_HD double trc_round14(double x) { return rint(x * 1e14) / 1e14; }  // N.round(x, 14), spatial_geometry.py:18
+// N.round(x, 14), spatial_geometry.py:18 (x * 1e-14 for x / 1e14: one unit of the last place apart at most, a float64 division less)
+TRC_HD double trc_round14(double x) { return rint(x * 1e14) * 1e-14; }
 
 // minimal rotation taking z to n, applied to e (ray_trace_utils/vector_manipulations.py:56-90,
 // spatial_geometry.py:8-22).  Used for the mirror slope error.
 TRC_HD void trc_rotate_z_to_normal(double ex, double ey, double ez, double nx, double ny, double nz,
                                    double *ox, double *oy, double *oz) {
-    double ang = acos(nz);
-    if (ang == 0.0) { *ox = ex; *oy = ey; *oz = ez; return; }
+    // angle = arccos(n_z) (:84); only its sine and cosine are used (:18): cos = n_z, sin = sqrt(1 - n_z^2) >= 0 -- an arc cosine and
+    // a sine / cosine pair less per call, the same numbers to a unit of the last place before they are rounded to 14 decimals
+    if (nz == 1.0) { *ox = ex; *oy = ey; *oz = ez; return; }          // (arccos gives 0 for 1 and nothing else)
     // axis = unit(z x n); undefined -> x axis
     double kx = -ny, ky = nx, kz = 0.0;
     double kn = sqrt(kx * kx + ky * ky);
     kx /= kn; ky /= kn;
     if (kx != kx) { kx = 1.0; ky = 0.0; kz = 0.0; }
-    double s, c;
-    trc_sincos(ang, &s, &c);
+    double s = sqrt((1.0 - nz) * (1.0 + nz)), c = nz;                // (nan for |n_z| > 1, as arccos)
     s = trc_round14(s); c = trc_round14(c);
     double vv = 1.0 - c;
     // M = outer(k,k)*v + I*c + [k]x*s
@@ -1013,19 +1038,30 @@ TRC_HD void trc_pillbox_dir(double xi1, double xi2, double ang_range, double *ax
     *ay = s1 * s;
     *az = sqrt(1.0 - s * s);
 }
+// the same with the azimuth given as the uniform it is drawn from (azimuth = 2 pi u): sincospi instead of reducing 2 pi u, and
+// no sine of the cone angle for the half space (sin(pi / 2) is 1 in float64 too)
+TRC_HD void trc_pillbox_dir_u(double u, double xi2, double ang_range, double *ax, double *ay, double *az) {
+    if (ang_range == 0.0) { *ax = 0.0; *ay = 0.0; *az = 1.0; return; }
+    double s = (ang_range == 1.57079632679489661923 ? 1.0 : sin(ang_range)) * sqrt(xi2);
+    double s1, c1;
+    trc_sincos_2pi(u, &s1, &c1);
+    *ax = c1 * s;
+    *ay = s1 * s;
+    *az = sqrt(1.0 - s * s);
+}
 
 // slope-error normal in the frame of the ideal normal (optics_callables.py:234-251)
 TRC_HD void trc_slope_error_local(double sigma, bool bi_var, double g0, double g1, double u2, double *ex,
                                   double *ey, double *ez) {
     if (bi_var) {
-        double tx = tan(sigma * g0), ty = tan(sigma * g1);
+        double tx = trc_tan_small(sigma * g0), ty = trc_tan_small(sigma * g1);
         double z = sqrt(1.0 / (1.0 + tx * tx + ty * ty));
         *ex = tx * z; *ey = ty * z; *ez = z;
     } else {
-        double th = sigma * g0, phi = TRC_TWO_PI * u2;
+        double th = sigma * g0;
         double st, ct, sp, cp;
-        trc_sincos(th, &st, &ct);
-        trc_sincos(phi, &sp, &cp);
+        trc_sincos_mostly_small(th, &st, &ct);
+        trc_sincos_2pi(u2, &sp, &cp);
         *ez = ct;
         *ex = st * cp;
         *ey = st * sp;
@@ -1034,9 +1070,8 @@ TRC_HD void trc_slope_error_local(double sigma, bool bi_var, double g0, double g
 
 // unpolarised Fresnel reflectance, optics.py:28-38 (formula kept as written, through arccos/sin)
 TRC_HD double trc_fresnel(double cos_abs, double n1, double n2) {
-    double th = acos(cos_abs);
-    double foo, sth;
-    trc_sincos(th, &sth, &foo);
+    // theta = arccos(|cos|) (:28) enters through its sine and cosine only: cos = |cos|, sin = sqrt(1 - cos^2)
+    double foo = cos_abs, sth = sqrt((1.0 - cos_abs) * (1.0 + cos_abs));
     double sn = n1 / n2 * sth;
     double bar = sqrt(1.0 - sn * sn);
     double rs = (n1 * foo - n2 * bar) / (n1 * foo + n2 * bar);
@@ -1260,7 +1295,7 @@ TRC_HD int trc_shade_k(int opt_kind, const double *opt, const double *extra, int
     case TRC_OPT_LAMBERTIAN: {                                      // :154-176
         double u0, u1, ax, ay, az;
         trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
-        trc_pillbox_dir(TRC_TWO_PI * u0, u1, opt[1], &ax, &ay, &az);
+        trc_pillbox_dir_u(u0, u1, opt[1], &ax, &ay, &az);
         trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
         if (FULL && opt[2] != 0.0) out[0].e = e * exp(-opt[2] * (path * opt[3])) * (1.0 - opt[0]);      // LambertianAbsorbant :895-906
         else {
@@ -1279,7 +1314,7 @@ TRC_HD int trc_shade_k(int opt_kind, const double *opt, const double *extra, int
         } else {
             double u0, u1, ax, ay, az;
             trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
-            trc_pillbox_dir(TRC_TWO_PI * u0, u1, opt[1], &ax, &ay, &az);
+            trc_pillbox_dir_u(u0, u1, opt[1], &ax, &ay, &az);
             trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
             out[0].blk = 1;
         }
@@ -1294,7 +1329,7 @@ TRC_HD int trc_shade_k(int opt_kind, const double *opt, const double *extra, int
         } else {
             double ax, ay, az;
             trc_uniform_pair(seed, rid, event, 1, &u2, &u3);
-            trc_pillbox_dir(TRC_TWO_PI * u1, u2, 1.57079632679489661923, &ax, &ay, &az);
+            trc_pillbox_dir_u(u1, u2, 1.57079632679489661923, &ax, &ay, &az);
             trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
         }
         out[0].e = e * (1.0 - opt[0]);
@@ -1314,7 +1349,7 @@ TRC_HD int trc_shade_k(int opt_kind, const double *opt, const double *extra, int
         double u0, u1, ax, ay, az;
         trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
         if (mode == 0) {
-            trc_pillbox_dir(TRC_TWO_PI * u0, u1, 1.57079632679489661923, &ax, &ay, &az);
+            trc_pillbox_dir_u(u0, u1, 1.57079632679489661923, &ax, &ay, &az);
             trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
         } else {
             const int n = extra_len / ncol;
@@ -1324,7 +1359,7 @@ TRC_HD int trc_shade_k(int opt_kind, const double *opt, const double *extra, int
             } else {
                 double u2, u3;
                 trc_uniform_pair(seed, rid, event, 1, &u2, &u3);
-                trc_pillbox_dir(TRC_TWO_PI * u1, u2, 1.57079632679489661923, &ax, &ay, &az);
+                trc_pillbox_dir_u(u1, u2, 1.57079632679489661923, &ax, &ay, &az);
                 trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
             }
         }
@@ -1550,7 +1585,7 @@ TRC_HD int trc_shade_x(int opt_kind, const double *opt, const double *extra, int
         }
         double u0, u1, ax, ay, az;
         trc_uniform_pair(seed, rid, event, 0, &u0, &u1);
-        trc_pillbox_dir(TRC_TWO_PI * u0, u1, 1.57079632679489661923, &ax, &ay, &az);
+        trc_pillbox_dir_u(u0, u1, 1.57079632679489661923, &ax, &ay, &az);
         trc_rotation_to_z_apply(nx, ny, nz, ax, ay, az, &out[0].dx, &out[0].dy, &out[0].dz);
         out[0].e = en;
         *poly_th = th;
@@ -1706,10 +1741,10 @@ TRC_HD void trc_source_ray_t(const trc_source_desc *src, const double *buie, con
             lz = p[1] * u0 - p[1] / 2.0;
             phi = p[2] + (p[3] - p[2]) * u1;
             { double sp, cp; trc_sincos(phi, &sp, &cp); lx = p[0] * cp; ly = p[0] * sp; }
-            trc_pillbox_dir(TRC_TWO_PI * u2, u3, p[4], &fx, &fy, &fz);
+            trc_pillbox_dir_u(u2, u3, p[4], &fx, &fy, &fz);
             slope = 0.0; sign = p[5];
         } else {
-            trc_pillbox_dir(TRC_TWO_PI * u0, u1, p[5], &fx, &fy, &fz);
+            trc_pillbox_dir_u(u0, u1, p[5], &fx, &fy, &fz);
             slope = (p[1] - p[0]) / p[2];
             double rs = sqrt((p[1] * p[1] - p[0] * p[0]) * u2 + p[0] * p[0]);
             lz = (rs - p[0]) / slope;
@@ -1727,7 +1762,7 @@ TRC_HD void trc_source_ray_t(const trc_source_desc *src, const double *buie, con
         break;
     }
     case TRC_SRC_PILLBOX_DISK: {        // draws: dir phi, dir R, pos xi, pos theta (sources.py:200-213)
-        trc_pillbox_dir(TRC_TWO_PI * u0, u1, p[4], &ax, &ay, &az);
+        trc_pillbox_dir_u(u0, u1, p[4], &ax, &ay, &az);
         double r = sqrt(p[1] * p[1] + u2 * (p[0] * p[0] - p[1] * p[1]));
         double th = p[2] + (p[3] - p[2]) * u3;
         { double st, ct; trc_sincos(th, &st, &ct); lx = r * ct; ly = r * st; }
@@ -1744,7 +1779,7 @@ TRC_HD void trc_source_ray_t(const trc_source_desc *src, const double *buie, con
         break;
     }
     case TRC_SRC_PILLBOX_RECT: {        // draws: dir phi, dir R, xs, ys (sources.py:243-256)
-        trc_pillbox_dir(TRC_TWO_PI * u0, u1, p[2], &ax, &ay, &az);
+        trc_pillbox_dir_u(u0, u1, p[2], &ax, &ay, &az);
         double xs = -p[0] / 2.0 + p[0] * u2, ys = -p[1] / 2.0 + p[1] * u3;
         if (p[3] != 0.0) { double tmp = xs; xs = ys; ys = tmp; }
         lx = ys; ly = xs;               // vertices_local = (ys, xs, 0)
@@ -1764,7 +1799,7 @@ TRC_HD void trc_source_ray_t(const trc_source_desc *src, const double *buie, con
     case TRC_SRC_PILLBOX_TRIANGLE: {    // draws: r1, r2 (point picking), dir phi, dir R (sources.py:559-568)
         double sq = sqrt(u0);
         lx = sq * (1.0 - u1); ly = u1 * sq;     // A + sqrt(r1)(1-r2) AB + r2 sqrt(r1) AC; AB, AC are the columns of rot_pos
-        trc_pillbox_dir(TRC_TWO_PI * u2, u3, p[0], &ax, &ay, &az);
+        trc_pillbox_dir_u(u2, u3, p[0], &ax, &ay, &az);
         break;
     }
     default: {                          // TRC_SRC_BUIE_RECT (sources.py:485-486)

@@ -76,19 +76,64 @@ __global__ __launch_bounds__(SHC_THREADS) void k_s_shade_c(StreamParams S) {
     const int bounce0 = S.bounce_no;          // every ray of a launch is at the same bounce
     const bool aux_in = !P.src || bounce0 > 0;     // fresh rays of a source carry (energy, 1, 0): nothing was written for them
     const long long stride = (long long)gridDim.x * blockDim.x;
+#if SHC_PREFETCH == 2
+    // Two loads stand in front of every hit -- its entry of the list, then the ray record the entry points to.  Both are fetched
+    // ahead, in two stages (as in k_s_shade): while hit i is worked on, the record of hit i + 1 (whose entry arrived an iteration
+    // ago) and the entry of hit i + 2 are on their way.  22 registers.
+    uint32_t slot_a = SQ_INVALID, hs_a = SQ_INVALID, slot_n = SQ_INVALID, hs_n = SQ_INVALID;
+    double t_a = TRC_INF, t_n = TRC_INF, ae_n = 0.0, aw_n = 0.0;
+    SRayGeo g_n;
+    g_n.px = g_n.py = g_n.pz = g_n.dx = g_n.dy = 0.0; g_n.dz = 1.0; g_n.head = SQ_INVALID; g_n.idx = 0u; g_n.tail = 0ull;
+    {
+        const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i0 < nh) { slot_n = S.hl_slot[i0]; hs_n = S.hl_surf[i0]; t_n = S.hl_t[i0]; }
+        if (i0 + stride < nh) { slot_a = S.hl_slot[i0 + stride]; hs_a = S.hl_surf[i0 + stride]; t_a = S.hl_t[i0 + stride]; }
+        if (slot_n != SQ_INVALID) {
+            g_n = W.geo[slot_n];
+            if (aux_in) { ae_n = W.aux[slot_n].e; if (CLS != TRC_CLS_MIRROR) aw_n = W.aux[slot_n].wl; }
+        }
+    }
+#elif defined(SHC_PREFETCH)
+    // the entry of the next iteration is on its way while this one is worked on
+    uint32_t slot_n = SQ_INVALID, hs_n = SQ_INVALID;
+    double t_n = TRC_INF;
+    { const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; if (i0 < nh) { slot_n = S.hl_slot[i0]; hs_n = S.hl_surf[i0]; t_n = S.hl_t[i0]; } }
+#endif
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += stride) {
         uint32_t slot = SQ_INVALID, hs = SQ_INVALID;
         double t = TRC_INF;
-        if (i < nh) { slot = S.hl_slot[i]; hs = S.hl_surf[i]; t = S.hl_t[i]; }
-        bool mine = false;
-        int s = 0, fl = 0;
         SRayGeo g;
         g.px = g.py = g.pz = g.dx = g.dy = 0.0; g.dz = 1.0; g.head = SQ_INVALID; g.idx = 0u; g.tail = 0ull;
+        bool have = false;
+        double ae = 0.0, aw = 0.0;
+#if SHC_PREFETCH == 2
+        slot = slot_n; hs = hs_n; t = t_n; g = g_n; ae = ae_n; aw = aw_n;
+        have = slot != SQ_INVALID;
+        // (everything fetched for this hit is made to arrive here, before the loads for the next ones are issued: see k_s_shade)
+        asm volatile("" : "+v"(slot), "+v"(hs), "+v"(t), "+v"(slot_a), "+v"(hs_a), "+v"(t_a));
+        asm volatile("" : "+v"(g.px), "+v"(g.py), "+v"(g.pz), "+v"(g.dx), "+v"(g.dy), "+v"(g.dz), "+v"(g.head), "+v"(g.idx), "+v"(g.tail));
+        asm volatile("" : "+v"(ae), "+v"(aw));
+        slot_n = slot_a; hs_n = hs_a; t_n = t_a;
+        if (slot_n != SQ_INVALID) {
+            g_n = W.geo[slot_n];
+            if (aux_in) { ae_n = W.aux[slot_n].e; if (CLS != TRC_CLS_MIRROR) aw_n = W.aux[slot_n].wl; }
+        }
+        slot_a = SQ_INVALID; hs_a = SQ_INVALID; t_a = TRC_INF;
+        if (i + 2 * stride < nh) { slot_a = S.hl_slot[i + 2 * stride]; hs_a = S.hl_surf[i + 2 * stride]; t_a = S.hl_t[i + 2 * stride]; }
+#elif defined(SHC_PREFETCH)
+        slot = slot_n; hs = hs_n; t = t_n;
+        asm volatile("" : "+v"(slot), "+v"(hs), "+v"(t));
+        slot_n = SQ_INVALID; hs_n = SQ_INVALID; t_n = TRC_INF;
+        if (i + stride < nh) { slot_n = S.hl_slot[i + stride]; hs_n = S.hl_surf[i + stride]; t_n = S.hl_t[i + stride]; }
+#else
+        if (i < nh) { slot = S.hl_slot[i]; hs = S.hl_surf[i]; t = S.hl_t[i]; }
+#endif
+        bool mine = false;
+        int s = 0, fl = 0;
         if (slot != SQ_INVALID) {
-            bool have = false;
             if (hs == SQ_INVALID) {
                 // general path: the nearest of the ray's linked hits; on equal t the lowest surface index (tracer_engine.py:58-63)
-                g = W.geo[slot];
+                if (!have) g = W.geo[slot];
                 have = true;
                 t = TRC_INF;
                 int sb = 0x7FFFFFFF;
@@ -115,7 +160,12 @@ __global__ __launch_bounds__(SHC_THREADS) void k_s_shade_c(StreamParams S) {
             n_hit += 1;
             const int prev = bounce0 == 0 ? Sn : (int)((uint32_t)(g.tail >> 32) & ~SQ_SKIP_SELF);      // the surface the ray left; Sn = the source
             double e = src_energy, wl = 0.0;
+#if SHC_PREFETCH == 2
+            if (aux_in) { e = ae; wl = aw; }
+#else
             if (aux_in) { e = W.aux[slot].e; if (CLS != TRC_CLS_MIRROR) wl = W.aux[slot].wl; }
+            (void)ae; (void)aw;
+#endif
             const double *rec = L.recs + (size_t)s * sc.stride;
             const double hx = g.px + t * g.dx, hy = g.py + t * g.dy, hz = g.pz + t * g.dz;
             double ox = g.dx, oy = g.dy, oz = g.dz, e_out = 0.0;

@@ -51,9 +51,10 @@ class LazySourceBundle(RayBundle):
         object.__setattr__(self, '_src_done', True)
         n = self._src_n
         ctx = _cabi.get_context()
-        v = N.empty((3, n))
-        d = N.empty((3, n))
-        e = N.empty(n)
+        # (page-locked for large bundles: 1e7 rays are 560 MB, 11 ms over the link instead of 40 through pageable memory)
+        v = _cabi.pinned_empty((3, n))
+        d = _cabi.pinned_empty((3, n))
+        e = _cabi.pinned_empty(n)
         rays = _cabi.make_rays(n, v[0], v[1], v[2], d[0], d[1], d[2], e)
         _cabi.check(ctx.lib.trc_source_generate(ctx.handle, C.byref(self._src_desc), n, self._src_seed,
                                                 self._src_offset, C.byref(rays)))

@@ -199,12 +199,16 @@ class TracerEngine(object):
             seed = rng.next_seed()
         self.reps = reps
         self.minener = min_energy
-        self.tree = RayTree()
+        t_call = time.time()
+        self.tree = RayTree()           # (the tree of the call before goes: levels nobody can read any more leave the device here)
+        self._t_marks = [('old tree released', time.time() - t_call)]
 
         if engine == 'protocol':
             return self._trace_protocol(bundle, reps, min_energy, tree)
         try:
+            t1 = time.time()
             dev = self._device_scene(unchanged=scene_unchanged)
+            self._t_marks.append(('scene checked', time.time() - t1))
         except NotNativeError as err:
             if engine != 'auto':
                 raise
@@ -474,7 +478,7 @@ class TracerEngine(object):
     def _set_stats(self, stats, wall, engine):
         self.stats = dict(engine=engine, segments=stats.segments, hits=stats.hits, rays_left=stats.rays_left,
                           energy_left=stats.energy_left, kernel_ms=stats.kernel_ms, bounces=stats.bounces,
-                          launches=stats.launches, wall_s=wall)
+                          launches=stats.launches, wall_s=wall, host_s=dict(getattr(self, '_t_marks', [])))
         logging.log(self.loglevel, 'trace time %s s' % wall)
 
     def _warn_left(self, rays_left, energy_left, bundle):
