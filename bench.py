@@ -359,8 +359,9 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_fetch_as_counted': traffic_raw,
                          'kernel': 'k_trace_coop<512>' if launches == 1 else
-                                   'fast engine, streaming form: k_s_cull + k_s_fresh (+ the general path for the aureole) + k_s_shade, '
-                                   'then k_s_bounce + k_s_shade + k_s_absorb (the hits on the receiver) per bounce (%d launches per step)' % launches,
+                                   'fast engine, streaming form: k_s_cull + k_s_fresh2 (+ the general path for the aureole) + k_s_shade_c<mirror>, '
+                                   'then k_s_bounce (the hits on the receiver finished inside) + k_s_shade_c<mirror> per bounce '
+                                   '(%d launches per step)' % launches,
                          'kernel_ms_per_launch': kms / args.steps,
                          'algorithmic_bytes_per_launch': seg / args.steps * B_SEG,
                          # what the counters say moves through HBM, over the same kernel time: the fraction of the 8 TB/s actually used

@@ -1,7 +1,8 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r3mesh
+export MESH_OUT=${MESH_OUT:-r3mesh}
+O=$GRAFT_REPO_ROOT/gpurun_out/$MESH_OUT
 mkdir -p $O
 R=$GRAFT_REPO_ROOT
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/tools/gpu_mesh.py 1e7 > $O/stats.log 2>&1); grep -a "^run\|faces:" $O/stats.log
@@ -11,7 +12,8 @@ python3 tools/kstats.py $O/stats | sort -k6 -n -r | head -10
 python3 tools/pmc_kernels.py 3 1e7 $O/pmc1 $O/pmc2 > $O/sq.json
 python3 - <<'PY'
 import json
-d=json.load(open('gpurun_out/r3mesh/sq.json'))
+import os
+d=json.load(open('gpurun_out/%s/sq.json' % os.environ.get('MESH_OUT','r3mesh')))
 for k,v in d['per_kernel'].items():
     c=v['counters']
     if c.get('SQ_WAVES',0)<64: continue

@@ -1,0 +1,9 @@
+set -e
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+L=$GRAFT_REPO_ROOT/tracer_amd/lib
+echo "== product, 2e5 rays first"; timeout -k 10 120 python tools/gpu_mesh.py 2e5 2>&1 | tail -1
+echo "== product"; timeout -k 10 120 python tools/gpu_mesh.py 1e7 2>&1 | tail -2
+echo "== wave per 64 rays"; TRC_STREAM_REFILL=0 timeout -k 10 120 python tools/gpu_mesh.py 1e7 2>&1 | tail -1
+echo "== stats"; TRACER_AMD_LIB=$L/var_stats.so timeout -k 10 300 python tools/gpu_mesh.py 1e7 2>&1 | tail -2
+timeout -k 10 900 python -m pytest tests/test_gpu_stream.py -m gpu -x -q -k "mesh" 2>&1 | tail -3

@@ -735,6 +735,30 @@ TRC_HD bool trc_obb_hit32(const float *B, float ox, float oy, float oz, float dx
     return hi * 1.0001f + 1e-6f >= lo;       // NaNs (0 * inf) are ignored by fminf/fmaxf: conservative, as in trc_box_hit32
 }
 
+// The same question for a triangular face (triangular_face.py:59-72) from its corner and two edges in single precision
+// (relative to the scene centre like the ray's origin): can the exact test succeed?  With T = o - v0, the scaled barycentric
+// coordinates are u = T . (d x e2), v = d . (T x e1) over det = e1 . (d x e2); the point is inside when u, v >= 0 and u + v <= det
+// (signs for det > 0).  A displacement of the ray by delta -- which covers single-precision rounding of the origin, the direction
+// and the products with two orders of magnitude to spare, as for the boxes above -- changes u and v by at most delta * max|edge|:
+// the test allows E = 1.5 delta max|edge| on every comparison, so that a ray is rejected only when the exact test rejects it too.
+// A ray within 1e-5 of the face's plane is passed on without a decision (the sign of det is not reliable there; the exact test
+// refuses |d . n| <= 1e-7 itself).  t * det = e2 . (T x e1) sorts out the faces behind the origin.
+// ent: [index | v0 (3) | e1 (3) | E | e2 (3) | max|edge|^2]
+TRC_HD bool trc_tri_hit32(float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float E, float e2x, float e2y, float e2z,
+                          float emax2, float delta, const trc_ray32 &r) {
+    const float tx = r.ox - v0x, ty = r.oy - v0y, tz = r.oz - v0z;
+    const float px = fmaf(r.dy, e2z, -(r.dz * e2y)), py = fmaf(r.dz, e2x, -(r.dx * e2z)), pz = fmaf(r.dx, e2y, -(r.dy * e2x));
+    const float det = fmaf(e1x, px, fmaf(e1y, py, e1z * pz));
+    const float qx = fmaf(ty, e1z, -(tz * e1y)), qy = fmaf(tz, e1x, -(tx * e1z)), qz = fmaf(tx, e1y, -(ty * e1x));
+    float u = fmaf(tx, px, fmaf(ty, py, tz * pz));
+    float v = fmaf(r.dx, qx, fmaf(r.dy, qy, r.dz * qz));
+    float tn = fmaf(e2x, qx, fmaf(e2y, qy, e2z * qz));
+    if (det < 0.0f) { u = -u; v = -v; tn = -tn; }
+    const float ad = fabsf(det);
+    if (!(ad > 1e-5f * emax2)) return true;
+    return u >= -E && v >= -E && u + v <= ad + 2.0f * E && tn >= -delta * (ad + emax2);
+}
+
 // One interior-node step of the conservative single-precision walk (used by trc_nearest_accel32 below and by the
 // wave-cooperative kernel).  w0/w1: the packed node.  Returns the node to continue with; when *push is set the
 // caller must push (*push_na = other child << 2 | axis code, *push_t = interval end of that child) and the

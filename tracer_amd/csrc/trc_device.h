@@ -49,7 +49,8 @@ struct DScene {
     int32_t a_g_ok, a_g_ncell, a_g_nlist, a_g_napart, a_gdim[3];
     float a_glo[3], a_gcs[3], a_ginv[3], a_groot[6];
     // the grid of scenes too large for LDS (trc_accel_build_grid32): 32-bit offsets and lists in global memory
-    const uint32_t *a_bg_off, *a_bg_list;
+    const uint32_t *a_bg_off, *a_bg_occ;    // first entry of every cell; one bit per cell that lists anything
+    const float *a_bg_ent;                  // TRC_BG_ENT floats per listed surface (trc_bounds.h)
     const int32_t *a_bg_apart;  // bounded surfaces kept out of that grid (box-tested for every ray)
     int32_t a_bg_napart, a_bg_pad;
     int32_t a_bg_ok, a_bg_dim[3];
@@ -464,6 +465,7 @@ struct StreamParams {
     int lds_extra;       // k_s_shade: the scene's table values (optics tables: absorptance over angle / wavelength, complex indices) in LDS
                          // too -- an interpolation is a binary search, every step a dependent load
     int bounce_no;       // the bounce this launch belongs to (every ray of a launch is at the same bounce)
+    int bg_occ_words;    // k_s_bounce<2>: the occupancy bits of the large grid staged in LDS (this many words), 0 = read from global memory
     int split_terminal;  // k_s_bounce lists the hits on surfaces that end every ray (TRC_SURF_TERMINAL) apart, for k_s_absorb: CN(11),
                          // entries in the arrays of the walker queue, which is idle in a bounce that k_s_bounce serves
     unsigned chunk_thit; // ... one pre-assigned chunk per wave of k_s_bounce

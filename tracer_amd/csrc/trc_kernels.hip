@@ -102,7 +102,8 @@ struct trc_scene {
     int32_t *d_a_unbounded;
     uint16_t *d_a_bleaf;
     uint16_t *d_a_goff, *d_a_glist;
-    uint32_t *d_a_bg_off, *d_a_bg_list;
+    uint32_t *d_a_bg_off, *d_a_bg_occ;
+    float *d_a_bg_ent;
     int32_t *d_a_bg_apart;
     int32_t *d_a_gapart;
     struct StreamEngine *stream_eng;   // slots of the streaming fast engine (trc_stream.inc), allocated on first use
@@ -1416,15 +1417,18 @@ static int scene_upload_surfaces(trc_scene *sc) {
         HIP_TRY(hipMemcpy(sc->d_a_goff, sc->accel.grid_off.data(), sc->accel.grid_off.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(sc->d_a_glist, sc->accel.grid_list.data(), sc->accel.grid_list.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
-    dev_free(sc->d_a_bg_off); dev_free(sc->d_a_bg_list); dev_free(sc->d_a_bg_apart);
-    sc->d_a_bg_off = nullptr; sc->d_a_bg_list = nullptr; sc->d_a_bg_apart = nullptr;
+    dev_free(sc->d_a_bg_off); dev_free(sc->d_a_bg_occ); dev_free(sc->d_a_bg_ent); dev_free(sc->d_a_bg_apart);
+    sc->d_a_bg_off = nullptr; sc->d_a_bg_occ = nullptr; sc->d_a_bg_ent = nullptr; sc->d_a_bg_apart = nullptr;
     if (!sc->accel.grid_ok) {      // a scene the LDS-sized grid cannot hold: the 32-bit grid in global memory
         trc_accel_build_grid32(sc->surfs.data(), sc->n_surf, sc->accel);
         if (sc->accel.big_ok) {
             TRC_TRY(dev_alloc(&sc->d_a_bg_off, sc->accel.big_off.size()));
-            TRC_TRY(dev_alloc(&sc->d_a_bg_list, sc->accel.big_list.size()));
+            TRC_TRY(dev_alloc(&sc->d_a_bg_ent, sc->accel.big_ent.size()));
+            TRC_TRY(dev_alloc(&sc->d_a_bg_occ, sc->accel.big_occ.size()));
             HIP_TRY(hipMemcpy(sc->d_a_bg_off, sc->accel.big_off.data(), sc->accel.big_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(sc->d_a_bg_list, sc->accel.big_list.data(), sc->accel.big_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(sc->d_a_bg_ent, sc->accel.big_ent.data(), sc->accel.big_ent.size() * sizeof(float), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(sc->d_a_bg_occ, sc->accel.big_occ.data(), sc->accel.big_occ.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            std::vector<float>().swap(sc->accel.big_ent);       // (the host keeps the list itself, not its 48-byte entries)
             TRC_TRY(dev_alloc(&sc->d_a_bg_apart, sc->accel.big_apart.size() + 1));
             if (!sc->accel.big_apart.empty())
                 HIP_TRY(hipMemcpy(sc->d_a_bg_apart, sc->accel.big_apart.data(), sc->accel.big_apart.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1473,7 +1477,7 @@ extern "C" int trc_scene_create(trc_ctx *ctx, int32_t n_surf, const trc_surface_
     sc->d_last_cap = 0;
     memset(sc->cnt_host, 0, sizeof(sc->cnt_host));
     sc->n_surf = n_surf;
-    sc->stride = TRC_REC_HDR + max_np;
+    sc->stride = (TRC_REC_HDR + max_np + 1) & ~1;      // even: a record starts on 16 bytes (k_s_bounce reads a triangle's whole record in 16-byte pieces)
     if ((sc->stride & 1) == 0) sc->stride += 1;  // odd number of doubles: spreads records over LDS banks
     sc->n_extra = n_extra;
     sc->surfs.assign(surfs, surfs + n_surf);
@@ -1515,7 +1519,7 @@ extern "C" int trc_scene_destroy(trc_scene *sc) {
     dev_free(sc->d_recs); dev_free(sc->d_opt); dev_free(sc->d_extra); dev_free(sc->d_sflags);
     dev_free(sc->d_kd_a); dev_free(sc->d_kd_b); dev_free(sc->d_kd_leaf); dev_free(sc->d_kd_always);
     dev_free(sc->d_a_sbox); dev_free(sc->d_a_obb); dev_free(sc->d_a_nodes); dev_free(sc->d_a_leaf); dev_free(sc->d_a_unbounded); dev_free(sc->d_a_bleaf);
-    dev_free(sc->d_a_goff); dev_free(sc->d_a_glist); dev_free(sc->d_a_gapart); dev_free(sc->d_a_bg_off); dev_free(sc->d_a_bg_list); dev_free(sc->d_a_bg_apart);
+    dev_free(sc->d_a_goff); dev_free(sc->d_a_glist); dev_free(sc->d_a_gapart); dev_free(sc->d_a_bg_off); dev_free(sc->d_a_bg_occ); dev_free(sc->d_a_bg_ent); dev_free(sc->d_a_bg_apart);
     dev_free(sc->d_kd_split); dev_free(sc->d_tally); dev_free(sc->d_fm_of_surf); dev_free(sc->d_fms);
     dev_free(sc->d_fm_edges); dev_free(sc->d_counters); dev_free(sc->d_src_buf); dev_free(sc->d_h_surf);
     for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
@@ -2110,7 +2114,7 @@ static DScene make_dscene(trc_scene *sc) {
     for (int i = 0; i < 6; ++i) d.a_root[i] = sc->accel.root[i];
     d.a_delta = sc->accel.delta;
     d.a_goff = sc->d_a_goff; d.a_glist = sc->d_a_glist; d.a_gapart = sc->d_a_gapart;
-    d.a_bg_off = sc->d_a_bg_off; d.a_bg_list = sc->d_a_bg_list; d.a_bg_ok = sc->accel.big_ok ? 1 : 0;
+    d.a_bg_off = sc->d_a_bg_off; d.a_bg_occ = sc->d_a_bg_occ; d.a_bg_ent = sc->d_a_bg_ent; d.a_bg_ok = sc->accel.big_ok ? 1 : 0;
     d.a_bg_apart = sc->d_a_bg_apart; d.a_bg_napart = sc->accel.big_ok ? (int32_t)sc->accel.big_apart.size() : 0;
     for (int i = 0; i < 3; ++i) {
         d.a_bg_dim[i] = sc->accel.big_ok ? sc->accel.big_dim[i] : 1;

@@ -236,6 +236,9 @@ __global__ __launch_bounds__(SHC_THREADS) void k_s_shade_c(StreamParams S) {
                 if (in) ts = -1;
                 todo &= ~m;
             }
+#ifdef SHC_DIAG_NO_TALLY        /* diagnostic builds only: what the scattered sums beyond LDS cost */
+            if (LDS)
+#endif
             if (ts >= 0) { atomicAdd(&tl[ts], tea); atomicAdd(&tl[Sn + ts], tei); atomicAdd(&tl[2 * Sn + ts], 1.0); }
         }
         if (P.capture) chunk_rebroadcast(hc, __ffsll((long long)my_lanes) - 1);   // hc was advanced by the lanes with a hit only
