@@ -319,3 +319,66 @@ def test_estimator_running_mean_and_interval():
     compat.install()
     from ray_trace_utils.estimator import Estimator as E2
     assert E2 is Estimator
+
+
+def test_mesh_faces_kept_as_arrays_compile_like_one_surface_per_face(tmp_path):
+    """
+    models/triangulated_surface.py:12-52 and ray_trace_utils/stl_utils.py:178-235 make one Surface per face; here the faces of a mesh
+    are one FaceSet of arrays (face_set.py) and a Surface exists once a script asks for it.  The device table compiled from the arrays
+    is byte for byte the one compiled from the Surfaces; moving the object moves the faces; nothing is materialised by compiling.
+    """
+    import ctypes as C
+    from tracer_amd import optics_callables as opt, stl_utils
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM
+    from tracer_amd.face_set import FaceSet, SurfaceSeq
+    from tracer_amd.models.triangulated_surface import TriangulatedSurface
+    from tracer_amd.triangular_face import TriangularFace
+    from tracer_amd.spatial_geometry import translate, rotx, rotz
+    from tracer_amd.scene import compile_scene
+    rng = N.random.default_rng(5)
+    V = rng.normal(size=(40, 3))
+    F = N.array([rng.choice(40, 3, replace=False) for _ in range(120)])
+    F[7] = (3, 3, 9)                 # degenerate: dropped, as in the reference
+    shared = opt.Reflective(0.2)
+    mesh = TriangulatedSurface(V, F, shared, transform=N.dot(translate(0.3, -0.2, 1.), rotx(0.4)))
+    plate = AssembledObject(surfs=[Surface(RectPlateGM(2., 3.), opt.LambertianReceiver(1.))], transform=translate(0., 0., 5.))
+    asm = Assembly(objects=[plate, mesh])
+    faces = mesh.get_surfaces()
+    assert isinstance(faces, FaceSet) and len(faces) == 119 and len(faces._made) == 0
+    surfaces = asm.get_surfaces()
+    assert isinstance(surfaces, SurfaceSeq) and len(surfaces) == 120
+    cs = compile_scene(asm)
+    assert len(faces._made) == 0 and cs.n_surf == 120 and cs.optics[1] is shared and len(cs.optics) == 2
+    eager = compile_scene(list(surfaces))            # one Surface per face now exists
+    assert len(faces._made) == 119
+    raw = lambda c: bytes(C.string_at(C.addressof(c.descs), C.sizeof(c.descs)))
+    assert raw(cs) == raw(eager) and N.array_equal(cs.frames12(), eager.frames12())
+    assert cs.signature_without_frames() == eager.signature_without_frames()
+    s5 = surfaces[6]
+    assert s5 is faces[5] and isinstance(s5.get_geometry_manager(), TriangularFace) and s5.get_optics_manager() is shared
+    assert surfaces.index(s5) == 6 and surfaces[-1] is faces[118] and [s for s in surfaces][0] is plate.get_surfaces()[0]
+    # moving the assembly moves the faces, made or not
+    asm.set_transform(N.dot(translate(1., 2., 3.), rotz(0.3)))
+    moved = compile_scene(asm)
+    assert raw(moved) == raw(compile_scene(list(asm.get_surfaces()))) and raw(moved) != raw(cs)
+    assert moved.signature_without_frames() == cs.signature_without_frames()
+    asm.reset_all_optics()
+    # an STL file of the same triangles: frames as stl_to_tracer_geom gives them one by one, optics instances per face on demand
+    tri = V[F[[0, 1, 2, 5]]]
+    path = str(tmp_path / 'm.stl')
+    stl_utils.make_stl(V, F[[0, 1, 2, 5]], path)
+    obj = stl_utils.load_stl_into_tracer(path, opt.Reflective, dict(absorptivity=0.3), option='triangle')
+    fs = obj.get_surfaces()
+    assert isinstance(fs, FaceSet) and len(fs) == 4 and len(obj.get_boundaries()) == 4
+    geoms, locs, rots = stl_utils.stl_to_tracer_geom(stl_utils.load_stl(path), option='triangle')
+    for k in range(4):
+        assert N.allclose(fs[k].get_location(), locs[k], atol=0) and N.allclose(fs[k].get_rotation(), rots[k], atol=1e-15)
+        assert N.allclose(fs[k].get_geometry_manager()._verts, geoms[k]._verts, atol=1e-15)
+    assert fs[0].get_optics_manager() is not fs[1].get_optics_manager() and fs[2] is fs[2]
+    box = obj.get_boundaries()[1]
+    assert N.allclose(box._AABB, [tri[1].min(axis=0), tri[1].max(axis=0)], atol=1e-6)
+    cs_stl = compile_scene(obj)
+    assert raw(cs_stl) == raw(compile_scene(list(fs)))

@@ -34,7 +34,7 @@ lid = AssembledObject(surfs=[Surface(RectPlateGM(90., 90.), opt.LambertianReceiv
 cs = compile_scene(Assembly(objects=[mesh, lid]))
 t1 = time.time()
 dev = DeviceScene(cs, ctx)
-print('%d faces: %.1f s to build the Surface objects and compile them, %.2f s to upload (boxes, 32-bit grid)' % (len(F), t1 - t0, time.time() - t1), flush=True)
+print('%d faces: %.2f s to build the mesh object and compile it, %.2f s to upload (boxes, 32-bit grid)' % (len(F), t1 - t0, time.time() - t1), flush=True)
 direction = N.r_[0.1, -0.05, -1.] / N.linalg.norm([0.1, -0.05, -1.])
 for r in range(3):
     b = sources.buie_sunshape(n, N.c_[-40. * direction], direction, float(os.environ.get("MESH_SRC_RADIUS", "12.")), 0.05, flux=1., seed=23 + r)

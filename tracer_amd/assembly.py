@@ -6,6 +6,7 @@ order defines the surface indices of the flattened device scene and the tie rule
 """
 import numpy as N
 from .has_frame import HasFrame
+from .face_set import FaceSet, SurfaceSeq
 
 
 class Assembly(HasFrame):
@@ -32,7 +33,10 @@ class Assembly(HasFrame):
         return found
 
     def get_surfaces(self):
-        return [s for obj in self.get_objects() for s in obj.get_surfaces()]
+        per_object = [obj.get_surfaces() for obj in self.get_objects()]
+        if any(isinstance(p, FaceSet) for p in per_object):     # a mesh that keeps its faces as arrays: nothing is materialised
+            return SurfaceSeq(per_object)
+        return [s for p in per_object for s in p]
 
     def add_object(self, object, transform=None):
         self._objects.append(object)
@@ -65,7 +69,8 @@ class Assembly(HasFrame):
             child.transform_children(mine)
 
     def reset_all_optics(self):
-        for s in self.get_surfaces():
-            opt = s.get_optics_manager()
+        surfaces = self.get_surfaces()
+        managers = surfaces.distinct_optics() if isinstance(surfaces, SurfaceSeq) else [s.get_optics_manager() for s in surfaces]
+        for opt in managers:
             if hasattr(opt, 'reset'):
                 opt.reset()

@@ -2331,7 +2331,10 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         const bool stream_ok = !mode_env && n >= 64 && stream_plan(sc, want_accel, &stream_mode, &stream_lds);
         const bool force_stream = (flags & TRC_TRACE_STREAM) || stream_env == 1;
         const bool force_mega = (flags & TRC_TRACE_MEGAKERNEL) || stream_env == 0;
-        const bool use_stream = stream_ok && (force_stream || (!force_mega && n >= TRC_STREAM_MIN_RAYS));
+        // (a scene on the large grid -- a mesh of 1e5 faces -- has nothing but its boxes to search in the megakernel: 2e5 rays on the
+        // relief of 105 800 triangles took 570 ms there, 1.3 ms here)
+        const long long stream_from = stream_mode == 3 ? 4096 : TRC_STREAM_MIN_RAYS;
+        const bool use_stream = stream_ok && (force_stream || (!force_mega && n >= stream_from));
         if (use_stream) {
             if (!sc->stream_eng) {
                 sc->stream_eng = new (std::nothrow) StreamEngine();

@@ -1,14 +1,14 @@
 """
 A surface given as an indexed set of triangular faces (reference: tracer/models/triangulated_surface.py:7-52): one
 TriangularFace Surface per non-degenerate face, in the face's own frame (origin at its first vertex, x along its first
-edge, z along the face normal).  Host construction, vectorised over the faces; the faces are ordinary native surfaces
-for the device (TRC_GM_TRIANGLE), found through the engine's grid or Kd-tree.
+edge, z along the face normal).  The faces are kept as arrays (face_set.FaceSet: origins, rotations, local edges, the shared
+optics); `get_surfaces()[k]` makes the Surface of face k when a script asks for it.  For the device they are ordinary native
+surfaces (TRC_GM_TRIANGLE), found through the engine's grid.
 """
 import numpy as N
 
 from ..object import AssembledObject
-from ..surface import Surface
-from ..triangular_face import TriangularFace
+from ..face_set import FaceSet
 
 
 class TriangulatedSurface(AssembledObject):
@@ -36,7 +36,6 @@ class TriangulatedSurface(AssembledObject):
 
         frames = N.concatenate((x_axis[..., None], y_axis[..., None], z_axis[..., None]), axis=2)      # columns = axes
         local_edges = N.einsum('fji,fej->fei', frames, edges)                                            # R^T e per face and edge
-        surfs = [Surface(TriangularFace(local_edges[k].T), optics, location=origin[k], rotation=frames[k])
-                 for k in range(len(origin))]
+        surfs = FaceSet(origin, frames, local_edges, optics=optics)
         # (the reference passes `transform` third positionally, where object.py now has `location`: by keyword here)
         AssembledObject.__init__(self, surfs=surfs, bounds=None, transform=transform)

@@ -43,8 +43,12 @@ class AssembledObject(Assembly):
 
     def transform_children(self, assembly_transform=N.eye(4)):
         mine = N.dot(assembly_transform, self.get_transform())
-        for child in list(self.surfaces) + list(self.boundaries):
-            child.transform_frame(mine)
+        for group in (self.surfaces, self.boundaries):
+            if hasattr(group, 'transform_frames'):      # the faces of a mesh kept as arrays (face_set.py): moved in one go
+                group.transform_frames(mine)
+            else:
+                for child in group:
+                    child.transform_frame(mine)
 
     def own_rays(self, rays, surface_id):
         """Default: the object claims no ray (object.py:81-95)."""

@@ -17,6 +17,7 @@ import numpy as N
 from . import _cabi
 from .geometry_manager import NativeGeometryManager, fill_desc
 from .deferred import Delivery
+from .face_set import FaceSet, SurfaceSeq
 from .optics_callables import OpticsCallable, native_optics_of, LocationAccountant, DirectionAccountant, \
     AbsorptionAccountant, ReceptionAccountant, ScatteringAccountant, NormalAccountant
 
@@ -42,7 +43,8 @@ class NotNativeError(NotImplementedError):
 
 class CompiledScene(object):
     def __init__(self, surfaces):
-        self.surfaces = list(surfaces)
+        # (the faces of a mesh kept as arrays stay arrays: face_set.SurfaceSeq -- everything else is a list of Surfaces)
+        self.surfaces = surfaces if isinstance(surfaces, SurfaceSeq) else list(surfaces)
         n = len(self.surfaces)
         if n == 0:
             raise ValueError("the assembly has no surfaces")
@@ -50,57 +52,96 @@ class CompiledScene(object):
         # the table is filled row by row into one array laid out like trc_surface_desc (6 int32, then frame 12, gm 16, opt 8 doubles)
         # and copied over the ctypes array at the end: this runs once per call of ray_tracer, to see whether the scene changed
         rows = N.zeros(n, dtype=_DESC_DTYPE)
-        extra = []
+        self._extra = []
         self.splits = False
         self.carries = False        # optics that read what only rays of the ordered engine carry (complex indices, spectra)
         self.materials = []         # materials of the Refractive surfaces; row k of trc_rays.mat is materials[k].m(wavelengths)
-        self.capture = []
-        for i, s in enumerate(self.surfaces):
-            gm = s.get_geometry_manager()
-            opt = s.get_optics_manager()
-            nat = native_optics_of(opt)
-            if not isinstance(gm, NativeGeometryManager):
-                raise NotNativeError("surface %d: geometry manager %s is not in the native table" % (i, type(gm).__name__))
-            if nat is None:
-                raise NotNativeError("surface %d: optics %s is not in the native table" % (i, type(opt).__name__))
-            gkind, gpar, gextra = gm._native()
-            try:
-                okind, opar, oextra = nat._native()
-            except NotImplementedError as err:
-                raise NotNativeError("surface %d: %s" % (i, err))
-            if len(gextra) and len(oextra):
-                raise NotNativeError("surface %d: both geometry and optics carry tables" % i)
-            if okind == _cabi.OPT_REFRACTIVE_MATERIAL:      # opt[4], opt[5]: the scene's rows of this surface's two materials
-                opar = list(opar)
-                for j, mat in enumerate(nat._materials):
-                    known = [k for k, m in enumerate(self.materials) if m is mat]
-                    if not known:
-                        self.materials.append(mat)
-                        known = [len(self.materials) - 1]
-                    opar[4 + j] = float(known[0])
-            if okind in (_cabi.OPT_REFRACTIVE_MATERIAL, _cabi.OPT_LAMBERTIAN_POLYCHROMATIC):
-                self.carries = True
-            ex = list(gextra) if len(gextra) else list(oextra)
-            off = len(extra) if len(ex) else -1
-            extra.extend(ex)
-            wants_hits = isinstance(opt, OpticsCallable) and len(opt.accountants) > 0
-            self.capture.append(wants_hits)
-            sflags = _cabi.SURF_CAPTURE_HITS if wants_hits else 0
-            # "Receiver" classes (absorbed energy + hit points): the device leaves incident energy and direction of their hits out
-            if wants_hits and all(type(a) in (AbsorptionAccountant, LocationAccountant) for a in opt.accountants):
-                sflags |= _cabi.SURF_CAPTURE_LEAN
-            row = rows[i]
-            row['ints'] = (gkind, okind, sflags, off, len(ex), 0)
-            row['frame'] = N.asarray(s._temp_frame, dtype=float)[:3].ravel()
-            if len(gpar):
-                row['gm'][:len(gpar)] = gpar
-            if len(opar):
-                row['opt'][:len(opar)] = opar
-            if getattr(nat, '_splits', False):
-                self.splits = True
+        self.capture = [False] * n
+        self.optics = []            # the distinct optics managers of the scene, in surface order; those that capture hits
+        self.capturing_optics = []
+        self._seen = set()
+        segments = self.surfaces.segments() if isinstance(self.surfaces, SurfaceSeq) else [(0, self.surfaces)]
+        for first, part in segments:
+            if isinstance(part, FaceSet):           # all faces of a mesh at once: one optics (or one recipe), one kind of geometry
+                m = len(part)
+                okind, opar, sflags = self._optics_row(first, part.optics_template(), no_tables=True)
+                if part.optics is None and (sflags & _cabi.SURF_CAPTURE_HITS):
+                    # every face its own accountants: they have to exist before hits are promised to them
+                    for s in part:
+                        self._note_optics(s.get_optics_manager(), True)
+                gkind, gpar = part.gm_rows()
+                block = rows[first:first + m]
+                block['ints'] = (gkind, okind, sflags, -1, 0, 0)
+                block['frame'] = part.global_frames12()
+                block['gm'][:, :gpar.shape[1]] = gpar
+                if len(opar):
+                    block['opt'][:, :len(opar)] = opar
+                if sflags & _cabi.SURF_CAPTURE_HITS:
+                    self.capture[first:first + m] = [True] * m
+                continue
+            for i, s in enumerate(part, first):
+                gm = s.get_geometry_manager()
+                if not isinstance(gm, NativeGeometryManager):
+                    raise NotNativeError("surface %d: geometry manager %s is not in the native table" % (i, type(gm).__name__))
+                gkind, gpar, gextra = gm._native()
+                okind, opar, sflags, oextra = self._optics_row(i, s.get_optics_manager())
+                if len(gextra) and len(oextra):
+                    raise NotNativeError("surface %d: both geometry and optics carry tables" % i)
+                ex = list(gextra) if len(gextra) else list(oextra)
+                off = len(self._extra) if len(ex) else -1
+                self._extra.extend(ex)
+                self.capture[i] = bool(sflags & _cabi.SURF_CAPTURE_HITS)
+                row = rows[i]
+                row['ints'] = (gkind, okind, sflags, off, len(ex), 0)
+                row['frame'] = N.asarray(s._temp_frame, dtype=float)[:3].ravel()
+                if len(gpar):
+                    row['gm'][:len(gpar)] = gpar
+                if len(opar):
+                    row['opt'][:len(opar)] = opar
         C.memmove(self.descs, rows.ctypes.data, n * C.sizeof(_cabi.SurfaceDesc))
-        self.extra = _cabi.f64(extra)
+        self.extra = _cabi.f64(self._extra)
+        del self._extra, self._seen
         self.n_surf = n
+
+    def _optics_row(self, i, opt, no_tables=False):
+        """(kind, parameters, surface flags[, table]) of an optics manager, and what it means for the scene as a whole"""
+        nat = native_optics_of(opt)
+        if nat is None:
+            raise NotNativeError("surface %d: optics %s is not in the native table" % (i, type(opt).__name__))
+        try:
+            okind, opar, oextra = nat._native()
+        except NotImplementedError as err:
+            raise NotNativeError("surface %d: %s" % (i, err))
+        if okind == _cabi.OPT_REFRACTIVE_MATERIAL:      # opt[4], opt[5]: the scene's rows of this surface's two materials
+            opar = list(opar)
+            for j, mat in enumerate(nat._materials):
+                known = [k for k, m in enumerate(self.materials) if m is mat]
+                if not known:
+                    self.materials.append(mat)
+                    known = [len(self.materials) - 1]
+                opar[4 + j] = float(known[0])
+        if okind in (_cabi.OPT_REFRACTIVE_MATERIAL, _cabi.OPT_LAMBERTIAN_POLYCHROMATIC):
+            self.carries = True
+        if getattr(nat, '_splits', False):
+            self.splits = True
+        wants_hits = isinstance(opt, OpticsCallable) and len(opt.accountants) > 0
+        self._note_optics(opt, wants_hits)
+        sflags = _cabi.SURF_CAPTURE_HITS if wants_hits else 0
+        # "Receiver" classes (absorbed energy + hit points): the device leaves incident energy and direction of their hits out
+        if wants_hits and all(type(a) in (AbsorptionAccountant, LocationAccountant) for a in opt.accountants):
+            sflags |= _cabi.SURF_CAPTURE_LEAN
+        if no_tables:
+            if len(oextra):
+                raise NotNativeError("surface %d: the faces of a mesh share optics that carry a table (%s)" % (i, type(opt).__name__))
+            return okind, opar, sflags
+        return okind, opar, sflags, oextra
+
+    def _note_optics(self, opt, captures):
+        if id(opt) not in self._seen:
+            self._seen.add(id(opt))
+            self.optics.append(opt)
+            if captures:
+                self.capturing_optics.append(opt)
 
     def signature(self):
         """Bytes that identify everything uploaded to the device."""
@@ -109,16 +150,18 @@ class CompiledScene(object):
     def signature_without_frames(self):
         """The same with the surface frames left out: equal for two states of a scene that only moved (a heliostat field
         following the sun) -- then DeviceScene.update_frames is enough."""
-        parts = []
-        for d in self.descs:
-            parts.append(bytes(N.array([d.gm_kind, d.optics_kind, d.flags, d.extra_off, d.extra_len], dtype=N.int32)))
-            parts.append(bytes(N.array(list(d.gm) + list(d.opt))))
-        return b''.join(parts) + self.extra.tobytes()
+        rows = N.frombuffer(self.descs, dtype=_DESC_DTYPE)
+        return rows['ints'][:, :5].tobytes() + rows['gm'].tobytes() + rows['opt'].tobytes() + self.extra.tobytes()
 
     def frames12(self):
         fr = N.empty((self.n_surf, 12))
-        for i, s in enumerate(self.surfaces):
-            fr[i] = N.asarray(s._temp_frame, dtype=float)[:3].ravel()
+        segments = self.surfaces.segments() if isinstance(self.surfaces, SurfaceSeq) else [(0, self.surfaces)]
+        for first, part in segments:
+            if isinstance(part, FaceSet):
+                fr[first:first + len(part)] = part.global_frames12()
+            else:
+                for i, s in enumerate(part, first):
+                    fr[i] = N.asarray(s._temp_frame, dtype=float)[:3].ravel()
         return fr
 
 
@@ -137,6 +180,7 @@ class TableScene(object):
         self.carries = False
         self.materials = []
         self.capture = [False] * n
+        self.optics, self.capturing_optics = [], []
         for i in range(n):
             fill_desc(self.descs[i], N.asarray(frames[i]), int(gm_kind[i]), list(gm[i]), int(optics_kind[i]), list(opt[i]),
                       flags=0 if flags is None else int(flags[i]), extra_off=int(extra_off[i]), extra_len=int(extra_len[i]))
@@ -265,7 +309,7 @@ class DeviceScene(object):
 
     def compiled_has_scattering(self):
         if self._has_scattering is None:
-            self._has_scattering = any(d.optics_kind == _cabi.OPT_REFRACTIVE_SCATTERING for d in self.compiled.descs)
+            self._has_scattering = bool((N.frombuffer(self.compiled.descs, dtype=_DESC_DTYPE)['ints'][:, 1] == _cabi.OPT_REFRACTIVE_SCATTERING).any())
         return self._has_scattering
 
     def hits_reserved(self):

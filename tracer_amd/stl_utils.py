@@ -15,6 +15,7 @@ from .object import AssembledObject
 from .boundary_shape import BoundaryBox
 from .spatial_geometry import roty, rotz
 from .vector_manipulations import AABB
+from .face_set import FaceSet, LazyBounds
 
 
 def load_stl(stl_file):
@@ -72,9 +73,41 @@ def stl_to_tracer_geom(triangles, option='polygon'):
     return geoms, locs, rots
 
 
-def make_stl_tracer_object(triangles, optics, optics_args, option='polygon'):
-    """AssembledObject of one Surface per triangle, each with optics(**optics_args) and the triangle's bounding box."""
+def stl_triangle_frames(triangles):
+    """
+    The frames stl_to_tracer_geom(option='triangle') gives the faces, for all of them at once: (origins (n, 3), rotations (n, 3, 3),
+    local edges (n, 2, 3)).  A face's rotation is rotz(azimuth) roty(polar) of its normal (:193-210); its edges B - A and C - A taken
+    into that frame have no z component.
+    """
     triangles = N.asarray(triangles, dtype=float)
+    A, B, C = triangles[:, 0], triangles[:, 1], triangles[:, 2]
+    normal = N.cross(B - A, C - B)
+    length = N.sqrt(N.sum(normal ** 2, axis=1))
+    ok = length > 0.
+    normal = N.where(ok[:, None], normal / N.where(ok, length, 1.)[:, None], N.array([1., 0., 0.]))
+    azimuth, polar = N.arctan2(normal[:, 1], normal[:, 0]), N.arccos(N.clip(normal[:, 2], -1., 1.))
+    ca, sa, cp, sp = N.cos(azimuth), N.sin(azimuth), N.cos(polar), N.sin(polar)
+    z, o = N.zeros_like(ca), N.ones_like(ca)
+    Rz = N.array([[ca, -sa, z], [sa, ca, z], [z, z, o]]).transpose(2, 0, 1)
+    Ry = N.array([[cp, z, sp], [z, o, z], [-sp, z, cp]]).transpose(2, 0, 1)
+    rots = N.einsum('fij,fjk->fik', Rz, Ry)
+    # to_local = roty(-polar) rotz(-azimuth), as the reference multiplies it (not the transpose of the product above to the last bit)
+    Rzm = N.array([[ca, sa, z], [-sa, ca, z], [z, z, o]]).transpose(2, 0, 1)
+    Rym = N.array([[cp, z, -sp], [z, o, z], [sp, z, cp]]).transpose(2, 0, 1)
+    to_local = N.einsum('fij,fjk->fik', Rym, Rzm)
+    edges = N.stack((N.einsum('fij,fj->fi', to_local, B - A), N.einsum('fij,fj->fi', to_local, C - A)), axis=1)
+    edges[:, :, 2] = 0.
+    return A.copy(), rots, edges
+
+
+def make_stl_tracer_object(triangles, optics, optics_args, option='polygon'):
+    """AssembledObject of one Surface per triangle, each with optics(**optics_args) and the triangle's bounding box.
+    option='triangle': the faces are kept as arrays (face_set.FaceSet), frames, optics instances and boxes made per face on demand."""
+    triangles = N.asarray(triangles, dtype=float)
+    if option == 'triangle':
+        origins, rots, edges = stl_triangle_frames(triangles)
+        faces = FaceSet(origins, rots, edges, optics_factory=lambda: optics(**optics_args))
+        return AssembledObject(surfs=faces, bounds=LazyBounds(triangles.min(axis=1), triangles.max(axis=1)))
     geoms, locs, rots = stl_to_tracer_geom(triangles, option=option)
     surfs = [Surface(geometry=g, optics=optics(**optics_args), location=l, rotation=r) for g, l, r in zip(geoms, locs, rots)]
     bounds = [BoundaryBox(AABB(t.T)) for t in triangles]

@@ -281,7 +281,7 @@ class TracerEngine(object):
             need = int(hit_capacity) if hit_capacity is not None else 2 * n + 1024
             if hit_capacity is None and dev.capture_rate is not None:
                 need = min(need, int(4. * dev.capture_rate * n) + 65536)
-            accs = [a for sf, cap in zip(dev.compiled.surfaces, dev.compiled.capture) if cap for a in sf.get_optics_manager().accountants]
+            accs = [a for opt in dev.compiled.capturing_optics for a in opt.accountants]
             pend = dev.pending_hits
             keep = bool(feed and hit_capacity is None and pend is not None and pend.wanted() and accs and all(pend.holds_mark(a) for a in accs))
             used = 0
@@ -319,7 +319,7 @@ class TracerEngine(object):
         stats, last = dev.trace_fast(bundle, reps, min_energy, seed, accel=accel, keep_last=True, stream=stream, last_capacity=cap)
         wall = time.time() - t0
         self._set_stats(stats, wall, 'fast')
-        self.stats['form'] = 'megakernel' if (stream is False or (stream is None and n < (1 << 20))) else 'stream'
+        self.stats['form'] = 'stream' if stats.launches > 1 else 'megakernel'
         if tuned and stats.kernel_ms > 0:
             dev.form_rate[self.stats['form']] = stats.segments / stats.kernel_ms
         if stats.hits_dropped:
@@ -364,8 +364,7 @@ class TracerEngine(object):
             if tree is True or lv == nlev - 1:
                 self.tree.append(LazyLevelBundle(levels, lv, names))
         surfaces = dev.compiled.surfaces
-        accs = [a for sf in surfaces if isinstance(sf.get_optics_manager(), OpticsCallable) for a in sf.get_optics_manager().accountants] \
-            if surfaces is not None else []
+        accs = [a for opt in dev.compiled.optics if isinstance(opt, OpticsCallable) for a in opt.accountants] if surfaces is not None else []
         if nlev > 1 and (accs or self._transfer):
             pend = PendingLevels(self, surfaces, levels, bundle, dev.n_surf, self._transfer)
             for a in accs:
