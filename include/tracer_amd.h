@@ -110,11 +110,12 @@ typedef enum trc_optics_kind {
                                            (Absorbant.attenuate :874-889 with k = Im m, optics.py:205-212).  Rays carry a complex index
                                            (trc_rays.ref_index_im), a wavelength, and the materials' indices at it (trc_rays.mat).
                                            opt: single_ray, sigma(<0:none), attenuate(0|1), scaling, k0, k1 (rows of trc_rays.mat of
-                                           material_1, material_2).  Ordered engine and per-surface protocol. */
+                                           material_1, material_2).  Ordered engine, per-surface protocol and (one ray per hit) the
+                                           streaming form of the fast engine. */
     TRC_OPT_LAMBERTIAN_POLYCHROMATIC = 15, /* Lambertian_directional_axisymmetric_piecewise_Polychromatic :393-425: every ray carries a
                                            spectrum (trc_rays.spectra over trc_rays.spec_wl); each sample is scaled by 1 - absorptance(theta_in,
                                            lambda_w), the ray energy is the trapezoid integral of the result.  extra as
-                                           LAMBERTIAN_DIRECTIONAL_SPECTRAL.  Ordered engine and protocol. */
+                                           LAMBERTIAN_DIRECTIONAL_SPECTRAL.  Ordered engine, protocol, streaming form of the fast engine. */
     TRC_OPT_PERIODIC_BOUNDARY = 16,     /* PeriodicBoundary :690-723: the ray stops on the surface (a stub of energy 0 keeps the tree
                                            connected: block 0) and goes on, unchanged, from the hit point moved by `period` along
                                            the oriented normal (block 1).  opt: period.  The fast engines follow the moved ray;
@@ -355,6 +356,9 @@ int trc_kdtree_traversal(trc_ctx *ctx, const trc_kdtree_desc *kd, int32_t n_surf
  * stream id ray_offset+i.  Tallies/flux maps/hit buffer accumulate on the scene.
  * If TRC_TRACE_KEEP_LAST, rays still alive after `reps` bounces are written to `last`
  * (capacity last->n on entry, count on exit).
+ * A given bundle may carry what Refractive / RefractiveAbsorbant and the polychromatic wall read (ref_index_im, mat, spec_wl +
+ * spectra): such calls, and calls on scenes with those optics, run the streaming form (64 rays or more; TRC_ERR_UNSUPPORTED with
+ * TRC_TRACE_MEGAKERNEL or fewer rays: use trc_trace_ordered).  Spectra are not captured per hit and not returned in `last`.
  */
 int trc_trace_fast(trc_scene *scene, const trc_rays *in, const trc_source_desc *src, int64_t n,
                    int32_t reps, double min_energy, uint64_t seed, uint64_t ray_offset,

@@ -127,9 +127,15 @@ def test_engines_refuse_what_they_do_not_carry(ctx):
     asm, air, glass = _slab_scene(True)
     b, wl = _bundle(100, air)
     eng = TracerEngine(asm)
-    with pytest.raises(TracerAmdError) as err:
-        eng.ray_tracer(b, reps=3, min_energy=1e-9, tree=False, engine='fast')
+    with pytest.raises(TracerAmdError) as err:          # the single persistent kernel of the fast engine carries neither
+        eng.ray_tracer(b, reps=3, min_energy=1e-9, tree=False, engine='fast', fast_kernel='megakernel')
     assert 'trc_trace_ordered' in str(err.value)
+    few = _bundle(40, air)[0]
+    with pytest.raises(TracerAmdError) as err:          # ... and the streaming form starts at 64 rays
+        eng.ray_tracer(few, reps=3, min_energy=1e-9, tree=False, engine='fast')
+    assert 'trc_trace_ordered' in str(err.value)
+    eng.ray_tracer(few, reps=3, min_energy=1e-9, tree=False)
+    assert eng.stats['engine'] == 'ordered'
     from tracer_amd.ray_bundle import RayBundle
     plain = RayBundle(vertices=b.get_vertices(), directions=b.get_directions(), energy=b.get_energy(), ref_index=N.ones(100))
     with pytest.raises(ValueError):                      # no wavelengths: the materials cannot be evaluated
@@ -206,6 +212,94 @@ def test_polychromatic_bundle_through_a_cavity(ctx):
     P1 = eng2.tree[1]
     assert N.array_equal(P1.get_parents(), B1.get_parents())
     assert N.allclose(P1.get_spectra(), B1.get_spectra(), rtol=1e-12) and N.allclose(P1.get_energy(), B1.get_energy(), rtol=1e-12)
+
+
+def test_carried_indices_and_materials_on_the_fast_path(ctx):
+    """
+    VERDICT r2 item 7: complex indices and tabulated materials in the streaming engine (k_s_shade_x; Refractive / RefractiveAbsorbant,
+    optics_callables.py:726-858, :908-944).  The glass slab of the test above with one ray per hit, tree=False: ray_tracer picks the
+    fast engine by itself; per surface, hits and segments equal the oracle's on the same Philox streams, absorbed and incident
+    energy to 1e-9; the ordered engine's accountants of the floor collect the same hits (as sets: the fast engine delivers them in
+    the order they were made).  Room for every list forced small, the call is reported, not wrong.
+    """
+    from tracer_amd.tracer_engine import TracerEngine
+    from tracer_amd.scene import compile_scene
+    from oracle import engine as oracle_engine
+    n = 60000
+    for absorb in (True, False):
+        asm, air, glass = _slab_scene(True, absorb=absorb)
+        b, wl = _bundle(n, air, seed=11, tilt=0.8)
+        eng = TracerEngine(asm)
+        eng.ray_tracer(b, reps=7, min_energy=1e-9, tree=False, seed=21)
+        assert eng.stats['engine'] == 'fast' and eng.stats['form'] == 'stream'
+        a, r, h = [x.copy() for x in eng.get_tallies()]
+        cs = compile_scene(asm)
+        with N.errstate(all='ignore'):
+            o = oracle_engine.trace_bundle(cs, b.get_vertices(), b.get_directions(), b.get_energy(), 7, 1e-9, 21,
+                                           ref_index=b.get_ref_index(), wavelengths=wl)
+        assert N.array_equal(h, o['hits']) and eng.stats['segments'] == o['segments']
+        assert N.allclose(a, o['absorbed'], rtol=1e-9, atol=1e-15) and N.allclose(r, o['received'], rtol=1e-9, atol=1e-15)
+        assert h[2] > 0.5 * n and (a[0] + a[1] > 0) == absorb        # the slab itself takes energy only when it attenuates
+        e_fast, p_fast = asm.get_surfaces()[2].get_optics_manager().get_all_hits()
+        # the ordered engine on the same bundle: the floor's accountant holds the same hits
+        asm2, _, _ = _slab_scene(True, absorb=absorb)
+        eng2 = TracerEngine(asm2)
+        eng2.ray_tracer(_bundle(n, air, seed=11, tilt=0.8)[0], reps=7, min_energy=1e-9, tree=False, seed=21, engine='ordered')
+        e_ord, p_ord = asm2.get_surfaces()[2].get_optics_manager().get_all_hits()
+        assert len(e_fast) == len(e_ord) == h[2]
+        k_f, k_o = N.lexsort((p_fast[1], p_fast[0])), N.lexsort((p_ord[1], p_ord[0]))
+        assert N.allclose(p_fast[:, k_f], p_ord[:, k_o], rtol=1e-12, atol=1e-12) and N.allclose(e_fast[k_f], e_ord[k_o], rtol=1e-9, atol=1e-18)
+        a2, r2, h2 = eng2.get_tallies()
+        assert N.array_equal(h2, h) and N.allclose(a2, a, rtol=1e-9, atol=1e-15)
+
+
+def test_polychromatic_bundle_on_the_fast_path(ctx):
+    """
+    VERDICT r2 item 7: spectra in the streaming engine -- one value per sample and slot beside the ray table, scaled per sample at
+    the polychromatic wall (optics_callables.py:393-425), as a whole elsewhere.  The cavity of the test above with the wall's
+    spectral accountant taken off (the fast engine captures no spectra per hit): tree=False goes to the fast engine; per surface,
+    hits, segments and energies equal the oracle's and the ordered engine's.
+    """
+    from tracer_amd.tracer_engine import TracerEngine
+    from tracer_amd.scene import compile_scene
+    from tracer_amd.ray_bundle import RayBundle
+    from tracer_amd import optics_callables as opt
+    from oracle import engine as oracle_engine
+
+    def scene():
+        asm, _ = _poly_scene()
+        wall = asm.get_surfaces()[0].get_optics_manager()
+        wall.accountants = [a for a in wall.accountants if not isinstance(a, opt.PolychromaticAccountant)]
+        return asm
+
+    n, W = 50000, 9
+    rng = N.random.RandomState(8)
+    v = N.vstack((rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), N.full(n, 1.)))
+    d = N.vstack((rng.uniform(-0.4, 0.4, n), rng.uniform(-0.4, 0.4, n), -N.ones(n)))
+    d /= N.sqrt(N.sum(d ** 2, axis=0))
+    swl = N.sort(rng.uniform(0.3e-6, 2.5e-6, size=(W, n)), axis=0)
+    spec = rng.uniform(0.5, 2., size=(W, n)) * 1e6
+    e = N.trapezoid(spec, swl, axis=0)
+    mk = lambda: RayBundle(vertices=v, directions=d, energy=e, spectra=spec.copy(), wavelengths=swl)
+    asm = scene()
+    eng = TracerEngine(asm)
+    eng.ray_tracer(mk(), reps=6, min_energy=1e-9, tree=False, seed=33)
+    assert eng.stats['engine'] == 'fast' and eng.stats['form'] == 'stream'
+    a, r, h = [x.copy() for x in eng.get_tallies()]
+    cs = compile_scene(asm)
+    with N.errstate(all='ignore'):
+        o = oracle_engine.trace_bundle(cs, v, d, e, 6, 1e-9, 33, wavelengths=swl, spectra=spec)
+    assert N.array_equal(h, o['hits']) and eng.stats['segments'] == o['segments']
+    assert N.allclose(a, o['absorbed'], rtol=1e-9, atol=1e-12) and N.allclose(r, o['received'], rtol=1e-9, atol=1e-12)
+    assert h[0] > n and h[1] > 0.2 * n and h[2] > 0          # rays come back to the wall with the spectrum they left it with
+    eng2 = TracerEngine(scene())
+    eng2.ray_tracer(mk(), reps=6, min_energy=1e-9, tree=False, seed=33, engine='ordered')
+    a2, r2, h2 = eng2.get_tallies()
+    assert N.array_equal(h2, h) and N.allclose(a2, a, rtol=1e-9, atol=1e-12)
+    # with the spectral accountant in place the call stays with the ordered engine
+    eng3 = TracerEngine(_poly_scene()[0])
+    eng3.ray_tracer(mk(), reps=2, min_energy=1e-9, tree=False, seed=33)
+    assert eng3.stats['engine'] == 'ordered'
 
 
 def test_polychromatic_wall_without_spectra_is_an_error(ctx):

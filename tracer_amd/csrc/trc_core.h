@@ -1584,7 +1584,7 @@ TRC_HD int trc_shade_x(int opt_kind, const double *opt, const double *extra, int
     *poly_th = -1.0;
     out_im[0] = out_im[1] = X.ref_im;
     if (opt_kind == TRC_OPT_REFRACTIVE_MATERIAL) {
-        out[0].blk = 0; out[1].blk = 1; out[0].back = out[1].back = 0.0; out[0].sf = out[1].sf = 1.0;
+        out[0].blk = 0; out[1].blk = 1; out[0].back = out[1].back = 0.0; out[0].sf = out[1].sf = 1.0; out[0].shift = out[1].shift = 0.0;
         const int k0 = (int)opt[4], k1 = (int)opt[5];
         trc_cplx m0 = trc_c(NAN, NAN), m1 = m0;
         if (X.mat && k0 < X.n_mat && k1 < X.n_mat) {
@@ -1594,7 +1594,7 @@ TRC_HD int trc_shade_x(int opt_kind, const double *opt, const double *extra, int
         return trc_shade_material(opt, m0, m1, dx, dy, dz, e, ref, X.ref_im, wl, path, nx, ny, nz, seed, rid, event, out, out_im);
     }
     if (opt_kind == TRC_OPT_LAMBERTIAN_POLYCHROMATIC) {         // :406-425
-        out[0].blk = 0; out[1].blk = 1; out[0].back = out[1].back = 0.0; out[0].sf = out[1].sf = 1.0;
+        out[0].blk = 0; out[1].blk = 1; out[0].back = out[1].back = 0.0; out[0].sf = out[1].sf = 1.0; out[0].shift = out[1].shift = 0.0;
         out[0].ref = ref;
         const double dn = dx * nx + dy * ny + dz * nz;
         const double wx = dn * nx, wy = dn * ny, wz = dn * nz;

@@ -288,6 +288,10 @@ struct FastParams {
     // given bundle (NULL when a source descriptor is used)
     const double *x, *y, *z, *dx, *dy, *dz, *e, *ref, *wl;
     const uint64_t *rid;
+    // what the rays of a given bundle carry beyond that (streaming form only, k_s_shade_x): Im of the refractive index (n), the
+    // materials at each ray's wavelength (2 n_mat x n), sample wavelengths and spectra of polychromatic bundles (n_spec x n)
+    const double *ref_im, *mat, *spec_wl, *spec;
+    int n_mat, n_spec;
     const trc_source_desc *src;  // device copy
     long long n;
     int reps;
@@ -403,6 +407,9 @@ struct StreamWs {
                         // it is expected to keep alive -- room for every ray of the batch behind pre-assigned chunks for every ray
     SRayGeo *geo;
     SRayAux *aux;
+    double *spec;       // polychromatic bundles: sample w of the spectrum of the ray in slot s at spec[w * room + s]
+    long long spec_len; // doubles allocated there;  spec_on: this call's rays carry spectra (P.n_spec samples)
+    int spec_on, spec_pad;
     uint32_t *q1_slot;
     float4 *q1_a, *q1_b;   // (ox, oy, oz, ix), (iy, iz, tmin, tmax)
     uint32_t *q3_slot, *q3_surf;
@@ -520,6 +527,7 @@ static inline int trc_shade_class_of(const trc_surface_desc &sd) {
 }
 
 // the lean shading kernels (trc_shade.hip): kernel of a class for a scene of flat surfaces only (flat) with its tables in LDS (lds)
+const void *trc_shade_carry_kernel(bool lds);      // k_s_shade_x (trc_shade.hip): every optics kind, with what the rays carry
 const void *trc_shade_lean_kernel(int cls, bool flat, bool lds);
 #ifndef SHC_THREADS
 #define SHC_THREADS 1024

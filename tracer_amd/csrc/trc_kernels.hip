@@ -1477,7 +1477,7 @@ extern "C" int trc_scene_create(trc_ctx *ctx, int32_t n_surf, const trc_surface_
     sc->d_last_cap = 0;
     memset(sc->cnt_host, 0, sizeof(sc->cnt_host));
     sc->n_surf = n_surf;
-    sc->stride = (TRC_REC_HDR + max_np + 1) & ~1;      // even: a record starts on 16 bytes (k_s_bounce reads a triangle's whole record in 16-byte pieces)
+    sc->stride = TRC_REC_HDR + max_np;
     if ((sc->stride & 1) == 0) sc->stride += 1;  // odd number of doubles: spreads records over LDS banks
     sc->n_extra = n_extra;
     sc->surfs.assign(surfs, surfs + n_surf);
@@ -2207,8 +2207,26 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
     if ((in == nullptr) == (src == nullptr)) return trc_fail(TRC_ERR_INVALID, "exactly one of `in` and `src` must be given");
     if (n < 0 || reps < 0) return trc_fail(TRC_ERR_INVALID, "n and reps must be >= 0");
     if (sc->splits) return trc_fail(TRC_ERR_UNSUPPORTED, "the scene has ray-splitting optics: use trc_trace_ordered");
-    if (sc->carries || (in && (in->ref_index_im || in->spectra || in->mat)))
-        return trc_fail(TRC_ERR_UNSUPPORTED, "complex refractive indices and spectra travel with the rays of trc_trace_ordered only");
+    // Rays that carry the imaginary part of a complex index, materials evaluated at their wavelength or a sampled spectrum are
+    // traced by the streaming form (k_s_shade_x); the megakernel knows nothing of them.
+    const bool carry = sc->carries || (in && (in->ref_index_im || in->spectra || in->mat));
+    const int carry_W = (in && in->spectra && in->spec_wl) ? in->n_spec : 0;
+    const int carry_mat = (in && in->mat) ? (int)in->n_mat : 0;
+    if (carry) {
+        if (!in) return trc_fail(TRC_ERR_UNSUPPORTED, "the scene has optics that read what only the rays of a given bundle carry (materials, spectra)");
+        if (carry_W < 0 || carry_W > 4096 || carry_mat < 0 || carry_mat > 64) return trc_fail(TRC_ERR_INVALID, "trc_trace_fast: n_spec or n_mat out of range");
+        int max_mat = -1;
+        bool poly = false;
+        for (const trc_surface_desc &sd : sc->surfs) {
+            if (sd.optics_kind == TRC_OPT_REFRACTIVE_MATERIAL) max_mat = std::max(max_mat, std::max((int)sd.opt[4], (int)sd.opt[5]));
+            if (sd.optics_kind == TRC_OPT_LAMBERTIAN_POLYCHROMATIC) poly = true;
+        }
+        if (max_mat >= 0 && (!in->wavelength || carry_mat <= max_mat))
+            return trc_fail(TRC_ERR_INVALID, "trc_trace_fast: surfaces between materials need the rays' wavelengths and the materials evaluated at them (trc_rays.mat)");
+        if (poly && carry_W < 2) return trc_fail(TRC_ERR_INVALID, "trc_trace_fast: a polychromatic wall needs rays with spectra of at least two samples");
+        if ((flags & TRC_TRACE_MEGAKERNEL) || n < 64)
+            return trc_fail(TRC_ERR_UNSUPPORTED, "complex refractive indices and spectra travel with the streaming form of the fast engine (64 rays or more) and with trc_trace_ordered");
+    }
     // TRC_TRACE_ACCEL without a Kd-tree: the streaming form searches its own grid; the megakernel tests every box
     trc_ctx *ctx = sc->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -2224,8 +2242,27 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
     double stream_seg = 0, stream_hits = 0;
     bool stream_counts_known = false;
     const int S = sc->n_surf;
+    double *carry_d[4] = {nullptr, nullptr, nullptr, nullptr};      // Im of the index, materials, sample wavelengths, spectra
+    bool carry_owned[4] = {false, false, false, false};
     do {
-        if (in) { if ((st = check_rays(in, n, "trc_trace_fast")) || (st = stage_rays(in, n, true, &dr))) break; }
+        if (in) {
+            if ((st = check_rays(in, n, "trc_trace_fast")) || (st = stage_rays(in, n, true, &dr))) break;
+            if (carry) {        // the carried columns: rows of the bundle's own length in->n apart on the host, n apart here
+                struct { const double *src; int rows; double **dst; } blk[4] = {{in->ref_index_im, 1, &carry_d[0]}, {in->mat, 2 * carry_mat, &carry_d[1]},
+                                                                                 {carry_W ? in->spec_wl : nullptr, carry_W, &carry_d[2]},
+                                                                                 {carry_W ? in->spectra : nullptr, carry_W, &carry_d[3]}};
+                for (int b = 0; b < 4 && st == TRC_OK; ++b) {
+                    if (!blk[b].src || blk[b].rows <= 0) continue;
+                    if (in->on_device && in->n == n) { *blk[b].dst = (double *)blk[b].src; continue; }
+                    if ((st = dev_alloc(blk[b].dst, (size_t)blk[b].rows * (size_t)n))) break;
+                    carry_owned[b] = true;
+                    if (hipMemcpy2D(*blk[b].dst, (size_t)n * 8, blk[b].src, (size_t)in->n * 8, (size_t)n * 8, (size_t)blk[b].rows,
+                                    in->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) != hipSuccess)
+                        st = trc_fail(TRC_ERR_DEVICE, "upload of the carried columns failed");
+                }
+                if (st) break;
+            }
+        }
         else {
             // the scene keeps a device buffer for the descriptor of the call in progress (hipMalloc / hipFree per call
             // cost more than the upload)
@@ -2276,6 +2313,7 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         P.sc = make_dscene(sc);
         P.x = dr.x; P.y = dr.y; P.z = dr.z; P.dx = dr.dx; P.dy = dr.dy; P.dz = dr.dz; P.e = dr.e;
         P.ref = dr.ref; P.wl = dr.wl; P.rid = dr.rid;
+        P.ref_im = carry_d[0]; P.mat = carry_d[1]; P.spec_wl = carry_d[2]; P.spec = carry_d[3]; P.n_mat = carry_mat; P.n_spec = carry_W;
         P.src = d_src;
         P.n = n; P.reps = reps; P.flags = flags; P.min_energy = min_energy; P.seed = seed; P.ray_offset = ray_offset;
         P.lx = d_last[0]; P.ly = d_last[1]; P.lz = d_last[2]; P.ldx = d_last[3]; P.ldy = d_last[4]; P.ldz = d_last[5]; P.le = d_last[6];
@@ -2329,12 +2367,13 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         int stream_mode = 0;
         size_t stream_lds = 0;
         const bool stream_ok = !mode_env && n >= 64 && stream_plan(sc, want_accel, &stream_mode, &stream_lds);
-        const bool force_stream = (flags & TRC_TRACE_STREAM) || stream_env == 1;
-        const bool force_mega = (flags & TRC_TRACE_MEGAKERNEL) || stream_env == 0;
+        const bool force_stream = (flags & TRC_TRACE_STREAM) || stream_env == 1 || carry;
+        const bool force_mega = !carry && ((flags & TRC_TRACE_MEGAKERNEL) || stream_env == 0);
         // (a scene on the large grid -- a mesh of 1e5 faces -- has nothing but its boxes to search in the megakernel: 2e5 rays on the
         // relief of 105 800 triangles took 570 ms there, 1.3 ms here)
         const long long stream_from = stream_mode == 3 ? 4096 : TRC_STREAM_MIN_RAYS;
         const bool use_stream = stream_ok && (force_stream || (!force_mega && n >= stream_from));
+        if (carry && !use_stream) { st = trc_fail(TRC_ERR_UNSUPPORTED, "no streaming form for this scene: rays that carry complex indices or spectra go through trc_trace_ordered"); break; }
         if (use_stream) {
             if (!sc->stream_eng) {
                 sc->stream_eng = new (std::nothrow) StreamEngine();
@@ -2428,6 +2467,7 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         }
     } while (0);
     dr.release();
+    for (int b = 0; b < 4; ++b) if (carry_owned[b]) pool_free(carry_d[b]);
     if (stats) *stats = s;
     return st;
 }

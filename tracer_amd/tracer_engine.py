@@ -28,7 +28,7 @@ from . import rng
 from .accel_tree import KdTree
 from .ray_bundle import RayBundle, concatenate_rays
 from .scene import compile_scene, DeviceScene, NotNativeError, feed_accountants, PendingHits
-from .optics_callables import OpticsCallable
+from .optics_callables import OpticsCallable, PolychromaticAccountant
 from .trace_tree import RayTree
 from .ordered_levels import OrderedLevels, LazyLevelBundle, PendingLevels, level_columns
 
@@ -216,8 +216,14 @@ class TracerEngine(object):
             return self._trace_protocol(bundle, reps, min_energy, tree)
 
         if engine == 'auto':
-            # complex refractive indices and spectra travel with the rays of the ordered engine only
+            # Complex refractive indices, materials evaluated at the rays' wavelengths and spectra travel with the rays of the
+            # ordered engine and of the streaming form of the fast engine (64 rays or more of a given bundle; k_s_shade_x).  The
+            # fast engine captures no spectra per hit: a scene whose accountants collect them (PolychromaticAccountant) stays
+            # with the ordered engine.
             carries = dev.compiled.carries or (not _pending(bundle) and (bundle.is_polychromatic() or bundle.has_complex_index()))
+            if carries:
+                spectral = any(isinstance(a, PolychromaticAccountant) for o in dev.compiled.capturing_optics for a in o.accountants)
+                carries = _pending(bundle) or bundle.get_num_rays() < 64 or spectral
             engine = 'ordered' if (tree or dev.compiled.splits or carries) else 'fast'
         if accel and Kd_Tree is None and (engine == 'fast' or (engine == 'ordered' and dev.n_surf <= 65535 and
                                                                 bundle.get_num_rays() * dev.n_surf <= self.KD_WORTH_IT)):
