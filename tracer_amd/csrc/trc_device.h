@@ -283,15 +283,21 @@ __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, 
 // ================================================================================================
 // fast engine
 // ================================================================================================
+// what the rays of a given bundle carry beyond the fast engine's record (streaming form only, k_s_shade_x): Im of the refractive
+// index (n), the materials at each ray's wavelength (2 n_mat x n), sample wavelengths and spectra of polychromatic bundles
+// (n_spec x n).  Kept out of FastParams and at the end of StreamParams: the kernels of the other scenes never read it, and six
+// more words in the middle of their arguments cost the NSTTF bench 4 % (scalar loads regrouped).
+struct CarryIn {
+    const double *ref_im, *mat, *spec_wl, *spec;
+    int n_mat, n_spec;
+    double *slot_spec;      // the slot's table of spectra under way: sample w of the ray in slot s at slot_spec[w * room + s] (null: none)
+};
+
 struct FastParams {
     DScene sc;
     // given bundle (NULL when a source descriptor is used)
     const double *x, *y, *z, *dx, *dy, *dz, *e, *ref, *wl;
     const uint64_t *rid;
-    // what the rays of a given bundle carry beyond that (streaming form only, k_s_shade_x): Im of the refractive index (n), the
-    // materials at each ray's wavelength (2 n_mat x n), sample wavelengths and spectra of polychromatic bundles (n_spec x n)
-    const double *ref_im, *mat, *spec_wl, *spec;
-    int n_mat, n_spec;
     const trc_source_desc *src;  // device copy
     long long n;
     int reps;
@@ -407,9 +413,6 @@ struct StreamWs {
                         // it is expected to keep alive -- room for every ray of the batch behind pre-assigned chunks for every ray
     SRayGeo *geo;
     SRayAux *aux;
-    double *spec;       // polychromatic bundles: sample w of the spectrum of the ray in slot s at spec[w * room + s]
-    long long spec_len; // doubles allocated there;  spec_on: this call's rays carry spectra (P.n_spec samples)
-    int spec_on, spec_pad;
     uint32_t *q1_slot;
     float4 *q1_a, *q1_b;   // (ox, oy, oz, ix), (iy, iz, tmin, tmax)
     uint32_t *q3_slot, *q3_surf;
@@ -493,6 +496,7 @@ struct StreamParams {
     // k_s_partition: per class, entries pre-assigned to every wave (0: the waves reserve as they go) and where those chunks start
     unsigned part_chunk[3];
     int part_static[3];
+    CarryIn carry;      // (last: see CarryIn)
 };
 
 // optics classes of the shading stage.  MIRROR and DIFFUSE are served by lean kernels (trc_shade.hip: <= 128 registers, four

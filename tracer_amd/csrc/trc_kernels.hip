@@ -2313,7 +2313,8 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         P.sc = make_dscene(sc);
         P.x = dr.x; P.y = dr.y; P.z = dr.z; P.dx = dr.dx; P.dy = dr.dy; P.dz = dr.dz; P.e = dr.e;
         P.ref = dr.ref; P.wl = dr.wl; P.rid = dr.rid;
-        P.ref_im = carry_d[0]; P.mat = carry_d[1]; P.spec_wl = carry_d[2]; P.spec = carry_d[3]; P.n_mat = carry_mat; P.n_spec = carry_W;
+        CarryIn carry_in;
+        carry_in.ref_im = carry_d[0]; carry_in.mat = carry_d[1]; carry_in.spec_wl = carry_d[2]; carry_in.spec = carry_d[3]; carry_in.n_mat = carry_mat; carry_in.n_spec = carry_W;
         P.src = d_src;
         P.n = n; P.reps = reps; P.flags = flags; P.min_energy = min_energy; P.seed = seed; P.ray_offset = ray_offset;
         P.lx = d_last[0]; P.ly = d_last[1]; P.lz = d_last[2]; P.ldx = d_last[3]; P.ldy = d_last[4]; P.ldz = d_last[5]; P.le = d_last[6];
@@ -2380,7 +2381,7 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
                 if (!sc->stream_eng) { st = trc_fail(TRC_ERR_NOMEM, "out of host memory"); break; }
                 memset(sc->stream_eng, 0, sizeof(StreamEngine));
             }
-            if ((st = stream_trace(sc, P, want_accel, src, *sc->stream_eng, &s, &stream_seg, &stream_hits))) {
+            if ((st = stream_trace(sc, P, carry_in, want_accel, src, *sc->stream_eng, &s, &stream_seg, &stream_hits))) {
                 // the hits captured by the bounces that completed: wind the buffer back to where the call found it
                 const std::string why = g_last_error;
                 unsigned long long now = 0;

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(SHC_THREADS) void k_s_shade_c(StreamParams S) {
 //   Im of the index       the fourth word of the ray's SRayAux, from the bundle's column for a ray not shaded yet
 //   materials, sample     do not change along a ray: read from the bundle's columns by the ray's number (SRayGeo.idx)
 //   wavelengths
-//   spectrum              one value per sample and slot in W.spec (sample-major, `room` apart); from the bundle's column at the
+//   spectrum              one value per sample and slot in CarryIn.slot_spec (sample-major, `room` apart); from the bundle's column at the
 //                         first interaction.  Scaled per sample by 1 - absorptance(theta, lambda_w) at a polychromatic wall, as a
 //                         whole by the optics' factor elsewhere -- what k_ord_bounce does for the ordered engine.
 // Given bundles only (a source descriptor makes rays of energy, index 1 and no wavelength).
@@ -339,7 +339,8 @@ __global__ __launch_bounds__(SHC_THREADS) void k_s_shade_x(StreamParams S) {
     unsigned n_hit = 0, n_alive = 0;
     const int bounce0 = S.bounce_no;
     const bool aux_in = !P.src || bounce0 > 0;
-    const int nW = W.spec_on ? P.n_spec : 0;
+    const CarryIn &C = S.carry;
+    const int nW = C.slot_spec ? C.n_spec : 0;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += stride) {
         uint32_t slot = SQ_INVALID, hs = SQ_INVALID;
@@ -375,19 +376,19 @@ __global__ __launch_bounds__(SHC_THREADS) void k_s_shade_x(StreamParams S) {
             const long long ray = S.base + (long long)g.idx;            // the ray's place in the bundle's columns
             double e = src_energy, ref = 1.0, wl = 0.0, ref_im = 0.0;
             if (aux_in) { const SRayAux a = W.aux[slot]; e = a.e; ref = a.ref; wl = a.wl; ref_im = a.pad; }
-            if (first) ref_im = P.ref_im ? P.ref_im[ray] : 0.0;
+            if (first) ref_im = C.ref_im ? C.ref_im[ray] : 0.0;
             const double *rec = L.recs + (size_t)s * sc.stride;
             double hx = g.px + t * g.dx, hy = g.py + t * g.dy, hz = g.pz + t * g.dz;
             double nx, ny, nz;
             trc_normal(rec, hx, hy, hz, g.dx, g.dy, g.dz, &nx, &ny, &nz);
             const double path = sqrt((hx - g.px) * (hx - g.px) + (hy - g.py) * (hy - g.py) + (hz - g.pz) * (hz - g.pz));
             trc_ray_ext X;
-            X.ref_im = ref_im; X.W = nW; X.n_mat = P.mat ? P.n_mat : 0; X.stride = P.n;
-            X.mat = P.mat ? P.mat + ray : nullptr;
-            X.wl = nW ? P.spec_wl + ray : nullptr;
-            X.spec = nW ? P.spec + ray : nullptr;
+            X.ref_im = ref_im; X.W = nW; X.n_mat = C.mat ? C.n_mat : 0; X.stride = P.n;
+            X.mat = C.mat ? C.mat + ray : nullptr;
+            X.wl = nW ? C.spec_wl + ray : nullptr;
+            X.spec = nW ? C.spec + ray : nullptr;
             long long spec_stride = P.n;                                 // ... of the spectrum as it reaches this hit
-            if (nW && !first) { X.spec = W.spec + slot; spec_stride = W.room; }
+            if (nW && !first) { X.spec = C.slot_spec + slot; spec_stride = W.room; }
             trc_ray_out out[2];
             double out_im[2], poly_th;
             const unsigned long long rid = P.rid ? P.rid[ray] : (P.ray_offset + (unsigned long long)ray);
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(SHC_THREADS) void k_s_shade_x(StreamParams S) {
                         const double *tab = L.extra + trc_rec_extra_off(rec);
                         for (int w = 0; w < nW; ++w) {
                             const double f = poly_th >= 0.0 ? 1.0 - trc_poly_absorptance(tab, poly_th, X.wl[(long long)w * P.n]) : out[0].sf;
-                            W.spec[(long long)w * W.room + slot] = X.spec[(long long)w * spec_stride] * f;
+                            C.slot_spec[(long long)w * W.room + slot] = X.spec[(long long)w * spec_stride] * f;
                         }
                     }
                 }
