@@ -159,6 +159,24 @@ def other_configs(ctx, log):
                          'roofline_frac_algorithmic': st.segments * B_SEG / (st.kernel_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
                          'absorbed_share': float(a.sum() / e.sum()), 'launches': int(st.launches)}
     log('configs[4]: %.1f ms of kernels, %.1f G segments/s' % (st.kernel_ms, st.segments / st.kernel_ms / 1e6))
+    # a mesh of 1e5 faces (one object of arrays on the host, the large grid on the device)
+    from tracer_amd import sources
+    t0 = time.time()
+    asm, nf, (center, direction, radius, csr) = scenes.relief_mesh()
+    cs = compile_scene(asm)
+    t_build = time.time() - t0
+    dev = DeviceScene(cs, ctx)
+    nm = 10 ** 7
+    for r in range(3):
+        t0 = time.time()
+        st, _ = dev.trace_fast(sources.buie_sunshape(nm, center, direction, radius, csr, flux=1., seed=23 + r), 6, 1e-10, 23 + r, accel=True)
+        wall = time.time() - t0
+    dev.close()
+    out['mesh'] = {'workload': 'relief of %d mirror triangles (models/triangulated_surface.py) under a black lid, Buie sunshape, 1e7 rays, reps=6' % nf,
+                   'rays': nm, 'segments': int(st.segments), 'kernel_ms': st.kernel_ms, 'wall_ms': wall * 1e3,
+                   'Gsegments_per_s_kernels': st.segments / st.kernel_ms / 1e6, 'Gsegments_per_s_wall': st.segments / wall / 1e9,
+                   'build_and_compile_s': t_build, 'launches': int(st.launches)}
+    log('mesh: %.1f ms of kernels, %.2f G segments/s' % (st.kernel_ms, st.segments / st.kernel_ms / 1e6))
     return out
 
 

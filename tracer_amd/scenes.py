@@ -169,3 +169,23 @@ def dish_cavity(sigma=2e-3, scale=0.12):
                     N.concatenate(([-1], c['extra_off'])), N.concatenate(([0], c['extra_len'])))
     src = dict(center=N.c_[[0., 0., 2.9]], direction=N.r_[0., 0., -1.], radius=2.5, CSR=0.05, flux=1000.)
     return ts, src
+
+
+def relief_mesh(m=230, extent=10., amp=0.8):
+    """
+    SURVEY 8(f)4, a mesh as the reference builds it (models/triangulated_surface.py:12-52, one face per triangle) beyond what LDS holds:
+    m x m quads over [-extent, extent]^2 on a relief steep enough for second and third bounces, two mirror faces each (absorptivity
+    0.2; 105 800 triangles at m = 230), under a black lid 50 m above.  Returns (assembly, faces, source) -- source: (center (3, 1),
+    direction, radius, CSR) of a Buie sun that fills the relief.
+    """
+    from .models.triangulated_surface import TriangulatedSurface
+    x, y = N.meshgrid(N.linspace(-extent, extent, m + 1), N.linspace(-extent, extent, m + 1), indexing='ij')
+    z = amp * N.sin(1.3 * x) * N.cos(1.1 * y)
+    V = N.c_[x.ravel(), y.ravel(), z.ravel()]
+    i, j = N.meshgrid(N.arange(m), N.arange(m), indexing='ij')
+    a, b, c, d = (i * (m + 1) + j).ravel(), ((i + 1) * (m + 1) + j).ravel(), ((i + 1) * (m + 1) + j + 1).ravel(), (i * (m + 1) + j + 1).ravel()
+    F = N.vstack((N.c_[a, b, c], N.c_[a, c, d]))
+    mesh = TriangulatedSurface(V, F, opt.Reflective(0.2))
+    lid = AssembledObject(surfs=[Surface(RectPlateGM(90., 90.), opt.LambertianReceiver(1.))], transform=N.dot(translate(0., 0., 50.), rotx(N.pi)))
+    direction = N.r_[0.1, -0.05, -1.] / N.linalg.norm([0.1, -0.05, -1.])
+    return Assembly(objects=[mesh, lid]), len(F), (N.c_[-40. * direction], direction, 12., 0.05)
