@@ -366,7 +366,7 @@ static inline bool trc_tri_box_overlap(const double c[3], const double h[3], con
     return true;
 }
 
-// The grid for scenes that do not fit the one above: same construction (cells of about equal sides, six cells per
+// The grid for scenes that do not fit the one above: same construction (cells of about equal sides, three cells per
 // surface, a surface listed in every cell its box inflated by 2*delta overlaps), at most 2^24 cells and 2^28 list entries, all
 // bounded surfaces but the few set apart (big_apart), 32-bit offsets and lists.  Call after trc_accel_build_surfaces.
 static inline void trc_accel_build_grid32(const trc_surface_desc *surfs, int n_surf, trc_accel_host &A) {
@@ -429,9 +429,9 @@ static inline void trc_accel_build_grid32(const trc_surface_desc *surfs, int n_s
         lo[k] = (double)A.big_root[k];
         ext[k] = (double)A.big_root[3 + k] - lo[k];
     }
-    // cells per listed surface: 6 measured best on the relief of 105 800 triangles once a face is listed only in the cells it
-    // touches (2: 15.7 ms per 1e7 rays, 6: 14.1, 16: 14.9); TRC_GRID32_DENSITY overrides it (measurements)
-    double density = 6.0;
+    // cells per listed surface: 3 measured best on the relief of 105 800 triangles with k_s_bounce_coop (1: 9.4 ms per 1e7 rays,
+    // 2: 9.0, 3: 8.7, 4: 8.9, 6: 9.8, 12: 10.5; with a lane per ray, k_s_bounce<2>, 6: 14.1); TRC_GRID32_DENSITY overrides it
+    double density = 3.0;
     if (const char *e = std::getenv("TRC_GRID32_DENSITY")) { const double v = std::atof(e); if (v > 0.0) density = v; }
     double target = std::fmin(16777216.0, std::fmax(8.0, density * (double)nb));
     for (int attempt = 0; attempt < 16; ++attempt, target *= 0.5) {

@@ -4,6 +4,7 @@ The reference reads and writes STL through the numpy-stl package; here the two f
 Every triangle becomes a native flat surface -- a `FlatSimplePolygonGM` or a `TriangularFace`, in the triangle's own frame
 (origin at its first vertex, z along its normal) -- with a BoundaryBox for the Kd-tree, as the reference builds them.
 """
+import functools
 import struct
 
 import numpy as N
@@ -106,7 +107,7 @@ def make_stl_tracer_object(triangles, optics, optics_args, option='polygon'):
     triangles = N.asarray(triangles, dtype=float)
     if option == 'triangle':
         origins, rots, edges = stl_triangle_frames(triangles)
-        faces = FaceSet(origins, rots, edges, optics_factory=lambda: optics(**optics_args))
+        faces = FaceSet(origins, rots, edges, optics_factory=functools.partial(optics, **optics_args))      # (picklable: TracerEngineMP)
         return AssembledObject(surfs=faces, bounds=LazyBounds(triangles.min(axis=1), triangles.max(axis=1)))
     geoms, locs, rots = stl_to_tracer_geom(triangles, option=option)
     surfs = [Surface(geometry=g, optics=optics(**optics_args), location=l, rotation=r) for g, l, r in zip(geoms, locs, rots)]
