@@ -749,6 +749,7 @@ def test_mesh_of_1e5_triangles(ctx, tmp_path):
     _same(ref, _trace(ctx, cs, bundle, reps=6, TRC_STREAM_FRESH=0), 'fresh rays through k_s_bounce<FRESH> / the general path')
     _same(ref, _trace(ctx, cs, bundle, reps=6, TRC_STREAM_FIRST=1), 'aureole through k_s_bounce<FRESH>')
     _same(ref, _trace(ctx, cs, bundle, reps=6, TRC_STREAM_FRESH=0, TRC_STREAM_FIRST=1), 'all fresh rays through k_s_bounce<FRESH>')
+    _same(ref, _trace(ctx, cs, bundle, reps=6, TRC_STREAM_COOP=0), 'a lane per ray (k_s_bounce<2>) against the shared tests of k_s_bounce_coop')
     small = lambda: sources.buie_sunshape(20000, center, direction, 12., 0.05, flux=1., seed=22)
     brute = _trace(ctx, cs, small, reps=6, accel=False, TRC_STREAM_FRESH=0, TRC_STREAM_BOUNCE=0)
     _same(brute, _trace(ctx, cs, small, reps=6), 'default route vs all boxes')
