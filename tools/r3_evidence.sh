@@ -28,3 +28,4 @@ timeout -k 10 300 python tools/api_profile.py 1e8 read 2>&1 | head -4 > $O/api_f
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dish -- python3 $R/tools/gpu_dish.py > $O/dish.log 2>&1); tail -1 $O/dish.log
 (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cav -- python3 $R/tools/gpu_cavity.py > $O/cav.log 2>&1); tail -1 $O/cav.log
 timeout -k 10 300 python tools/gpu_mesh.py > $O/mesh.txt 2>&1 || true; tail -3 $O/mesh.txt
+timeout -k 10 300 python tools/gpu_poly.py 2e6 16 2>&1 | grep -v WARNING > $O/poly.txt || true; tail -4 $O/poly.txt
