@@ -803,6 +803,75 @@ def test_mesh_of_1e5_triangles(ctx, tmp_path):
     assert abs(a4[:nf].sum() / a0[:nf].sum() - 1.) < 1e-3 and abs(a4[nf] / a0[nf] - 1.) < 1e-3
 
 
+def test_large_grid_with_plates_and_a_closed_mesh(ctx):
+    """
+    The large grid (scenes beyond what LDS holds) with what the relief of test_mesh_of_1e5_triangles does not have: surfaces that
+    are not triangles -- listed with their boxes instead of corner and edges -- and a closed mesh, whose far side a ray that runs a
+    stage ahead of its exact tests (k_s_bounce_coop) meets too.  12 000 small mirror plates in random poses over a sphere of 20 480
+    triangles, a black floor: the shared tests of k_s_bounce_coop == a lane per ray (k_s_bounce<2>) == every box tested (accel=False)
+    == the megakernel on a sample == the oracle on the same Philox streams.
+    """
+    from tracer_amd import sources
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM
+    from tracer_amd.models.triangulated_surface import TriangulatedSurface
+    from tracer_amd import optics_callables as opt
+    from tracer_amd.spatial_geometry import translate, general_axis_rotation
+    from tracer_amd.scene import compile_scene
+    from oracle import engine as oracle_engine
+    rng = N.random.default_rng(12)
+    # an icosphere: 20 faces split five times
+    t = (1. + 5. ** 0.5) / 2.
+    V = N.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t], [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], float)
+    F = N.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8],
+                 [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]])
+    V /= N.linalg.norm(V, axis=1)[:, None]
+    for _ in range(5):
+        mid = {}
+        V = list(V)
+        def m(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in mid:
+                p = (V[a] + V[b]) / 2.
+                V.append(p / N.linalg.norm(p))
+                mid[k] = len(V) - 1
+            return mid[k]
+        F = N.array([f for a, b, c in F for f in ([a, m(a, b), m(c, a)], [b, m(b, c), m(a, b)], [c, m(c, a), m(b, c)], [m(a, b), m(b, c), m(c, a)])])
+        V = N.array(V)
+    assert len(F) == 20480
+    ball = TriangulatedSurface(3. * V, F, opt.Reflective(0.3), transform=translate(0., 0., 4.))
+    plates = []
+    for k in range(12000):
+        axis = rng.normal(size=3)
+        rot = general_axis_rotation(axis / N.linalg.norm(axis), rng.uniform(0., N.pi))
+        tr = N.eye(4)
+        tr[:3, :3] = rot
+        tr[:3, 3] = (rng.uniform(-9., 9.), rng.uniform(-9., 9.), rng.uniform(8., 14.))
+        plates.append(AssembledObject(surfs=[Surface(RectPlateGM(0.25, 0.15), opt.Reflective(0.1))], transform=tr))
+    floor = AssembledObject(surfs=[Surface(RectPlateGM(60., 60.), opt.LambertianReceiver(1.))], transform=translate(0., 0., -0.5))
+    asm = Assembly(objects=plates + [ball, floor])
+    cs = compile_scene(asm)
+    assert cs.n_surf == 12000 + 20480 + 1
+    direction = N.r_[0.05, 0.1, -1.] / N.linalg.norm([0.05, 0.1, -1.])
+    n = 300000
+    bundle = lambda: sources.buie_sunshape(n, N.c_[-30. * direction + N.r_[0., 0., 4.]], direction, 10., 0.05, flux=1., seed=5)
+    ref = _trace(ctx, cs, bundle, reps=8)
+    assert ref['launches'] > 1 and ref['h'][:12000].sum() > 0.03 * n and ref['h'][12000:-1].sum() > 0.05 * n and ref['h'][-1] > 0.3 * n
+    assert ref['segments'] > 1.1 * n
+    _same(ref, _trace(ctx, cs, bundle, reps=8, TRC_STREAM_COOP=0), 'a lane per ray against the shared tests')
+    small = lambda: sources.buie_sunshape(15000, N.c_[-30. * direction + N.r_[0., 0., 4.]], direction, 10., 0.05, flux=1., seed=6)
+    brute = _trace(ctx, cs, small, reps=8, accel=False, TRC_STREAM_FRESH=0, TRC_STREAM_BOUNCE=0)
+    _same(brute, _trace(ctx, cs, small, reps=8), 'the large grid against every box')
+    _same(brute, _trace(ctx, cs, small, reps=8, TRC_STREAM_COOP=0), 'the large grid, a lane per ray, against every box')
+    _same(brute, _trace(ctx, cs, small, reps=8, stream=False, accel=False), 'megakernel, brute force')
+    with N.errstate(all='ignore'):
+        o = oracle_engine.trace_from_compiled(cs, small().source_args(), reps=8, min_energy=1e-10)
+    assert N.array_equal(o['hits'], brute['h']) and o['segments'] == brute['segments']
+    assert N.allclose(o['absorbed'], brute['a'], rtol=1e-9, atol=1e-12)
+
+
 def test_scattering_slab_vs_oracle(ctx):
     """
     SURVEY 8(f)2, participating media: RefractiveScatteringHomogenous (optics_callables.py:1350-1376 on Scattering :946-1036,
