@@ -1,3 +1,4 @@
+# mesh timing, the whole GPU test suite, a short bench run: what is run after every change of the kernels
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
