@@ -870,6 +870,19 @@ def test_large_grid_with_plates_and_a_closed_mesh(ctx):
         o = oracle_engine.trace_from_compiled(cs, small().source_args(), reps=8, min_energy=1e-10)
     assert N.array_equal(o['hits'], brute['h']) and o['segments'] == brute['segments']
     assert N.allclose(o['absorbed'], brute['a'], rtol=1e-9, atol=1e-12)
+    # the ordered engine (tree=True, the reference's default) walks the large grid too (trc_nearest_grid32): the tree equals the
+    # oracle's level by level, the tallies those of the fast engine
+    from tracer_amd.tracer_engine import TracerEngine
+    eng = TracerEngine(asm)
+    eng.ray_tracer(small(), reps=8, min_energy=1e-10, tree=True, accel=True, seed=6)
+    assert eng.stats['engine'] == 'ordered' and eng.Kd_Tree is None
+    a, r, h = eng.get_tallies()
+    assert N.array_equal(h, brute['h']) and N.allclose(a, brute['a'], rtol=1e-9, atol=1e-12)
+    assert eng.tree.num_bunds() == len(o['levels'])
+    for k in range(1, eng.tree.num_bunds()):
+        B, Lo = eng.tree[k], o['levels'][k]
+        assert N.array_equal(B.get_parents(), Lo['parents']), k
+        assert N.allclose(B.get_vertices(), Lo['vertices'], rtol=1e-9, atol=1e-9) and N.allclose(B.get_energy(), Lo['energy'], rtol=1e-9, atol=1e-15), k
 
 
 def test_scattering_slab_vs_oracle(ctx):

@@ -553,6 +553,76 @@ __device__ __forceinline__ trc_accel_view stream_accel_global(const DScene &sc, 
     return A;
 }
 
+// Nearest hit of ONE ray through the large grid, one lane per ray (the ordered engine on a scene that stands on the large grid:
+// a mesh of 1e5 faces, where testing every surface for every ray -- what the engine did -- took 370 ms per 2e5 rays).  The cells
+// of the DDA with the occupancy bits, the listed faces from their 48-byte entries (trc_tri_hit32 / box and oriented box), the exact
+// test at once; the walk ends at the first cell behind the nearest hit.  Same candidates, same exact test and tie rule as
+// k_s_bounce<2> and trc_nearest_brute: t > 0, the lowest index among equal distances.  *s_out < 0: no hit.
+__device__ __forceinline__ void trc_nearest_grid32(const DScene &sc, double px, double py, double pz, double dx, double dy, double dz,
+                                                    double *t_out, int *s_out) {
+    trc_accel_view A = stream_accel_global(sc, 0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) A.root[i] = sc.a_bg_root[i];
+    trc_grid_view32 G;
+    memset(&G, 0, sizeof(G));
+    G.off = sc.a_bg_off; G.list = nullptr;
+    G.nx = sc.a_bg_dim[0]; G.ny = sc.a_bg_dim[1]; G.nz = sc.a_bg_dim[2];
+    G.lox = sc.a_bg_lo[0]; G.loy = sc.a_bg_lo[1]; G.loz = sc.a_bg_lo[2];
+    G.csx = sc.a_bg_cs[0]; G.csy = sc.a_bg_cs[1]; G.csz = sc.a_bg_cs[2];
+    G.ivx = sc.a_bg_inv[0]; G.ivy = sc.a_bg_inv[1]; G.ivz = sc.a_bg_inv[2];
+    double tb = TRC_INF;
+    int sb = 0x7FFFFFFF;
+    auto exact = [&](int s) __attribute__((always_inline)) {
+        const double t = trc_intersect(sc.recs + (size_t)s * sc.stride, sc.extra, px, py, pz, dx, dy, dz);
+        if (t > 0.0 && t < TRC_INF && (t < tb || (t == tb && s < sb))) { tb = t; sb = s; }
+    };
+    for (int k = 0; k < A.n_unbounded; ++k) exact(A.unbounded[k]);
+    trc_ray32 r;
+    double t0 = 0.0;
+    if (trc_ray32_prepare(A.slo, A.shi, A.cen, px, py, pz, dx, dy, dz, &r, &t0)) {
+        for (int k = 0; k < sc.a_bg_napart; ++k) {        // surfaces set apart from the grid
+            const int sidx = sc.a_bg_apart[k];
+            const float *b = A.sbox + 6 * (size_t)sidx;
+            if (b[3] == TRC_INF && b[0] == -TRC_INF) continue;
+            if (trc_box_hit32(b, r) && trc_obb_hit32(sc.a_obb + (size_t)TRC_OBB_STRIDE * sidx, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz)) exact(sidx);
+        }
+        float tmin = 1.0f, tmax = 0.0f;
+        if (trc_kd32_root(A.root, r, &tmin, &tmax)) {
+            const float4 *ent = (const float4 *)sc.a_bg_ent;
+            trc_dda dd;
+            trc_dda_start(G, r, tmin, &dd);
+            float t_enter = tmin;
+            bool walk = true;
+            while (walk) {
+                if (sb != 0x7FFFFFFF) {
+                    const float tbr = (float)(tb - t0);
+                    if (tbr < t_enter - (1e-3f + 1e-4f * fabsf(tbr))) break;      // every cell from here on starts behind the best hit
+                }
+                const int cell = trc_dda_cell(G, dd);
+                if ((sc.a_bg_occ[cell >> 5] >> (cell & 31)) & 1u) {
+                    const uint32_t k1 = G.off[cell + 1];
+                    for (uint32_t k = G.off[cell]; k < k1; ++k) {
+                        const float4 c0 = ent[3 * (size_t)k], c1 = ent[3 * (size_t)k + 1], c2 = ent[3 * (size_t)k + 2];
+                        const uint32_t w = __float_as_uint(c0.x);
+                        const int sidx = (int)(w & 0x7FFFFFFFu);
+                        bool pass;
+                        if (!(w & 0x80000000u)) pass = trc_tri_hit32(c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, A.delta, r);
+                        else {
+                            const float b[6] = {c0.y, c0.z, c0.w, c1.x, c1.y, c1.z};
+                            pass = trc_box_hit32(b, r) && trc_obb_hit32(sc.a_obb + (size_t)TRC_OBB_STRIDE * sidx, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz);
+                        }
+                        if (pass) exact(sidx);
+                    }
+                }
+                t_enter = fminf(dd.tnx, fminf(dd.tny, dd.tnz));
+                walk = trc_dda_next(G, r, tmax, &dd);
+            }
+        }
+    }
+    *t_out = sb != 0x7FFFFFFF ? tb : 0.0;
+    *s_out = sb != 0x7FFFFFFF ? sb : -1;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // capacity of the ray table and of the lists of slots / ray numbers: rays per batch + room for the unused tails of the chunks
 #define SQ_ROOM(W) ((W).room)

@@ -941,8 +941,10 @@ struct LdsStack32 {
 // FAST: the conservative single-precision search of the fast engines (boxes of the geometry, packed Kd nodes) in front of the exact
 // float64 tests -- the same nearest hit, the same tie rule (trc_nearest_accel32; tests/hostcheck pins it against brute force) --
 // with its stack in LDS; otherwise the float64 walk of the caller's tree / brute force, with a stack in private memory.
-template <bool FAST>
+// MODE 2: the scene stands on the large grid (a mesh): trc_nearest_grid32.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_ord_bounce(OrdParams P) {
+    constexpr bool FAST = MODE == 1;
     __shared__ uint32_t s_na[FAST ? ORD_STACK_DEPTH * 256 : 1];
     __shared__ float s_tm[FAST ? ORD_STACK_DEPTH * 256 : 1];
     const DScene &sc = P.sc;
@@ -955,7 +957,9 @@ __global__ __launch_bounds__(256) void k_ord_bounce(OrdParams P) {
     double t;
     int s;
     const bool use_kd = sc.has_kd && (P.flags & TRC_TRACE_ACCEL);
-    if (FAST) {
+    if (MODE == 2) {
+        trc_nearest_grid32(sc, px, py, pz, dx, dy, dz, &t, &s);
+    } else if (FAST) {
         const trc_accel_view A = stream_accel_global(sc, use_kd ? 1 : 0);
         LdsStack32 stk;
         stk.na = s_na + threadIdx.x; stk.tmax = s_tm + threadIdx.x;
@@ -2743,8 +2747,10 @@ extern "C" int trc_trace_ordered(trc_scene *sc, const trc_rays *in, const trc_so
             {
                 const bool use_kd = sc->has_kd && (flags & TRC_TRACE_ACCEL);
                 const bool fast = sc->accel_ok && sc->n_surf <= 65535 && (!use_kd || (sc->accel_kd_ok && sc->accel.kd_depth + 2 <= ORD_STACK_DEPTH));
-                if (fast) hipLaunchKernelGGL(k_ord_bounce<true>, dim3((unsigned)((n_cur + 255) / 256)), dim3(256), 0, ctx->stream, P);
-                else hipLaunchKernelGGL(k_ord_bounce<false>, dim3((unsigned)((n_cur + 255) / 256)), dim3(256), 0, ctx->stream, P);
+                const bool big = sc->accel_ok && sc->accel.big_ok && !use_kd;      // the scene stands on the large grid (and the caller brought no tree)
+                if (big) hipLaunchKernelGGL(k_ord_bounce<2>, dim3((unsigned)((n_cur + 255) / 256)), dim3(256), 0, ctx->stream, P);
+                else if (fast) hipLaunchKernelGGL(k_ord_bounce<1>, dim3((unsigned)((n_cur + 255) / 256)), dim3(256), 0, ctx->stream, P);
+                else hipLaunchKernelGGL(k_ord_bounce<0>, dim3((unsigned)((n_cur + 255) / 256)), dim3(256), 0, ctx->stream, P);
             }
             hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, sx.key, (long long)slots,
                                sx.blk_cnt, sx.blk_cul);

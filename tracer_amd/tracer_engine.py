@@ -225,14 +225,16 @@ class TracerEngine(object):
                 spectral = any(isinstance(a, PolychromaticAccountant) for o in dev.compiled.capturing_optics for a in o.accountants)
                 carries = _pending(bundle) or bundle.get_num_rays() < 64 or spectral
             engine = 'ordered' if (tree or dev.compiled.splits or carries) else 'fast'
-        if accel and Kd_Tree is None and (engine == 'fast' or (engine == 'ordered' and dev.n_surf <= 65535 and
-                                                                bundle.get_num_rays() * dev.n_surf <= self.KD_WORTH_IT)):
+        if accel and Kd_Tree is None and (engine == 'fast' or (engine == 'ordered' and (dev.n_surf > self.KD_BUILD_MAX or (
+                dev.n_surf <= 65535 and bundle.get_num_rays() * dev.n_surf <= self.KD_WORTH_IT)))):
             # The fast engine does not walk the reference's Kd-tree: large calls search the library's own uniform grid over the same
             # geometry boxes (csrc/trc_bounds.h), small ones test the boxes themselves.  Building the tree -- the reference's SAH
             # build, Python: 38 ms for the 219 surfaces of the NSTTF field, minutes for a mesh of 1e5 faces -- before every trace
             # of a scene that moves (a day of sun positions) cost more than the traces.  engine.Kd_Tree builds it when it is read.
             # The ordered engine walks it, but below KD_WORTH_IT box tests per bounce (rays x surfaces: a millisecond of the GPU)
             # testing every surface's box costs less than the build: 1e5 rays on the NSTTF field took 30 ms with the tree, 3 without.
+            # Beyond KD_BUILD_MAX surfaces (a mesh) the tree is never built for a trace: the scene stands on the library's large grid,
+            # which the ordered engine walks too (trc_nearest_grid32).
             num_surfs = dev.n_surf
             kw = dict(kwargs)
             kw.setdefault('min_leaf', 1)
