@@ -39,6 +39,13 @@ class FaceSet(object):
         self._parent = N.eye(4)         # frame of the owning object in global coordinates
         self._global = None             # (m, 3, 4): upper rows of the faces' global frames, made when first needed
         self._template = None           # optics instance the per-face ones are copies of in all but identity (optics_factory)
+        self._rows = None               # (key, rows): the device-table rows of the faces as last compiled (scene.CompiledScene)
+        self.stamp = 0                  # counts what could change those rows behind the key's back (nothing, so far: the arrays are fixed)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_rows'] = state['_global'] = None        # (made again when needed: not worth 38 MB per copy of a mesh of 1e5 faces)
+        return state
 
     # -- a sequence of Surfaces -------------------------------------------------------------------------------------
     def __len__(self):
@@ -106,6 +113,12 @@ class FaceSet(object):
         if self.optics is not None:
             return [self.optics]
         return [s.get_optics_manager() for s in self._made.values()]
+
+    def compiled_rows(self, key):
+        return self._rows[1] if self._rows is not None and self._rows[0] == key else None
+
+    def keep_compiled_rows(self, key, rows):
+        self._rows = (key, rows)
 
     def gm_rows(self):
         """(kind, (m, 6) parameters) of the faces' geometry managers: TriangularFace._native() of each"""

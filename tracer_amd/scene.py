@@ -48,7 +48,6 @@ class CompiledScene(object):
         n = len(self.surfaces)
         if n == 0:
             raise ValueError("the assembly has no surfaces")
-        self.descs = (_cabi.SurfaceDesc * n)()
         # the table is filled row by row into one array laid out like trc_surface_desc (6 int32, then frame 12, gm 16, opt 8 doubles)
         # and copied over the ctypes array at the end: this runs once per call of ray_tracer, to see whether the scene changed
         rows = N.zeros(n, dtype=_DESC_DTYPE)
@@ -56,6 +55,7 @@ class CompiledScene(object):
         self.splits = False
         self.carries = False        # optics that read what only rays of the ordered engine carry (complex indices, spectra)
         self.materials = []         # materials of the Refractive surfaces; row k of trc_rays.mat is materials[k].m(wavelengths)
+        self._sig_parts = []        # (first row, rows, key) of the parts whose rows a short key stands for (the faces of a mesh)
         self.capture = [False] * n
         self.optics = []            # the distinct optics managers of the scene, in surface order; those that capture hits
         self.capturing_optics = []
@@ -69,13 +69,21 @@ class CompiledScene(object):
                     # every face its own accountants: they have to exist before hits are promised to them
                     for s in part:
                         self._note_optics(s.get_optics_manager(), True)
-                gkind, gpar = part.gm_rows()
-                block = rows[first:first + m]
-                block['ints'] = (gkind, okind, sflags, -1, 0, 0)
-                block['frame'] = part.global_frames12()
-                block['gm'][:, :gpar.shape[1]] = gpar
-                if len(opar):
-                    block['opt'][:, :len(opar)] = opar
+                # the rows of the faces as they stand -- pose of the object, parameters of the optics -- are kept by the FaceSet: a
+                # script that traces the same mesh again and again pays one copy per call, and the table's signature a few bytes
+                key = (part._parent.tobytes(), int(okind), tuple(float(x) for x in opar), int(sflags))
+                block = part.compiled_rows(key)
+                if block is None:
+                    gkind, gpar = part.gm_rows()
+                    block = N.zeros(m, dtype=_DESC_DTYPE)
+                    block['ints'] = (gkind, okind, sflags, -1, 0, 0)
+                    block['frame'] = part.global_frames12()
+                    block['gm'][:, :gpar.shape[1]] = gpar
+                    if len(opar):
+                        block['opt'][:, :len(opar)] = opar
+                    part.keep_compiled_rows(key, block)
+                rows[first:first + m] = block
+                self._sig_parts.append((first, m, ('faces', id(part), part.stamp) + key))
                 if sflags & _cabi.SURF_CAPTURE_HITS:
                     self.capture[first:first + m] = [True] * m
                 continue
@@ -98,7 +106,8 @@ class CompiledScene(object):
                     row['gm'][:len(gpar)] = gpar
                 if len(opar):
                     row['opt'][:len(opar)] = opar
-        C.memmove(self.descs, rows.ctypes.data, n * C.sizeof(_cabi.SurfaceDesc))
+        self._rows = rows                                   # (the ctypes table is a view of this array: no second copy of 38 MB for a mesh)
+        self.descs = (_cabi.SurfaceDesc * n).from_buffer(rows)
         self.extra = _cabi.f64(self._extra)
         del self._extra, self._seen
         self.n_surf = n
@@ -143,15 +152,32 @@ class CompiledScene(object):
             if captures:
                 self.capturing_optics.append(opt)
 
+    def _sig(self, rows_bytes):
+        """what identifies the table: the rows of the surfaces compiled one by one as bytes, a short key for the faces of a mesh"""
+        out, at = [], 0
+        for first, m, key in self._sig_parts:
+            if first > at:
+                out.append(rows_bytes(at, first))
+            out.append(key)
+            at = first + m
+        if at < self.n_surf:
+            out.append(rows_bytes(at, self.n_surf))
+        out.append(self.extra.tobytes())
+        return tuple(out)
+
     def signature(self):
-        """Bytes that identify everything uploaded to the device."""
-        return bytes(self.descs) + self.extra.tobytes()
+        """What identifies everything uploaded to the device (compared with ==)."""
+        return self._sig(lambda a, b: self._rows[a:b].tobytes())
 
     def signature_without_frames(self):
         """The same with the surface frames left out: equal for two states of a scene that only moved (a heliostat field
         following the sun) -- then DeviceScene.update_frames is enough."""
-        rows = N.frombuffer(self.descs, dtype=_DESC_DTYPE)
-        return rows['ints'][:, :5].tobytes() + rows['gm'].tobytes() + rows['opt'].tobytes() + self.extra.tobytes()
+        def part(a, b):
+            rows = self._rows[a:b]
+            return rows['ints'][:, :5].tobytes() + rows['gm'].tobytes() + rows['opt'].tobytes()
+        # (the key of a mesh's faces holds the pose of their object: left out here)
+        sig = self._sig(part)
+        return tuple(k[:3] + k[4:] if isinstance(k, tuple) and k and k[0] == 'faces' else k for k in sig)
 
     def frames12(self):
         fr = N.empty((self.n_surf, 12))
