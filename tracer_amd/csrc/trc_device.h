@@ -512,7 +512,7 @@ struct StreamParams {
                               (1u << TRC_OPT_REAL_REFLECTIVE) | (1u << TRC_OPT_ONE_SIDED_REAL_REFLECTIVE))
 #define TRC_CLS_DIFFUSE_KINDS ((1u << TRC_OPT_LAMBERTIAN) | (1u << TRC_OPT_LAMBERTIAN_SPECULAR) | (1u << TRC_OPT_SEMI_LAMBERTIAN) | \
                                (1u << TRC_OPT_REFLECTIVE_SPECTRAL) | (1u << TRC_OPT_LAMBERTIAN_DIRECTIONAL) |                     \
-                               (1u << TRC_OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL))
+                               (1u << TRC_OPT_LAMBERTIAN_DIRECTIONAL_SPECTRAL) | (1u << TRC_OPT_FRESNEL_CONDUCTOR))
 
 // class of a surface from its optics kind and parameters (host side, when the flags are uploaded)
 static inline int trc_shade_class_of(const trc_surface_desc &sd) {

@@ -10,7 +10,9 @@
 //
 //   TRC_CLS_MIRROR    Transparent, Reflective, OneSidedReflective, RealReflective, OneSidedRealReflective (:93-140, :195-269, :492-504)
 //   TRC_CLS_DIFFUSE   Lambertian, LambertianSpecular, SemiLambertian, Reflective_spectral and the table-driven
-//                     Lambertian_directional_axisymmetric_piecewise family (:143-193, :331-391, :427-487, :506-585)
+//                     Lambertian_directional_axisymmetric_piecewise family (:143-193, :331-391, :427-487, :506-585), and
+//                     FresnelConductorHomogenous (:1536-1558: a mirror whose reflectance comes from a tabulated complex index -- the metal
+//                     ring of the cavity receiver, 4.5 % of its hits, was the only reason for a third kernel and a third list there)
 //   (TRC_CLS_GENERAL  everything else stays with k_s_shade)
 //
 // Per hit the arithmetic is the one of the other engines: trc_normal, trc_shade_k = trc_shade with the other kinds left out.
