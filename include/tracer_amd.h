@@ -308,6 +308,12 @@ int trc_scene_get_fluxmap(trc_scene *scene, int32_t surf, double *out /* nu*nv, 
    reserved so far (trc_scene_hits_reserved: an upper bound of n) and read n afterwards. */
 int trc_scene_get_hits(trc_scene *scene, int64_t *n, int32_t *surf, double *e_abs, double *e_in,
                        double *px, double *py, double *pz, double *dx, double *dy, double *dz);
+/* The same with the spectra of polychromatic hits (trc_trace_fast on a bundle with spectra, k_s_shade_x): n_x = 3 W more columns per
+   hit, x[k * n + i] for hit i -- k in [0, W): sample wavelengths, [W, 2W): the spectrum that arrived, [2W, 3W): the spectrum that
+   left (optics_callables.py:1825-1848 takes their difference).  trc_scene_hit_spectral_columns: the n_x the buffer holds (0: none). */
+int trc_scene_get_hits_x(trc_scene *scene, int64_t *n, int32_t *surf, double *e_abs, double *e_in, double *px, double *py,
+                         double *pz, double *dx, double *dy, double *dz, int32_t n_x, double *x);
+int trc_scene_hit_spectral_columns(trc_scene *scene, int32_t *n_x);
 /* View-factor allocation (emissive_losses/view_factors_3D.py:239-356 and :598-674, `alloc_VF`): the absorbed energy of
    the captured hits collected per element on the device instead of fetching every hit and looping over the elements on
    the host.  Element j takes the hits of the surfaces surf_lo[j]..surf_hi[j] whose global azimuth atan2(y,x) (brought
@@ -358,7 +364,7 @@ int trc_kdtree_traversal(trc_ctx *ctx, const trc_kdtree_desc *kd, int32_t n_surf
  * (capacity last->n on entry, count on exit).
  * A given bundle may carry what Refractive / RefractiveAbsorbant and the polychromatic wall read (ref_index_im, mat, spec_wl +
  * spectra): such calls, and calls on scenes with those optics, run the streaming form (64 rays or more; TRC_ERR_UNSUPPORTED with
- * TRC_TRACE_MEGAKERNEL or fewer rays: use trc_trace_ordered).  Spectra are not captured per hit and not returned in `last`.
+ * TRC_TRACE_MEGAKERNEL or fewer rays: use trc_trace_ordered).  Captured hits keep their spectra (trc_scene_get_hits_x); `last` does not.
  */
 int trc_trace_fast(trc_scene *scene, const trc_rays *in, const trc_source_desc *src, int64_t n,
                    int32_t reps, double min_energy, uint64_t seed, uint64_t ray_offset,

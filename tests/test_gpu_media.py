@@ -296,10 +296,26 @@ def test_polychromatic_bundle_on_the_fast_path(ctx):
     eng2.ray_tracer(mk(), reps=6, min_energy=1e-9, tree=False, seed=33, engine='ordered')
     a2, r2, h2 = eng2.get_tallies()
     assert N.array_equal(h2, h) and N.allclose(a2, a, rtol=1e-9, atol=1e-12)
-    # with the spectral accountant in place the call stays with the ordered engine
-    eng3 = TracerEngine(_poly_scene()[0])
-    eng3.ray_tracer(mk(), reps=2, min_energy=1e-9, tree=False, seed=33)
-    assert eng3.stats['engine'] == 'ordered'
+    # with the wall's spectral accountant in place (PolychromaticAccountant, optics_callables.py:1825-1848): the captured hits keep
+    # their sample wavelengths and their spectra before and after the wall -- the accountant holds what the ordered engine gives it
+    # (the fast engine delivers the hits in the order they were made: compared hit by hit after sorting both by hit point)
+    asm3, asm4 = _poly_scene()[0], _poly_scene()[0]
+    eng3, eng4 = TracerEngine(asm3), TracerEngine(asm4)
+    eng3.ray_tracer(mk(), reps=6, min_energy=1e-9, tree=False, seed=33)
+    eng4.ray_tracer(mk(), reps=6, min_energy=1e-9, tree=False, seed=33, engine='ordered')
+    assert eng3.stats['engine'] == 'fast' and eng3.stats['form'] == 'stream' and eng4.stats['engine'] == 'ordered'
+    got = asm3.get_surfaces()[0].get_optics_manager().get_all_hits()
+    ref = asm4.get_surfaces()[0].get_optics_manager().get_all_hits()
+    (e3, (w3, s3)), (e4, (w4, s4)) = got[:2], ref[:2]
+    assert len(e3) == len(e4) == h[0] and s3.shape == s4.shape == (W, h[0]) and w3.shape == w4.shape
+    k3, k4 = N.lexsort((s3[1], s3[0], e3)), N.lexsort((s4[1], s4[0], e4))
+    assert N.allclose(e3[k3], e4[k4], rtol=1e-9, atol=1e-9)
+    assert N.allclose(s3[:, k3], s4[:, k4], rtol=1e-9, atol=1e-6) and N.array_equal(w3[:, k3], w4[:, k4])
+    assert N.allclose(N.trapezoid(s3, w3, axis=0), e3, rtol=1e-9)          # absorbed energy = integral of the absorbed spectrum
+    # a second call: its hits and their spectra are appended behind those of the first
+    eng3.ray_tracer(mk(), reps=6, min_energy=1e-9, tree=False, seed=34)
+    e5, (w5, s5) = asm3.get_surfaces()[0].get_optics_manager().get_all_hits()[:2]
+    assert len(e5) > 1.9 * h[0] and s5.shape[1] == len(e5) and N.allclose(s5[:, :h[0]][:, k3], s4[:, k4], rtol=1e-9, atol=1e-6)
 
 
 def test_polychromatic_wall_without_spectra_is_an_error(ctx):

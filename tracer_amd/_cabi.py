@@ -112,6 +112,8 @@ SIGNATURES = {
     'trc_scene_get_tallies': (C.c_int, [_vp, _p_f64, _p_f64, _p_i64]),
     'trc_scene_get_fluxmap': (C.c_int, [_vp, C.c_int32, _p_f64]),
     'trc_scene_get_hits': (C.c_int, [_vp, _p_i64, _p_i32] + [_p_f64] * 8),
+    'trc_scene_get_hits_x': (C.c_int, [_vp, _p_i64, _p_i32] + [_p_f64] * 8 + [C.c_int32, _p_f64]),
+    'trc_scene_hit_spectral_columns': (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     'trc_scene_bin_hits': (C.c_int, [_vp, C.c_int32, _p_i32, _p_i32, _p_f64, _p_i32, _p_f64]),
     'trc_scene_enable_transfer': (C.c_int, [_vp, C.c_int32]),
     'trc_scene_get_transfer': (C.c_int, [_vp, _p_f64]),

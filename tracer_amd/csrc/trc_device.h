@@ -208,7 +208,9 @@ template <bool LDS_TALLY>
 __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, int s, double e_in,
                                            double e_abs, double hx, double hy, double hz, double dx,
                                            double dy, double dz, bool capture_enabled, int prev, WaveChunk *hc = nullptr,
-                                           double *lds_fm = nullptr, bool volume = false, bool tallied = false) {
+                                           double *lds_fm = nullptr, bool volume = false, bool tallied = false,
+                                           unsigned long long *slot_out = nullptr) {
+    // slot_out: where the hit went in the hit buffer (~0: not captured) -- chunked appends only
     // tallied: the caller has added the three per-surface sums itself (k_s_absorb: once per wave)
     // volume: the ray was scattered in the medium before it reached the surface -- nothing is recorded, but the lane takes part
     // in the appends of the wave below (their bookkeeping is per wave)
@@ -245,6 +247,7 @@ __device__ __forceinline__ void record_hit(const DScene &sc, double *lds_tally, 
         const int fl = sc.sflags[s];
         bool want = !volume && (fl & TRC_SURF_CAPTURE_HITS) != 0;
         unsigned long long slot = chunk_append(&sc.counters[0], *hc, want, nullptr, 0);
+        if (slot_out) *slot_out = (want && (long long)slot < sc.hit_cap) ? slot : ~0ull;
         if (want) {
             if ((long long)slot < sc.hit_cap) {
                 sc.h_surf[slot] = s;
@@ -291,6 +294,8 @@ struct CarryIn {
     const double *ref_im, *mat, *spec_wl, *spec;
     int n_mat, n_spec;
     double *slot_spec;      // the slot's table of spectra under way: sample w of the ray in slot s at slot_spec[w * room + s] (null: none)
+    double *hit_x;          // 3 n_spec columns beside the hit buffer, hit_x_cap entries each (null: no spectra per captured hit):
+    long long hit_x_cap;    // sample wavelengths, spectrum that arrived, spectrum that left
 };
 
 struct FastParams {

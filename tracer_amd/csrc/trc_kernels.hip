@@ -135,6 +135,9 @@ struct trc_scene {
     uint32_t hit_chunk;   // entries a wave of the streaming engine's shading kernels reserves per atomic (set with the capacity)
     int32_t *d_h_surf;
     double *d_h[8];
+    double *d_hx;         // polychromatic hits: hx_cols more columns of the hit buffer (column k at d_hx + k * hx_cap): per hit the W sample
+    int hx_cols;          // wavelengths, the W samples of the spectrum that arrived and the W that left (k_s_shade_x)
+    int64_t hx_cap;
 };
 
 // what rays of the ordered engine carry beyond the nine columns: rows of one matrix `pay` (row r of ray i at pay[r * n + i]):
@@ -1525,7 +1528,7 @@ extern "C" int trc_scene_destroy(trc_scene *sc) {
     dev_free(sc->d_a_sbox); dev_free(sc->d_a_obb); dev_free(sc->d_a_nodes); dev_free(sc->d_a_leaf); dev_free(sc->d_a_unbounded); dev_free(sc->d_a_bleaf);
     dev_free(sc->d_a_goff); dev_free(sc->d_a_glist); dev_free(sc->d_a_gapart); dev_free(sc->d_a_bg_off); dev_free(sc->d_a_bg_occ); dev_free(sc->d_a_bg_ent); dev_free(sc->d_a_bg_apart);
     dev_free(sc->d_kd_split); dev_free(sc->d_tally); dev_free(sc->d_fm_of_surf); dev_free(sc->d_fms);
-    dev_free(sc->d_fm_edges); dev_free(sc->d_counters); dev_free(sc->d_src_buf); dev_free(sc->d_h_surf);
+    dev_free(sc->d_fm_edges); dev_free(sc->d_counters); dev_free(sc->d_src_buf); dev_free(sc->d_h_surf); dev_free(sc->d_hx);
     for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
     for (int i = 0; i < 7; ++i) dev_free(sc->d_last[i]);
     delete sc;
@@ -1647,6 +1650,7 @@ extern "C" int trc_scene_set_hit_capacity(trc_scene *sc, int64_t capacity) {
     }
     dev_free(sc->d_h_surf);
     for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
+    dev_free(sc->d_hx); sc->hx_cols = 0; sc->hx_cap = 0;      // (made again by the next call that brings spectra)
     sc->hit_cap = 0;
     sc->hit_cap_user = 0;
     sc->hit_epoch += 1;
@@ -1697,6 +1701,7 @@ extern "C" int trc_scene_reserve_hits(trc_scene *sc, int64_t capacity) {
     }
     dev_free(sc->d_h_surf);
     for (int i = 0; i < 8; ++i) dev_free(sc->d_h[i]);
+    dev_free(sc->d_hx); sc->hx_cols = 0; sc->hx_cap = 0;      // (a buffer that grows keeps its hits, not their spectra: the host reads those before)
     sc->d_h_surf = n_surf;
     for (int i = 0; i < 8; ++i) sc->d_h[i] = n_col[i];
     sc->hit_dirty_to = used;
@@ -1852,6 +1857,10 @@ struct HitPack {
     double *o_col[8];
     int want[8];
     const int32_t *sflags;      // TRC_SURF_CAPTURE_LEAN: columns 1 (incident energy) and 5-7 (direction) of the hit were not written
+    const double *x;            // n_x more columns (spectra), column k at x + k * x_cap; packed to o_x + k * o_cnt
+    double *o_x;
+    int n_x;
+    long long x_cap, o_cnt;
 };
 __global__ __launch_bounds__(256) void k_hits_pack(HitPack H, const uint32_t *offs, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1867,6 +1876,7 @@ __global__ __launch_bounds__(256) void k_hits_pack(HitPack H, const uint32_t *of
 #pragma unroll
         for (int k = 5; k < 8; ++k) if (H.want[k]) H.o_col[k][o] = 0.0;
     }
+    for (int k = 0; k < H.n_x; ++k) H.o_x[(long long)k * H.o_cnt + o] = H.x[(long long)k * H.x_cap + i];
 }
 
 // The same, surface by surface: entry src[o] of the buffer goes to place o (src = the entries sorted by surface, stably).
@@ -1890,11 +1900,14 @@ __global__ __launch_bounds__(256) void k_hits_gather(HitPack H, const uint32_t *
 #pragma unroll
         for (int k = 5; k < 8; ++k) if (H.want[k]) H.o_col[k][o] = 0.0;
     }
+    for (int k = 0; k < H.n_x; ++k) H.o_x[(long long)k * H.o_cnt + o] = H.x[(long long)k * H.x_cap + i];
 }
 
-extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, double *e_abs, double *e_in, double *px,
-                                  double *py, double *pz, double *dx, double *dy, double *dz) {
+static int scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, double *e_abs, double *e_in, double *px,
+                          double *py, double *pz, double *dx, double *dy, double *dz, int32_t n_x, double *x_out) {
     if (!sc || !n) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    if (n_x < 0 || (n_x > 0 && (!x_out || n_x != sc->hx_cols || !sc->d_hx)))
+        return trc_fail(TRC_ERR_INVALID, "trc_scene_get_hits_x: the hit buffer holds %d spectral columns, %d asked for", sc ? sc->hx_cols : 0, n_x);
     HIP_TRY(hipSetDevice(sc->ctx->device));
     HIP_TRY(hipStreamSynchronize(sc->ctx->stream));
     unsigned long long c[2];
@@ -1938,6 +1951,10 @@ extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, doub
             if (dst[k]) st = dev_alloc(&H.o_col[k], (size_t)cnt);
         }
         if (st) break;
+        if (n_x > 0) {
+            H.x = sc->d_hx; H.n_x = n_x; H.x_cap = sc->hx_cap; H.o_cnt = cnt;
+            if ((st = dev_alloc(&H.o_x, (size_t)cnt * (size_t)n_x))) break;
+        }
         int n_capture = 0;
         for (int i = 0; i < sc->n_surf; ++i) if (sc->surfs[i].flags & TRC_SURF_CAPTURE_HITS) ++n_capture;
         if (n_capture <= 1) {
@@ -1964,6 +1981,7 @@ extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, doub
         if (surf && hipMemcpyAsync(surf, H.o_surf, (size_t)cnt * 4, hipMemcpyDeviceToHost, sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
         for (int k = 0; k < 8; ++k)
             if (dst[k] && hipMemcpyAsync(dst[k], H.o_col[k], (size_t)cnt * 8, hipMemcpyDeviceToHost, sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
+        if (n_x > 0 && hipMemcpyAsync(x_out, H.o_x, (size_t)cnt * (size_t)n_x * 8, hipMemcpyDeviceToHost, sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "memcpy failed"); break; }
         if (st == TRC_OK && hipStreamSynchronize(sc->ctx->stream) != hipSuccess) { st = trc_fail(TRC_ERR_DEVICE, "fetching the hits failed"); break; }
     } while (0);
     (void)hipStreamSynchronize(sc->ctx->stream);
@@ -1971,8 +1989,25 @@ extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, doub
     dev_free(d_key[0]); dev_free(d_key[1]); dev_free(d_ent[0]); dev_free(d_ent[1]);
     dev_free(d_tmp);
     dev_free(H.o_surf);
+    dev_free(H.o_x);
     for (int k = 0; k < 8; ++k) dev_free(H.o_col[k]);
     return st;
+}
+
+extern "C" int trc_scene_get_hits(trc_scene *sc, int64_t *n, int32_t *surf, double *e_abs, double *e_in, double *px,
+                                  double *py, double *pz, double *dx, double *dy, double *dz) {
+    return scene_get_hits(sc, n, surf, e_abs, e_in, px, py, pz, dx, dy, dz, 0, nullptr);
+}
+
+extern "C" int trc_scene_get_hits_x(trc_scene *sc, int64_t *n, int32_t *surf, double *e_abs, double *e_in, double *px,
+                                    double *py, double *pz, double *dx, double *dy, double *dz, int32_t n_x, double *x) {
+    return scene_get_hits(sc, n, surf, e_abs, e_in, px, py, pz, dx, dy, dz, n_x, x);
+}
+
+extern "C" int trc_scene_hit_spectral_columns(trc_scene *sc, int32_t *n_x) {
+    if (!sc || !n_x) return trc_fail(TRC_ERR_INVALID, "bad arguments");
+    *n_x = sc->d_hx ? sc->hx_cols : 0;
+    return TRC_OK;
 }
 
 #define BIN_TILE 256
@@ -2317,7 +2352,26 @@ extern "C" int trc_trace_fast(trc_scene *sc, const trc_rays *in, const trc_sourc
         P.sc = make_dscene(sc);
         P.x = dr.x; P.y = dr.y; P.z = dr.z; P.dx = dr.dx; P.dy = dr.dy; P.dz = dr.dz; P.e = dr.e;
         P.ref = dr.ref; P.wl = dr.wl; P.rid = dr.rid;
+        // polychromatic hits: the captured ones keep their sample wavelengths and their spectrum before and after (3 W columns beside
+        // the hit buffer, made when the first call with spectra finds a buffer to capture into)
+        double *hit_x = nullptr;
+        bool captures = false;
+        if (sc->hit_cap > 0)
+            for (int i = 0; i < S && !captures; ++i) captures = (sc->surfs[i].flags & TRC_SURF_CAPTURE_HITS) != 0;
+        if (carry_W > 0 && captures) {
+            const int cols = 3 * carry_W;
+            if (sc->d_hx && (sc->hx_cols != cols || sc->hx_cap != sc->hit_cap)) {
+                if (cnt_before[0] != 0ull) { st = trc_fail(TRC_ERR_INVALID, "the hit buffer holds hits with spectra of another sample count: read or clear them first"); break; }
+                dev_free(sc->d_hx); sc->hx_cols = 0; sc->hx_cap = 0;
+            }
+            if (!sc->d_hx) {
+                if ((st = dev_alloc(&sc->d_hx, (size_t)cols * (size_t)sc->hit_cap))) break;
+                sc->hx_cols = cols; sc->hx_cap = sc->hit_cap;
+            }
+            hit_x = sc->d_hx;
+        }
         CarryIn carry_in;
+        carry_in.hit_x = hit_x; carry_in.hit_x_cap = sc->hx_cap;
         carry_in.ref_im = carry_d[0]; carry_in.mat = carry_d[1]; carry_in.spec_wl = carry_d[2]; carry_in.spec = carry_d[3]; carry_in.n_mat = carry_mat; carry_in.n_spec = carry_W;
         P.src = d_src;
         P.n = n; P.reps = reps; P.flags = flags; P.min_energy = min_energy; P.seed = seed; P.ray_offset = ray_offset;

@@ -429,8 +429,19 @@ __global__ __launch_bounds__(SHC_THREADS) void k_s_shade_x(StreamParams S) {
             if (volume) { hx -= out[0].back * g.dx; hy -= out[0].back * g.dy; hz -= out[0].back * g.dz; }
             const double e_out = out[0].e;
             const double e_abs = e - e_out;
-            record_hit<LDS>(L, l_tally, s, e, e_abs, hx, hy, hz, g.dx, g.dy, g.dz, P.capture != 0, prev, &hc, l_fm, volume, true);
+            unsigned long long hslot = ~0ull;
+            record_hit<LDS>(L, l_tally, s, e, e_abs, hx, hy, hz, g.dx, g.dy, g.dz, P.capture != 0, prev, &hc, l_fm, volume, true, &hslot);
             if (!volume) { ts = s; tea = e_abs; tei = e; }
+            if (nW && C.hit_x && hslot != ~0ull) {        // a captured hit of a polychromatic ray: wavelengths, spectrum in, spectrum out
+                const double *tab = L.extra + trc_rec_extra_off(rec);
+                for (int w = 0; w < nW; ++w) {
+                    const double xw = X.wl[(long long)w * P.n], yin = X.spec[(long long)w * spec_stride];
+                    const double f = poly_th >= 0.0 ? 1.0 - trc_poly_absorptance(tab, poly_th, xw) : out[0].sf;
+                    C.hit_x[(long long)w * C.hit_x_cap + (long long)hslot] = xw;
+                    C.hit_x[(long long)(nW + w) * C.hit_x_cap + (long long)hslot] = yin;
+                    C.hit_x[(long long)(2 * nW + w) * C.hit_x_cap + (long long)hslot] = yin * f;
+                }
+            }
             const double ox = out[0].dx, oy = out[0].dy, oz = out[0].dz;
             if (e_out > P.min_energy) {                               // tracer_engine.py:242
                 if (bounce0 + 1 >= P.reps) {

@@ -386,14 +386,28 @@ class DeviceScene(object):
         e_in = e_abs if lean else _cabi.pinned_empty(k)
         directions = None if lean else _cabi.pinned_empty((3, k))
         cols = [e_abs, None if lean else e_in, points[0], points[1], points[2]] + ([None] * 3 if lean else [directions[0], directions[1], directions[2]])   # rows: no copy afterwards
-        if k:
+        # hits of polychromatic rays bring 3 W more columns: sample wavelengths, the spectrum that arrived, the one that left
+        nx = C.c_int32(0)
+        _cabi.check(self.lib.trc_scene_hit_spectral_columns(self.handle, C.byref(nx)))
+        nx = nx.value
+        x = _cabi.pinned_empty((nx, k)) if (nx and k) else None
+        if k and x is not None:
+            _cabi.check(self.lib.trc_scene_get_hits_x(self.handle, C.byref(n), surf.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                      *([(_cabi.ptr(c) if c is not None else nul) for c in cols] + [nx, _cabi.ptr(x)])))
+        elif k:
             _cabi.check(self.lib.trc_scene_get_hits(self.handle, C.byref(n), surf.ctypes.data_as(C.POINTER(C.c_int32)),
                                                     *[(_cabi.ptr(c) if c is not None else nul) for c in cols]))
         m = n.value
         surf, e_abs, points = surf[:m], e_abs[:m], points[:, :m]
         e_in = e_abs if lean else e_in[:m]
         directions = None if lean else directions[:, :m]
-        return dict(surf=surf, e_abs=e_abs, e_in=e_in, points=points, directions=directions)
+        out = dict(surf=surf, e_abs=e_abs, e_in=e_in, points=points, directions=directions)
+        if x is not None:
+            # (the library packs column k of the m hits at x[k * m + i]: the first nx * m doubles of the block)
+            W = nx // 3
+            xs = x.reshape(-1)[:nx * m].reshape(nx, m)
+            out['spectra'] = (xs[W:2 * W], xs[2 * W:], xs[:W])         # (in, out, wavelengths): feed_accountants' order
+        return out
 
     def bin_hits(self, surf_lo, surf_hi, ranges, mode):
         """
@@ -588,11 +602,12 @@ class PendingHits(Delivery):
         h = dev.get_hits()
         cap = [i for i, c in enumerate(dev.compiled.capture) if c]
         one = cap[0] if len(cap) == 1 else None
+        sp = h.get('spectra')               # polychromatic hits: (spectra in, spectra out, sample wavelengths), (W, hits) each
         if h['directions'] is None:         # Receiver accountants only: absorbed energy and hit points
-            feed_accountants(self.surfaces, h['surf'], h['e_in'], None, h['points'], None, e_abs=h['e_abs'], only=holders, one_surface=one)
+            feed_accountants(self.surfaces, h['surf'], h['e_in'], None, h['points'], None, e_abs=h['e_abs'], only=holders, one_surface=one, spectra=sp)
         else:
             feed_accountants(self.surfaces, h['surf'], h['e_in'], h['e_in'] - h['e_abs'], h['points'], h['directions'], only=holders,
-                             one_surface=one)
+                             one_surface=one, spectra=sp)
 
     def release(self):
         if self.dev.pending_hits is self:

@@ -28,7 +28,7 @@ from . import rng
 from .accel_tree import KdTree
 from .ray_bundle import RayBundle, concatenate_rays
 from .scene import compile_scene, DeviceScene, NotNativeError, feed_accountants, PendingHits
-from .optics_callables import OpticsCallable, PolychromaticAccountant
+from .optics_callables import OpticsCallable
 from .trace_tree import RayTree
 from .ordered_levels import OrderedLevels, LazyLevelBundle, PendingLevels, level_columns
 
@@ -217,13 +217,12 @@ class TracerEngine(object):
 
         if engine == 'auto':
             # Complex refractive indices, materials evaluated at the rays' wavelengths and spectra travel with the rays of the
-            # ordered engine and of the streaming form of the fast engine (64 rays or more of a given bundle; k_s_shade_x).  The
-            # fast engine captures no spectra per hit: a scene whose accountants collect them (PolychromaticAccountant) stays
-            # with the ordered engine.
+            # ordered engine and of the streaming form of the fast engine (64 rays or more of a given bundle; k_s_shade_x).  A
+            # captured hit of a polychromatic ray keeps its sample wavelengths and its spectrum before and after the surface (what
+            # PolychromaticAccountant collects).
             carries = dev.compiled.carries or (not _pending(bundle) and (bundle.is_polychromatic() or bundle.has_complex_index()))
             if carries:
-                spectral = any(isinstance(a, PolychromaticAccountant) for o in dev.compiled.capturing_optics for a in o.accountants)
-                carries = _pending(bundle) or bundle.get_num_rays() < 64 or spectral
+                carries = _pending(bundle) or bundle.get_num_rays() < 64
             engine = 'ordered' if (tree or dev.compiled.splits or carries) else 'fast'
         if accel and Kd_Tree is None and (engine == 'fast' or (engine == 'ordered' and (dev.n_surf > self.KD_BUILD_MAX or (
                 dev.n_surf <= 65535 and bundle.get_num_rays() * dev.n_surf <= self.KD_WORTH_IT)))):
@@ -292,6 +291,8 @@ class TracerEngine(object):
             accs = [a for opt in dev.compiled.capturing_optics for a in opt.accountants]
             pend = dev.pending_hits
             keep = bool(feed and hit_capacity is None and pend is not None and pend.wanted() and accs and all(pend.holds_mark(a) for a in accs))
+            if keep and not _pending(bundle) and bundle.is_polychromatic():
+                keep = False        # (the spectra of captured hits live beside the buffer as it is: hits waiting there are delivered first)
             used = 0
             if keep:
                 used = dev.hits_reserved()[0]
