@@ -331,6 +331,84 @@ int hc_footprint(int n_surf, const trc_surface_desc *surfs, const double *extra,
     return 0;
 }
 
+// the large grid of scenes beyond LDS (a mesh): the lists of trc_accel_build_grid32 -- a triangular face only in the cells it touches --
+// with their 48-byte entries, the occupancy bits, trc_tri_hit32 in front of the exact test, the walk that ends behind the best
+// hit: what trc_nearest_grid32 / k_s_bounce<2> / k_s_bounce_coop do on the device, one ray after the other.
+// stats[0] = cells, [1] = listed faces looked at, [2] = exact tests, [3] = cells of the grid, [4] = list entries.  -2: no grid.
+int hc_nearest_grid32(int n_surf, const trc_surface_desc *surfs, const double *extra, long n, const double *x, const double *y,
+                      const double *z, const double *dx, const double *dy, const double *dz, double *t_out, int *s_out, double *stats) {
+    int max_np = 0;
+    for (int i = 0; i < n_surf; ++i) { int np = trc_gm_nparams(surfs[i].gm_kind); if (np > max_np) max_np = np; }
+    int stride = TRC_REC_HDR + max_np;
+    if ((stride & 1) == 0) stride += 1;
+    std::vector<double> recs_v((size_t)n_surf * stride);
+    for (int i = 0; i < n_surf; ++i) pack_record(surfs[i], recs_v.data() + (size_t)i * stride, stride);
+    const double *recs = recs_v.data();
+    trc_accel_host H;
+    trc_accel_build_surfaces(surfs, n_surf, H);
+    trc_accel_build_grid32(surfs, n_surf, H);
+    if (!H.big_ok) return -2;
+    trc_grid_view32 G;
+    G.off = H.big_off.data(); G.list = nullptr;
+    G.nx = H.big_dim[0]; G.ny = H.big_dim[1]; G.nz = H.big_dim[2];
+    G.lox = H.big_lo[0]; G.loy = H.big_lo[1]; G.loz = H.big_lo[2];
+    G.csx = H.big_cs[0]; G.csy = H.big_cs[1]; G.csz = H.big_cs[2];
+    G.ivx = H.big_inv[0]; G.ivy = H.big_inv[1]; G.ivz = H.big_inv[2];
+    stats[0] = stats[1] = stats[2] = 0.0;
+    stats[3] = (double)((long)G.nx * G.ny * G.nz); stats[4] = (double)H.big_list.size();
+    for (long i = 0; i < n; ++i) {
+        const double vx = x[i], vy = y[i], vz = z[i];
+        const double ddx = dx[i], ddy = dy[i], ddz = dz[i];
+        double tb = TRC_INF;
+        int sb = -1;
+        {
+            const double dx = ddx, dy = ddy, dz = ddz;
+            for (size_t k = 0; k < H.unbounded.size(); ++k) TRC_TEST_EXACT(H.unbounded[k]);
+            trc_ray32 r;
+            double t0;
+            float tmin, tmax;
+            const bool in = trc_ray32_prepare(H.slo, H.shi, H.cen, vx, vy, vz, dx, dy, dz, &r, &t0);
+            if (in)
+                for (size_t k = 0; k < H.big_apart.size(); ++k) {
+                    const int sidx = H.big_apart[k];
+                    if (trc_box_hit32(H.sbox.data() + 6 * (size_t)sidx, r) &&
+                        trc_obb_hit32(H.obb.data() + (size_t)TRC_OBB_STRIDE * sidx, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz)) { stats[2] += 1.0; TRC_TEST_EXACT(sidx); }
+                }
+            if (in && trc_kd32_root(H.big_root, r, &tmin, &tmax)) {
+                trc_dda s;
+                trc_dda_start(G, r, tmin, &s);
+                float t_enter = tmin;
+                bool walk = true;
+                while (walk) {
+                    if (sb >= 0) {
+                        const float tbr = (float)(tb - t0);
+                        if (tbr < t_enter - (1e-3f + 1e-4f * std::fabs(tbr))) break;
+                    }
+                    stats[0] += 1.0;
+                    const int c = trc_dda_cell(G, s);
+                    if ((H.big_occ[c >> 5] >> (c & 31)) & 1u)
+                        for (uint32_t k = G.off[c]; k < G.off[c + 1]; ++k) {
+                            const float *e = &H.big_ent[(size_t)TRC_BG_ENT * k];
+                            uint32_t w;
+                            std::memcpy(&w, e, 4);
+                            const int sidx = (int)(w & 0x7FFFFFFFu);
+                            stats[1] += 1.0;
+                            bool pass;
+                            if (!(w & 0x80000000u)) pass = trc_tri_hit32(e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8], e[9], e[10], e[11], H.delta, r);
+                            else pass = trc_box_hit32(e + 1, r) && trc_obb_hit32(H.obb.data() + (size_t)TRC_OBB_STRIDE * sidx, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz);
+                            if (pass) { stats[2] += 1.0; TRC_TEST_EXACT(sidx); }
+                        }
+                    t_enter = std::fmin(s.tnx, std::fmin(s.tny, s.tnz));
+                    walk = trc_dda_next(G, r, tmax, &s);
+                }
+            }
+        }
+        t_out[i] = tb;
+        s_out[i] = sb;
+    }
+    return 0;
+}
+
 // the oriented-box test against the exact test on arbitrary rays (the walk kernel's use): a ray that hits surface s exactly must
 // pass the box of s from an origin advanced to the scene box.  Returns the number of violations; *passed = rays passing the box.
 long hc_obb(const trc_surface_desc *s, const double *extra, long n, const double *x, const double *y, const double *z, const double *dx,

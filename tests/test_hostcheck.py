@@ -532,6 +532,90 @@ def test_oriented_box_never_rejects_a_hit(hc):
     assert tested > 2000
 
 
+def test_large_grid_search_on_triangle_soups(hc):
+    """
+    The search of scenes beyond LDS (trc_accel_build_grid32 + what trc_nearest_grid32 / k_s_bounce<2> / k_s_bounce_coop do per ray:
+    a face listed only in the cells it touches, trc_tri_hit32 in front of the exact test, the walk that ends behind the best hit)
+    against brute force, on what a smooth relief does not have: 4000 triangles thrown into a box -- needles (edges 1000 : 1),
+    specks, faces that cross dozens of cells, faces that cut each other -- with a few plates among them (listed by their boxes)
+    and one plate far away (set apart from the grid).  Rays from outside, from inside, along the faces' planes, parallel to the
+    axes, and leaving from the points just hit (two generations): the same (t, surface) for every ray.
+    """
+    from tracer_amd import _cabi as K
+    from tracer_amd.models.triangulated_surface import TriangulatedSurface
+    from tracer_amd.assembly import Assembly
+    from tracer_amd.object import AssembledObject
+    from tracer_amd.surface import Surface
+    from tracer_amd.flat_surface import RectPlateGM
+    from tracer_amd.spatial_geometry import translate, general_axis_rotation
+    from tracer_amd import optics_callables as opt
+    from tracer_amd.scene import compile_scene
+    for seed, box in ((3, 10.), (4, 0.02)):
+        rng = N.random.default_rng(seed)
+        nt = 4000
+        c = rng.uniform(-box, box, size=(nt, 3))
+        size = box * 10. ** rng.uniform(-3.5, -0.3, size=nt)                # specks to faces a third of the box long
+        e1, e2 = rng.normal(size=(nt, 3)), rng.normal(size=(nt, 3))
+        e1 *= (size / N.linalg.norm(e1, axis=1))[:, None]
+        needle = rng.random(nt) < 0.3
+        e2 *= (size * N.where(needle, 1e-3, rng.uniform(0.2, 1., nt)) / N.linalg.norm(e2, axis=1))[:, None]
+        V = N.vstack((c, c + e1, c + e2))
+        F = N.c_[N.arange(nt), N.arange(nt) + nt, N.arange(nt) + 2 * nt]
+        soup = TriangulatedSurface(V, F, opt.Reflective(0.1))
+        nf = len(soup.get_surfaces())
+        plates = []
+        for k in range(40):
+            ax = rng.normal(size=3)
+            tr = N.eye(4)
+            tr[:3, :3] = general_axis_rotation(ax / N.linalg.norm(ax), rng.uniform(0., N.pi))
+            tr[:3, 3] = rng.uniform(-box, box, size=3)
+            plates.append(AssembledObject(surfs=[Surface(RectPlateGM(0.3 * box, 0.1 * box), opt.Reflective(0.1))], transform=tr))
+        far = AssembledObject(surfs=[Surface(RectPlateGM(8. * box, 8. * box), opt.Reflective(0.1))], transform=translate(0., 0., 12. * box))
+        cs = compile_scene(Assembly(objects=[soup] + plates + [far]))
+        assert cs.n_surf == nf + 41 and nf > 3600          # (needles whose cross product vanishes are dropped, as in the reference)
+        m = 60000
+        v = rng.uniform(-1.5 * box, 1.5 * box, size=(3, m))
+        d = rng.normal(size=(3, m))
+        k = m // 4
+        tgt = rng.uniform(-box, box, size=(3, k))
+        v[:, :k] = 6. * box * (lambda u: u / N.linalg.norm(u, axis=0))(rng.normal(size=(3, k)))       # from outside, aimed inside
+        d[:, :k] = tgt - v[:, :k]
+        # along the planes of faces: from a point of the face's plane towards its inside
+        f = rng.integers(0, nt, k)
+        a, b = rng.uniform(-2., 3., k), rng.uniform(-2., 3., k)
+        v[:, k:2 * k] = (c[f] + a[:, None] * e1[f] + b[:, None] * e2[f]).T
+        d[:, k:2 * k] = (c[f] + (e1[f] + e2[f]) / 3.).T - v[:, k:2 * k] + 1e-9 * box * rng.normal(size=(3, k))
+        # parallel to an axis
+        ax = rng.integers(0, 3, k)
+        d[:, 2 * k:3 * k] = 0.
+        d[ax, N.arange(2 * k, 3 * k)] = rng.choice([-1., 1.], k)
+        d /= N.linalg.norm(d, axis=0)
+        extra = N.zeros(1)
+        total = 0
+        for gen in range(3):
+            v, d = N.ascontiguousarray(v), N.ascontiguousarray(d)
+            mm = v.shape[1]
+            tb, tk, sb, sk = N.empty(mm), N.empty(mm), N.empty(mm, dtype=N.int32), N.empty(mm, dtype=N.int32)
+            hc.hc_nearest(cs.n_surf, cs.descs, _p(extra), None, C.c_long(mm), _p(v[0]), _p(v[1]), _p(v[2]), _p(d[0]), _p(d[1]), _p(d[2]),
+                          _p(tb), _p(sb, C.c_int32), _p(tk), _p(sk, C.c_int32))
+            t32, s32, st = N.empty(mm), N.empty(mm, dtype=N.int32), N.zeros(8)
+            rc = hc.hc_nearest_grid32(cs.n_surf, cs.descs, _p(extra), C.c_long(mm), _p(v[0]), _p(v[1]), _p(v[2]), _p(d[0]), _p(d[1]), _p(d[2]),
+                                      _p(t32), _p(s32, C.c_int32), _p(st))
+            assert rc == 0
+            bad = N.nonzero((s32 != sb) | (t32 != tb))[0]
+            assert len(bad) == 0, (seed, gen, len(bad), bad[:5], sb[bad[:5]], s32[bad[:5]], tb[bad[:5]], t32[bad[:5]])
+            hit = sb >= 0
+            total += int(hit.sum())
+            if gen == 0:
+                print('seed %d: %d cells, %d list entries for %d faces; per ray %.1f cells, %.1f faces looked at, %.2f exact tests; %d of %d rays hit'
+                      % (seed, st[3], st[4], nf, st[0] / mm, st[1] / mm, st[2] / mm, hit.sum(), mm))
+            # the next generation leaves from the points hit, in random directions
+            p = v[:, hit] + tb[hit] * d[:, hit]
+            dn = rng.normal(size=p.shape)
+            v, d = p, dn / N.linalg.norm(dn, axis=0)
+        assert total > 0.5 * m
+
+
 def test_core_henyey_greenstein_vs_reference(hc):
     """trc_hg_theta (the device's scattering angle) on the reference's recorded draws, sampling.py:160-168"""
     g = load('scattering.npz')

@@ -28,7 +28,7 @@ def height_field(m, extent=10., amp=0.8):
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000000
 ctx = _cabi.get_context(0)
 t0 = time.time()
-V, F = height_field(230)
+V, F = height_field(int(os.environ.get("MESH_M", "230")))
 mesh = TriangulatedSurface(V, F, opt.Reflective(0.2))
 lid = AssembledObject(surfs=[Surface(RectPlateGM(90., 90.), opt.LambertianReceiver(1.))], transform=N.dot(translate(0., 0., 50.), rotx(N.pi)))
 cs = compile_scene(Assembly(objects=[mesh, lid]))
