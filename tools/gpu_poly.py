@@ -22,8 +22,7 @@ def poly_scene():
     ths = N.linspace(0., N.pi / 2., 7)
     wls = N.linspace(0.25e-6, 2.6e-6, 5)
     grid = 0.2 + 0.7 * N.outer(N.cos(ths) ** 0.5, 1. / (1. + (wls * 1e6 - 1.) ** 2))
-    wall = opt.Lambertian_directional_axisymmetric_piecewise_PolychromaticAbsorberPolychromatic(ths, grid, wls)
-    wall.accountants = [a for a in wall.accountants if not isinstance(a, opt.PolychromaticAccountant)]
+    wall = opt.Lambertian_directional_axisymmetric_piecewise_PolychromaticAbsorberPolychromatic(ths, grid, wls)      # (absorbed energy and absorbed spectrum per hit)
     floor = AssembledObject(surfs=[Surface(RectPlateGM(4., 4.), wall)], transform=translate(0., 0., 0.))
     roof = AssembledObject(surfs=[Surface(RectPlateGM(4., 4.), opt.Reflective(0.1))], transform=N.dot(translate(0., 0., 1.5), rotx(N.pi)))
     side = AssembledObject(surfs=[Surface(RectPlateGM(4., 1.5), opt.Lambertian(0.3))], transform=N.dot(translate(0., 2., 0.75), rotx(N.pi / 2.)))
@@ -54,8 +53,13 @@ for engine in ('fast', 'ordered'):
         t0 = time.time()
         eng.ray_tracer(b, reps=6, min_energy=1e-9, tree=False, seed=33 + r, engine=engine)
         wall = time.time() - t0
-        print('polychromatic box, %d rays x %d samples, %s engine, run %d: wall %.1f ms, kernels %.2f ms, %d segments (%.0f M segments/s by kernel time)'
-              % (n, W, engine, r, wall * 1e3, eng.stats['kernel_ms'], eng.stats['segments'], eng.stats['segments'] / eng.stats['kernel_ms'] / 1e3), flush=True)
+        t0 = time.time()
+        absorbed, (hw, hs) = eng._asm.get_surfaces()[0].get_optics_manager().get_all_hits()
+        read = time.time() - t0
+        eng._asm.reset_all_optics()
+        print('polychromatic box, %d rays x %d samples, %s engine, run %d: wall %.1f ms, kernels %.2f ms, %d segments (%.0f M segments/s by kernel time); '
+              'reading the wall\'s %d hits with their spectra %.1f ms'
+              % (n, W, engine, r, wall * 1e3, eng.stats['kernel_ms'], eng.stats['segments'], eng.stats['segments'] / eng.stats['kernel_ms'] / 1e3, len(absorbed), read * 1e3), flush=True)
 asm, air = slab_scene()
 v[2] = 3.
 wl = rng.uniform(0.4e-6, 2.4e-6, n)
