@@ -403,7 +403,9 @@ struct __attribute__((aligned(32))) SRayAux {
 // Workgroups of k_s_shade add into one of TALLY_PARTS copies of the tally buffer (copy = workgroup number mod TALLY_PARTS):
 // the end-of-workgroup flush of ~3S sums and the flux-map bins would otherwise be thousands of atomics per 128-byte line,
 // which serialise at ~88 per microsecond.
-#define TALLY_PARTS 16
+#ifndef TALLY_PARTS
+#define TALLY_PARTS 16          /* (the mesh of 1e5 faces, sums added per hit in global memory: 2 copies 12.6 ms per 1e7 rays, 4: 10.1, 16: 8.8, 32: 8.6, 64: 8.8) */
+#endif
 
 // counters live 128 bytes apart: atomics on words of one cache line serialise in the same L2 bank
 #define CN(k) ((k) << 4)
