@@ -18,7 +18,7 @@ dev = DeviceScene(ts, ctx)
 for r in range(2):
     dev.reset_tallies()
     t0 = time.time()
-    st, _ = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e, wavelengths=wl), 12, 1e-3 * e[0], 31, stream=True)
+    st, _ = dev.trace_fast(RayBundle(vertices=v, directions=d, energy=e, wavelengths=wl), 12, 1e-3 * e[0], 31, stream=os.environ.get("CAVITY_MEGAKERNEL", "0") != "1")
     wall = time.time() - t0
     a, rcv, h = dev.get_tallies()
     print('run %d: kernels %8.2f ms  wall (incl. 7 columns over PCIe) %8.1f ms  %8.1f Mseg/s by kernel time  segments %d  hits %s  absorbed share %.4f  launches %d' %
