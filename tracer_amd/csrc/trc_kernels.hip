@@ -1413,6 +1413,7 @@ static int scene_upload_surfaces(trc_scene *sc) {
     if (!sc->accel.unbounded.empty())
         HIP_TRY(hipMemcpy(sc->d_a_unbounded, sc->accel.unbounded.data(), sc->accel.unbounded.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     trc_accel_build_grid(sc->accel, sc->n_surf);
+    { const char *ev = getenv("TRC_GRID_FORCE32"); if (ev && atoi(ev)) sc->accel.grid_ok = false; }      // (measurements: the large grid for a scene the LDS-sized one holds)
     dev_free(sc->d_a_goff); dev_free(sc->d_a_glist); dev_free(sc->d_a_gapart);
     sc->d_a_goff = nullptr; sc->d_a_glist = nullptr; sc->d_a_gapart = nullptr;
     if (sc->accel.grid_ok) {
